@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Tanimoto top-1000 scan of synthetic 1024-bit tables.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one query: the packed table resident in HBM is scanned once, the exact
+top-k is selected, (N > 1: per-GPU top-k blocks are all-gathered over RCCL/xGMI and
+merged), and the k hits land in host memory.  Weak scaling: every rank holds
+--rows-per-gpu rows (default 100 M at N = 1 = BASELINE.json configs[2], the
+HBM-bound roofline run; 125 M at N > 1 so that 8 GPUs hold the 1 B-row table of
+configs[3]).  value = rows of the whole table * steps / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  The `roofline` object is the scan kernel's
+algorithmic bytes (128 B per fingerprint per pass) over its HIP-event duration on
+the stream it runs on; `cpu_baseline` times the reference's host functor path
+(oracle/_ref when present, else the oracle port) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: one HIP runtime in the process, see capi.load)
+import torch.distributed as dist  # noqa: E402
+
+from gpusimilarity_amd import capi  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+DB_SEED = 0x5EED0001
+GOLDEN = 0x9E3779B97F4A7C15
+M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    z = (x + GOLDEN) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def synth_row(seed, kind, row, W):
+    """Host twin of the device generator for one row -- used to make the
+    query fingerprints (queries are rows of the table: guaranteed score-1.0 self hit)."""
+    out = np.zeros(W, dtype=np.uint32)
+    for j in range(W):
+        ctr = row * W + j
+        if kind == capi.SYNTH_DENSE:
+            out[j] = _splitmix64((seed + ctr * GOLDEN) & M64) & 0xFFFFFFFF
+        else:
+            h0 = _splitmix64((seed + (2 * ctr) * GOLDEN) & M64)
+            h1 = _splitmix64((seed + (2 * ctr + 1) * GOLDEN) & M64)
+            out[j] = (h0 & 0xFFFFFFFF) & (h0 >> 32) & (h1 & 0xFFFFFFFF) & (h1 >> 32)
+    return out
+
+
+def query_row(q, nrows):
+    return _splitmix64((0xC0FFEE + q) & M64) % nrows
+
+
+def cpu_baseline(fp_bits, k, kind, budget_s=12.0):
+    """The reference's host functor path on this box's cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    W = fp_bits // 32
+    cores = os.cpu_count() or 1
+    n = 2_000_000
+    db = O.synth_rows(DB_SEED, kind, 0, n, W)
+    q = db[query_row(0, n)]
+    use_ref = O.ref_lib() is not None
+    if use_ref:
+        tab = O.RefTable(db)
+        run = lambda: tab.scan(q, nthreads=cores)  # noqa: E731
+        what = "reference TanimotoFunctorCPU (calculation_functors.cpp compiled in place, oracle/_ref), scoring only"
+    else:
+        run = lambda: O.search(q, db, k, 0.0, nthreads=cores)  # noqa: E731
+        what = "oracle port gso_search (scan + heap top-%d)" % k
+    run()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 200:
+            break
+    return {"value": n * reps / el, "unit": "fingerprints/s", "cores": cores,
+            "kind": "reference" if use_ref else "port",
+            "sample": "%d queries over a %d-row x %d-bit synthetic slice, %d threads, %.1f s; %s" %
+                      (reps, n, fp_bits, cores, el, what)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows-per-gpu", type=int, default=0)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--fp-bits", type=int, default=1024)
+    ap.add_argument("--kind", choices=["sparse", "dense"], default="sparse")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    R = args.rows_per_gpu or (100_000_000 if world == 1 else 125_000_000)
+    total_rows = R * world
+    kind = capi.SYNTH_SPARSE if args.kind == "sparse" else capi.SYNTH_DENSE
+    W = args.fp_bits // 32
+    k = args.k
+
+    table = capi.Table(args.fp_bits)
+    table.generate(DB_SEED, kind, rank * R, R, local_rank)  # this rank's contiguous shard, made in HBM
+    table.set_row_base(rank * R)
+    stream = torch.cuda.Stream(device=dev)
+    table.set_stream(stream.cuda_stream)
+
+    blk = capi.result_block_bytes(k)
+    nq = args.warmup + args.steps
+    queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(nq)]
+    with torch.cuda.stream(stream):
+        local_block = torch.zeros(blk, dtype=torch.uint8, device=dev)
+        gathered = torch.zeros(blk * world, dtype=torch.uint8, device=dev) if world > 1 else None
+        merged = torch.zeros(blk, dtype=torch.uint8, device=dev) if world > 1 else None
+    host_out = torch.zeros(blk, dtype=torch.uint8).pin_memory()
+
+    def one_query(q):
+        with torch.cuda.stream(stream):
+            table.search_device(q, k, local_block.data_ptr())
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, local_block)  # RCCL over xGMI: k*12 B per GPU
+                capi.merge_device(local_rank, stream.cuda_stream, gathered.data_ptr(), world, blk, k,
+                                  merged.data_ptr())
+                host_out.copy_(merged, non_blocking=True)
+            else:
+                host_out.copy_(local_block, non_blocking=True)
+        stream.synchronize()  # the query is done when its k hits are in host memory
+
+    for i in range(args.warmup):
+        one_query(queries[i])
+    # sanity on the last warm-up query: the self hit leads the result
+    if args.warmup:
+        hits, approx, _ = capi.parse_result_block(host_out.numpy().tobytes(), k)
+        want_row = query_row(args.warmup - 1, total_rows)
+        assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
+            "self hit missing: %r" % (hits[:3],)
+        assert approx == total_rows
+
+    table.enable_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nq):
+        one_query(queries[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = table.timing()
+
+    if rank == 0:
+        steps = args.steps
+        ms = 1e3 * elapsed / steps
+        scan_ms = tm["scan_ms_sum"] / max(1, tm["queries"])
+        algo_bytes = R * (args.fp_bits // 8)  # per scan-kernel launch on one GPU
+        achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "fingerprints scanned/sec (1024-bit Tanimoto top-1000)",
+            "value": total_rows * steps / elapsed,
+            "unit": "fingerprints/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": ms, "ms_per_query": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {
+                "workload": ("%d x %d-bit %s synthetic fingerprints per GPU x %d GPU(s) = %d rows, Tanimoto top-%d, "
+                             "cutoff 0; %s" % (R, args.fp_bits, args.kind, world, total_rows, k,
+                                               "BASELINE configs[2] (100M x 1024-bit, 1 MI355X, HBM-bound roofline run)"
+                                               if world == 1 and R == 100_000_000 else
+                                               "BASELINE configs[3] shape (1B x 1024-bit over 8 GPUs = 125M rows/GPU), "
+                                               "per-GPU top-k + RCCL all-gather + merge")),
+                "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "metric": "tanimoto",
+                "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of top-k blocks" if world > 1 else ""),
+            },
+            "whole_path_hbm_frac": (total_rows * (args.fp_bits // 8) / (elapsed / steps)) / (HBM_PEAK_GBS * 1e9 * world),
+            "roofline": {
+                "kernel": "scan_kernel<8,8>" if args.fp_bits == 1024 else "scan_kernel",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "scan_ms_avg": scan_ms, "select_ms_avg": tm["select_ms_sum"] / max(1, tm["queries"]),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "candidates_per_query": tm["candidates_sum"] / max(1, tm["queries"]),
+                "finalists_per_query": tm["finalists_sum"] / max(1, tm["queries"]),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            table.close()
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.fp_bits, k, kind)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "fingerprints/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

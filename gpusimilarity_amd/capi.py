@@ -1,0 +1,258 @@
+"""ctypes binding of the C ABI in ``include/gpusim_hip.h`` (libgsim_hip.so).
+
+This is the only way Python reaches the GPU in this package: there is no
+PyTorch/numpy fallback.  If the library is missing or no GPU is usable the calls
+fail loudly (``GsimError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsim_hip.so")
+
+OK = 0
+METRIC_TANIMOTO = 0
+METRIC_TVERSKY = 1
+SYNTH_SPARSE = 0
+SYNTH_DENSE = 1
+SELECT_CAP = 8192
+
+HIT_DTYPE = np.dtype([("row", "<u4"), ("score", "<f4"), ("common", "<u2"), ("popc_db", "<u2")])
+HEADER_DTYPE = np.dtype([("count", "<u4"), ("flags", "<u4"), ("approx", "<u8")])
+
+
+class GsimTiming(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("scan_ms_sum", C.c_double), ("select_ms_sum", C.c_double),
+                ("candidates_sum", C.c_uint64), ("finalists_sum", C.c_uint64)]
+
+
+class GsimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gsim error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+EXPORTS = [
+    "gsim_device_count", "gsim_device_free_bytes", "gsim_available_device_bytes", "gsim_next_device",
+    "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_generate", "gsim_db_attach_device_rows",
+    "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
+    "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
+    "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_enable_timing",
+    "gsim_db_get_timing", "gsim_debug_score_table", "gsim_last_error", "gsim_version",
+]
+
+
+def load():
+    """Load libgsim_hip.so.  PyTorch (when importable) is imported FIRST so that the
+    process holds exactly one HIP runtime: torch ships its own libamdhip64.so.7 and
+    the dynamic linker then resolves our NEEDED entry to that same object."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsimError(-100, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C gpusimilarity_amd/csrc`" % LIB_PATH)
+    if os.environ.get("GSIM_NO_TORCH", "") != "1" and "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing, not a requirement of the ABI
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    u32p, u64p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
+    sig = {
+        "gsim_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "gsim_device_free_bytes": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
+        "gsim_available_device_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
+        "gsim_next_device": (C.c_int, [C.c_size_t, C.POINTER(C.c_int)]),
+        "gsim_db_create": (C.c_int, [C.c_uint32, C.POINTER(vp)]),
+        "gsim_db_add_rows": (C.c_int, [vp, u32p, C.c_uint64]),
+        "gsim_db_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gsim_db_generate": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
+        "gsim_db_attach_device_rows": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
+        "gsim_db_destroy": (C.c_int, [vp]),
+        "gsim_db_count": (C.c_uint64, [vp]),
+        "gsim_db_fp_bits": (C.c_uint32, [vp]),
+        "gsim_db_data_bytes": (C.c_size_t, [vp]),
+        "gsim_db_row": (C.c_int, [vp, C.c_uint64, u32p]),
+        "gsim_db_shard_count": (C.c_int, [vp]),
+        "gsim_db_search": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float,
+                                     vp, u32p, u64p]),
+        "gsim_db_search_cpu": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, vp, u32p]),
+        "gsim_db_set_stream": (C.c_int, [vp, vp]),
+        "gsim_db_set_row_base": (C.c_int, [vp, C.c_uint32]),
+        "gsim_result_block_bytes": (C.c_size_t, [C.c_uint32]),
+        "gsim_db_search_device": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float, vp]),
+        "gsim_merge_device": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
+        "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
+        "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
+        "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.POINTER(C.c_float)]),
+        "gsim_last_error": (C.c_char_p, []),
+        "gsim_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise GsimError(rc, load().gsim_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().gsim_device_count(C.byref(n)))
+    return n.value
+
+
+def device_free_bytes(device: int) -> int:
+    v = C.c_size_t(0)
+    check(load().gsim_device_free_bytes(device, C.byref(v)))
+    return v.value
+
+
+def available_device_bytes() -> int:
+    v = C.c_size_t(0)
+    check(load().gsim_available_device_bytes(C.byref(v)))
+    return v.value
+
+
+def next_device(required_bytes: int) -> int:
+    d = C.c_int(-1)
+    check(load().gsim_next_device(required_bytes, C.byref(d)))
+    return d.value
+
+
+def result_block_bytes(k: int) -> int:
+    return int(load().gsim_result_block_bytes(k))
+
+
+def _u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Table:
+    """A fingerprint table on the GPU(s): thin object wrapper over ``gsim_db``."""
+
+    def __init__(self, fp_bits: int):
+        self._L = load()
+        h = C.c_void_p()
+        check(self._L.gsim_db_create(fp_bits, C.byref(h)))
+        self._h = h
+        self.fp_bits = fp_bits
+        self.W = fp_bits // 32
+
+    # -- lifecycle ---------------------------------------------------------
+    def add_rows(self, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, self.W)
+        check(self._L.gsim_db_add_rows(self._h, _u32(rows), rows.shape[0]))
+        return self
+
+    def finalize(self, device: int = 0, ndevices: int = 1):
+        check(self._L.gsim_db_finalize(self._h, device, ndevices))
+        return self
+
+    def generate(self, seed: int, kind: int, first_row: int, nrows: int, device: int = 0):
+        check(self._L.gsim_db_generate(self._h, seed, kind, first_row, nrows, device))
+        return self
+
+    def attach_device_rows(self, ptr: int, nrows: int, device: int = 0):
+        check(self._L.gsim_db_attach_device_rows(self._h, C.c_void_p(ptr), nrows, device))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsim_db_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- accessors -----------------------------------------------------------
+    def count(self) -> int:
+        return int(self._L.gsim_db_count(self._h))
+
+    def data_bytes(self) -> int:
+        return int(self._L.gsim_db_data_bytes(self._h))
+
+    def shard_count(self) -> int:
+        return int(self._L.gsim_db_shard_count(self._h))
+
+    def row(self, i: int) -> np.ndarray:
+        out = np.empty(self.W, dtype=np.uint32)
+        check(self._L.gsim_db_row(self._h, i, _u32(out)))
+        return out
+
+    # -- search ----------------------------------------------------------------
+    def search(self, queries, k, cutoff=0.0, metric=METRIC_TANIMOTO, alpha=1.0, beta=1.0):
+        """-> (list of HIT_DTYPE arrays, one per query; approx uint64 array)"""
+        q = np.ascontiguousarray(queries, dtype=np.uint32).reshape(-1, self.W)
+        nq = q.shape[0]
+        hits = np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE)
+        counts = np.zeros(nq, dtype=np.uint32)
+        approx = np.zeros(nq, dtype=np.uint64)
+        check(self._L.gsim_db_search(self._h, _u32(q), nq, k, cutoff, metric, alpha, beta,
+                                     hits.ctypes.data_as(C.c_void_p), _u32(counts),
+                                     approx.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return [hits[i, :counts[i]].copy() for i in range(nq)], approx
+
+    def search_cpu(self, queries, k, cutoff=0.0):
+        q = np.ascontiguousarray(queries, dtype=np.uint32).reshape(-1, self.W)
+        nq = q.shape[0]
+        hits = np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE)
+        counts = np.zeros(nq, dtype=np.uint32)
+        check(self._L.gsim_db_search_cpu(self._h, _u32(q), nq, k, cutoff, hits.ctypes.data_as(C.c_void_p),
+                                         _u32(counts)))
+        return [hits[i, :counts[i]].copy() for i in range(nq)]
+
+    def set_stream(self, stream_ptr: int):
+        check(self._L.gsim_db_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_row_base(self, base: int):
+        check(self._L.gsim_db_set_row_base(self._h, base))
+
+    def search_device(self, query, k, d_result_ptr, cutoff=0.0, metric=METRIC_TANIMOTO, alpha=1.0, beta=1.0):
+        q = np.ascontiguousarray(query, dtype=np.uint32).reshape(self.W)
+        check(self._L.gsim_db_search_device(self._h, _u32(q), k, cutoff, metric, alpha, beta,
+                                            C.c_void_p(d_result_ptr)))
+
+    def enable_timing(self, enable=True):
+        check(self._L.gsim_db_enable_timing(self._h, 1 if enable else 0))
+
+    def timing(self) -> dict:
+        t = GsimTiming()
+        check(self._L.gsim_db_get_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in GsimTiming._fields_}
+
+
+def merge_device(device, stream_ptr, d_blocks_ptr, nblocks, block_bytes, k, d_result_ptr):
+    check(load().gsim_merge_device(device, C.c_void_p(stream_ptr), C.c_void_p(d_blocks_ptr), nblocks, block_bytes, k,
+                                   C.c_void_p(d_result_ptr)))
+
+
+def parse_result_block(buf: bytes, k: int):
+    """bytes of one result block -> (HIT_DTYPE array, approx, flags)"""
+    hdr = np.frombuffer(buf, dtype=HEADER_DTYPE, count=1)[0]
+    hits = np.frombuffer(buf, dtype=HIT_DTYPE, count=int(hdr["count"]), offset=HEADER_DTYPE.itemsize)
+    return hits.copy(), int(hdr["approx"]), int(hdr["flags"])
+
+
+def debug_score_table(metric, alpha, beta, a, max_b, max_c, device=0) -> np.ndarray:
+    out = np.empty((max_c + 1, max_b + 1), dtype=np.float32)
+    check(load().gsim_debug_score_table(device, metric, alpha, beta, a, max_b, max_c,
+                                        out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out

@@ -1,0 +1,733 @@
+// gsim_capi.cpp -- implementation of the C ABI in include/gpusim_hip.h.
+//
+// Host side of the scan engine: table placement (shards), per-query launch
+// sequence (scan -> compact -> select), result transfer, host merge across
+// in-process shards, the reference's explicit CPU path, timing.  All device work
+// goes through gsim_device.h.  No exception crosses the ABI.
+#include "../../include/gpusim_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gsim_device.h"
+
+namespace
+{
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char* what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return GSIM_ERR_HIP;
+}
+
+#define GSIM_HIP(call)                                   \
+    do {                                                 \
+        hipError_t e__ = (call);                         \
+        if (e__ != hipSuccess) return fail_hip(e__, #call); \
+    } while (0)
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return std::atoi(v);
+}
+
+constexpr int kTimingRing = 1024;
+constexpr int kQueryRing = 16;
+
+struct Shard {
+    int device = 0;
+    int num_cus = 256;
+    uint64_t first_row = 0; // offset inside the handle's table
+    uint64_t nrows = 0;
+    void* d_rows = nullptr;
+    bool owns_rows = false;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr; // the stream in use (own or caller's)
+    gsim::ScanGeometry geo{};
+    uint32_t* d_query = nullptr;
+    gsim::QueryState* d_state = nullptr;
+    unsigned long long* d_cand = nullptr;
+    uint32_t* d_seg_count = nullptr;
+    unsigned long long* d_final = nullptr;
+    uint32_t final_cap = 0;
+    void* d_result = nullptr;
+    size_t result_bytes = 0;
+    // pinned host staging; queries go through a ring so that back-to-back
+    // asynchronous searches never overwrite a query whose upload is still queued
+    uint32_t* h_query = nullptr; // kQueryRing slots of W words
+    std::vector<hipEvent_t> q_ev; // upload-done event per slot
+    uint32_t q_next = 0;
+    unsigned char* h_result = nullptr;
+    size_t h_result_bytes = 0;
+    gsim::QueryState* h_state = nullptr; // ring of kTimingRing entries (stats only)
+    // timing
+    std::vector<hipEvent_t> ev; // 3 per slot
+    uint32_t ev_used = 0;
+};
+
+} // namespace
+
+struct gsim_db {
+    uint32_t fp_bits = 0;
+    uint32_t W = 0;
+    uint64_t nrows = 0;
+    std::vector<uint32_t> host_rows; // host copy (reference: m_data)
+    bool has_host_copy = false;
+    bool finalized = false;
+    std::vector<Shard> shards;
+    uint32_t row_base = 0;
+    bool timing = false;
+    gsim_timing acc{};
+};
+
+namespace
+{
+
+int free_shard(Shard& s)
+{
+    (void) hipSetDevice(s.device);
+    if (s.stream) (void) hipStreamSynchronize(s.stream);
+    if (s.owns_rows && s.d_rows) (void) hipFree(s.d_rows);
+    if (s.d_query) (void) hipFree(s.d_query);
+    if (s.d_state) (void) hipFree(s.d_state);
+    if (s.d_cand) (void) hipFree(s.d_cand);
+    if (s.d_seg_count) (void) hipFree(s.d_seg_count);
+    if (s.d_final) (void) hipFree(s.d_final);
+    if (s.d_result) (void) hipFree(s.d_result);
+    if (s.h_query) (void) hipHostFree(s.h_query);
+    if (s.h_result) (void) hipHostFree(s.h_result);
+    if (s.h_state) (void) hipHostFree(s.h_state);
+    for (auto e : s.ev) (void) hipEventDestroy(e);
+    for (auto e : s.q_ev) (void) hipEventDestroy(e);
+    if (s.own_stream) (void) hipStreamDestroy(s.own_stream);
+    s = Shard{};
+    return 0;
+}
+
+uint32_t next_pow2_u32(uint64_t x)
+{
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p > 0x80000000ull ? 0x80000000u : static_cast<uint32_t>(p);
+}
+
+// Allocate the per-shard search scratch once the rows are in place.
+int setup_shard(gsim_db* db, Shard& s)
+{
+    GSIM_HIP(hipSetDevice(s.device));
+    hipDeviceProp_t prop;
+    GSIM_HIP(hipGetDeviceProperties(&prop, s.device));
+    s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    GSIM_HIP(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
+    s.stream = s.own_stream;
+    const int wpc = env_int("GSIM_SCAN_WAVES_PER_CU", 8);
+    const int unroll = env_int("GSIM_SCAN_UNROLL", 8);
+    s.geo = gsim::scan_geometry(s.nrows, db->W, s.num_cus, wpc, unroll);
+    const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
+    GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(db->W) * 4));
+    GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
+    GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
+    GSIM_HIP(hipMalloc(&s.d_seg_count, static_cast<size_t>(s.geo.nwaves) * 4));
+    s.final_cap = next_pow2_u32(slots);
+    GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
+    GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(db->W) * 4 * kQueryRing, hipHostMallocDefault));
+    for (int i = 0; i < kQueryRing; i++) {
+        hipEvent_t e;
+        GSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s.q_ev.push_back(e);
+    }
+    GSIM_HIP(hipHostMalloc(&s.h_state, sizeof(gsim::QueryState) * kTimingRing, hipHostMallocDefault));
+    return GSIM_OK;
+}
+
+int ensure_result_capacity(Shard& s, uint32_t k)
+{
+    const size_t need = gsim_result_block_bytes(k);
+    if (need > s.result_bytes) {
+        GSIM_HIP(hipSetDevice(s.device));
+        if (s.d_result) GSIM_HIP(hipFree(s.d_result));
+        s.d_result = nullptr;
+        GSIM_HIP(hipMalloc(&s.d_result, need));
+        s.result_bytes = need;
+    }
+    if (need > s.h_result_bytes) {
+        if (s.h_result) GSIM_HIP(hipHostFree(s.h_result));
+        s.h_result = nullptr;
+        GSIM_HIP(hipHostMalloc(&s.h_result, need, hipHostMallocDefault));
+        s.h_result_bytes = need;
+    }
+    return GSIM_OK;
+}
+
+uint32_t popcount_words(const uint32_t* q, uint32_t W)
+{
+    uint32_t a = 0;
+    for (uint32_t i = 0; i < W; i++) a += static_cast<uint32_t>(__builtin_popcount(q[i]));
+    return a;
+}
+
+// Enqueue one query on one shard; the result block ends up at d_out (device).
+// Nothing here synchronises with the host unless k > kSelectCap.
+int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                  float beta, uint32_t row_base, void* d_out)
+{
+    GSIM_HIP(hipSetDevice(s.device));
+    const uint32_t slot = s.q_next++ % kQueryRing;
+    uint32_t* hq = s.h_query + static_cast<size_t>(slot) * db->W;
+    GSIM_HIP(hipEventSynchronize(s.q_ev[slot])); // no-op unless 16 searches are still queued
+    std::memcpy(hq, query, static_cast<size_t>(db->W) * 4);
+    GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(db->W) * 4, hipMemcpyHostToDevice, s.stream));
+    GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream));
+    GSIM_HIP(hipMemsetAsync(s.d_state, 0, sizeof(gsim::QueryState), s.stream));
+
+    gsim::ScanArgs a{};
+    a.rows = s.d_rows;
+    a.nrows = s.nrows;
+    a.W = db->W;
+    a.query = s.d_query;
+    a.qpop = popcount_words(query, db->W);
+    a.k = k;
+    a.cutoff = cutoff;
+    a.metric = metric;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.cand = s.d_cand;
+    a.seg_count = s.d_seg_count;
+    a.state = s.d_state;
+
+    hipEvent_t* ev = nullptr;
+    if (db->timing && s.ev_used < kTimingRing) {
+        if (s.ev.size() < static_cast<size_t>(3 * (s.ev_used + 1))) {
+            for (int i = 0; i < 3; i++) {
+                hipEvent_t e;
+                GSIM_HIP(hipEventCreate(&e));
+                s.ev.push_back(e);
+            }
+        }
+        ev = &s.ev[3 * s.ev_used];
+    }
+    if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+    if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
+    if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
+    if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.final_cap, s.stream));
+    if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
+        GSIM_HIP(gsim::launch_select(a, s.d_final, s.final_cap, row_base, d_out, s.stream));
+    } else {
+        // large k: sort every finalist in global memory (host reads the count)
+        uint32_t nfinal = 0;
+        GSIM_HIP(hipMemcpyAsync(&nfinal, &s.d_state->nfinal, 4, hipMemcpyDeviceToHost, s.stream));
+        GSIM_HIP(hipStreamSynchronize(s.stream));
+        if (nfinal > s.final_cap) nfinal = s.final_cap;
+        const uint32_t np2 = next_pow2_u32(nfinal ? nfinal : 1);
+        GSIM_HIP(gsim::launch_fill_zero_keys(s.d_final, nfinal, np2, s.stream));
+        GSIM_HIP(gsim::launch_bitonic_global(s.d_final, np2, s.stream));
+        const uint32_t nout = nfinal < k ? nfinal : k;
+        GSIM_HIP(gsim::launch_emit_hits(a, s.d_final, nout, row_base, s.nrows, 1u, d_out, s.stream));
+    }
+    if (ev) {
+        GSIM_HIP(hipEventRecord(ev[2], s.stream));
+        GSIM_HIP(hipMemcpyAsync(&s.h_state[s.ev_used], s.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost,
+                                s.stream));
+        s.ev_used++;
+    }
+    return GSIM_OK;
+}
+
+// Fold the recorded events of a shard into the handle's accumulators.
+int drain_timing(gsim_db* db, Shard& s)
+{
+    if (s.ev_used == 0) return GSIM_OK;
+    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(hipStreamSynchronize(s.stream));
+    for (uint32_t i = 0; i < s.ev_used; i++) {
+        float scan = 0.f, sel = 0.f;
+        GSIM_HIP(hipEventElapsedTime(&scan, s.ev[3 * i], s.ev[3 * i + 1]));
+        GSIM_HIP(hipEventElapsedTime(&sel, s.ev[3 * i + 1], s.ev[3 * i + 2]));
+        db->acc.scan_ms_sum += scan;
+        db->acc.select_ms_sum += sel;
+        db->acc.candidates_sum += s.h_state[i].ncand;
+        db->acc.finalists_sum += s.h_state[i].nfinal;
+        db->acc.queries++;
+    }
+    s.ev_used = 0;
+    return GSIM_OK;
+}
+
+bool hit_before(const gsim_hit& x, const gsim_hit& y)
+{
+    if (x.score > y.score) return true;
+    if (x.score < y.score) return false;
+    return x.row < y.row;
+}
+
+std::mutex g_rr_mutex;
+int g_next_device = 0;
+
+} // namespace
+
+extern "C" {
+
+const char* gsim_last_error(void)
+{
+    return g_last_error.c_str();
+}
+
+const char* gsim_version(void)
+{
+    return "gpusimilarity_amd 0.1 (gfx950)";
+}
+
+int gsim_device_count(int* count)
+{
+    if (!count) return fail(GSIM_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        // reference get_gpu_count() reports 0 GPUs rather than failing (fingerprintdb_cuda.cu:40-52)
+        (void) hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return GSIM_OK;
+}
+
+int gsim_device_free_bytes(int device, size_t* free_bytes)
+{
+    if (!free_bytes) return fail(GSIM_ERR_INVALID, "free_bytes is NULL");
+    int n = 0;
+    gsim_device_count(&n);
+    if (device < 0 || device >= n) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    GSIM_HIP(hipSetDevice(device));
+    size_t fr = 0, tot = 0;
+    GSIM_HIP(hipMemGetInfo(&fr, &tot));
+    *free_bytes = fr;
+    return GSIM_OK;
+}
+
+int gsim_available_device_bytes(size_t* total_free_bytes)
+{
+    if (!total_free_bytes) return fail(GSIM_ERR_INVALID, "total_free_bytes is NULL");
+    int n = 0;
+    gsim_device_count(&n);
+    size_t sum = 0;
+    for (int d = 0; d < n; d++) {
+        size_t fr = 0;
+        int rc = gsim_device_free_bytes(d, &fr);
+        if (rc != GSIM_OK) return rc;
+        sum += fr;
+    }
+    *total_free_bytes = sum;
+    return GSIM_OK;
+}
+
+int gsim_next_device(size_t required_bytes, int* device)
+{
+    if (!device) return fail(GSIM_ERR_INVALID, "device is NULL");
+    int n = 0;
+    gsim_device_count(&n);
+    if (n == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");
+    std::lock_guard<std::mutex> lock(g_rr_mutex);
+    for (int i = 0; i < n; i++) {
+        const int d = g_next_device++ % n;
+        size_t fr = 0;
+        int rc = gsim_device_free_bytes(d, &fr);
+        if (rc != GSIM_OK) return rc;
+        if (fr > required_bytes) {
+            *device = d;
+            return GSIM_OK;
+        }
+    }
+    return fail(GSIM_ERR_NOMEM, "Can't find a GPU with enough memory to copy data.");
+}
+
+int gsim_db_create(uint32_t fp_bits, gsim_db** out)
+{
+    if (!out) return fail(GSIM_ERR_INVALID, "out is NULL");
+    if (fp_bits == 0 || fp_bits % 32 != 0 || fp_bits > 32768)
+        return fail(GSIM_ERR_INVALID, "fp_bits must be a positive multiple of 32, <= 32768");
+    gsim_db* db = new (std::nothrow) gsim_db;
+    if (!db) return fail(GSIM_ERR_NOMEM, "out of host memory");
+    db->fp_bits = fp_bits;
+    db->W = fp_bits / 32;
+    *out = db;
+    return GSIM_OK;
+}
+
+int gsim_db_add_rows(gsim_db* db, const uint32_t* rows, uint64_t nrows)
+{
+    if (!db || (!rows && nrows)) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (db->finalized) return fail(GSIM_ERR_STATE, "table already finalized");
+    if (db->nrows + nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
+    try {
+        db->host_rows.insert(db->host_rows.end(), rows, rows + nrows * db->W);
+    } catch (const std::bad_alloc&) {
+        return fail(GSIM_ERR_NOMEM, "out of host memory");
+    }
+    db->nrows += nrows;
+    db->has_host_copy = true;
+    return GSIM_OK;
+}
+
+int gsim_db_finalize(gsim_db* db, int device, int ndevices)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    if (db->finalized) return fail(GSIM_ERR_STATE, "table already finalized");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (ndev == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");
+    if (ndevices == 0) {
+        ndevices = ndev;
+        if (device < 0) device = 0;
+    }
+    if (ndevices < 0) return fail(GSIM_ERR_INVALID, "ndevices < 0");
+    const size_t row_bytes = static_cast<size_t>(db->W) * 4;
+    if (ndevices == 1 && device < 0) {
+        int rc = gsim_next_device(static_cast<size_t>(db->nrows) * row_bytes, &device);
+        if (rc != GSIM_OK) return rc;
+    }
+    if (device < 0) device = 0;
+    if (device + ndevices > ndev) return fail(GSIM_ERR_NO_DEVICE, "device range exceeds the GPUs present");
+    if (static_cast<uint64_t>(ndevices) > db->nrows && db->nrows > 0) ndevices = static_cast<int>(db->nrows);
+    const uint64_t per = (db->nrows + ndevices - 1) / (ndevices ? ndevices : 1);
+    db->shards.resize(static_cast<size_t>(ndevices));
+    for (int i = 0; i < ndevices; i++) {
+        Shard& s = db->shards[i];
+        s.device = device + i;
+        s.first_row = std::min<uint64_t>(per * i, db->nrows);
+        s.nrows = std::min<uint64_t>(per, db->nrows - s.first_row);
+        GSIM_HIP(hipSetDevice(s.device));
+        const size_t bytes = static_cast<size_t>(s.nrows) * row_bytes;
+        GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
+        s.owns_rows = true;
+        if (bytes)
+            GSIM_HIP(hipMemcpy(s.d_rows, db->host_rows.data() + s.first_row * db->W, bytes, hipMemcpyHostToDevice));
+        int rc = setup_shard(db, s);
+        if (rc != GSIM_OK) return rc;
+    }
+    db->finalized = true;
+    return GSIM_OK;
+}
+
+int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows, int device)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    if (db->finalized || db->nrows) return fail(GSIM_ERR_STATE, "table already holds rows");
+    if (kind != GSIM_SYNTH_SPARSE && kind != GSIM_SYNTH_DENSE) return fail(GSIM_ERR_INVALID, "unknown synthetic kind");
+    if (nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (ndev == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");
+    if (device < 0 || device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    db->nrows = nrows;
+    db->shards.resize(1);
+    Shard& s = db->shards[0];
+    s.device = device;
+    s.first_row = 0;
+    s.nrows = nrows;
+    GSIM_HIP(hipSetDevice(device));
+    const size_t bytes = static_cast<size_t>(nrows) * db->W * 4;
+    GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
+    s.owns_rows = true;
+    int rc = setup_shard(db, s);
+    if (rc != GSIM_OK) return rc;
+    GSIM_HIP(gsim::launch_generate(s.d_rows, seed, kind, first_row, nrows, db->W, s.stream));
+    GSIM_HIP(hipStreamSynchronize(s.stream));
+    db->finalized = true;
+    return GSIM_OK;
+}
+
+int gsim_db_attach_device_rows(gsim_db* db, const void* d_rows, uint64_t nrows, int device)
+{
+    if (!db || (!d_rows && nrows)) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (db->finalized || db->nrows) return fail(GSIM_ERR_STATE, "table already holds rows");
+    if (reinterpret_cast<uintptr_t>(d_rows) % 16 != 0) return fail(GSIM_ERR_INVALID, "device rows must be 16-byte aligned");
+    if (nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (device < 0 || device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    db->nrows = nrows;
+    db->shards.resize(1);
+    Shard& s = db->shards[0];
+    s.device = device;
+    s.nrows = nrows;
+    s.d_rows = const_cast<void*>(d_rows);
+    s.owns_rows = false;
+    int rc = setup_shard(db, s);
+    if (rc != GSIM_OK) return rc;
+    db->finalized = true;
+    return GSIM_OK;
+}
+
+int gsim_db_destroy(gsim_db* db)
+{
+    if (!db) return GSIM_OK;
+    for (auto& s : db->shards) free_shard(s);
+    delete db;
+    return GSIM_OK;
+}
+
+uint64_t gsim_db_count(const gsim_db* db)
+{
+    return db ? db->nrows : 0;
+}
+
+uint32_t gsim_db_fp_bits(const gsim_db* db)
+{
+    return db ? db->fp_bits : 0;
+}
+
+size_t gsim_db_data_bytes(const gsim_db* db)
+{
+    return db ? static_cast<size_t>(db->nrows) * db->W * 4 : 0;
+}
+
+int gsim_db_shard_count(const gsim_db* db)
+{
+    return db ? static_cast<int>(db->shards.size()) : 0;
+}
+
+int gsim_db_row(const gsim_db* db, uint64_t row, uint32_t* out_words)
+{
+    if (!db || !out_words) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (row >= db->nrows) return fail(GSIM_ERR_INVALID, "row index out of range");
+    if (db->has_host_copy) {
+        std::memcpy(out_words, db->host_rows.data() + row * db->W, static_cast<size_t>(db->W) * 4);
+        return GSIM_OK;
+    }
+    for (const auto& s : db->shards) {
+        if (row >= s.first_row && row < s.first_row + s.nrows) {
+            GSIM_HIP(hipSetDevice(s.device));
+            const unsigned char* src = static_cast<const unsigned char*>(s.d_rows) +
+                                       static_cast<size_t>(row - s.first_row) * db->W * 4;
+            GSIM_HIP(hipMemcpy(out_words, src, static_cast<size_t>(db->W) * 4, hipMemcpyDeviceToHost));
+            return GSIM_OK;
+        }
+    }
+    return fail(GSIM_ERR_STATE, "row not resident");
+}
+
+int gsim_db_set_stream(gsim_db* db, void* hip_stream)
+{
+    if (!db || !db->finalized) return fail(GSIM_ERR_STATE, "table not finalized");
+    if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "set_stream needs a single-shard handle");
+    Shard& s = db->shards[0];
+    s.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s.own_stream;
+    return GSIM_OK;
+}
+
+int gsim_db_set_row_base(gsim_db* db, uint32_t row_base)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    db->row_base = row_base;
+    return GSIM_OK;
+}
+
+size_t gsim_result_block_bytes(uint32_t k)
+{
+    const size_t raw = sizeof(gsim_result_header) + static_cast<size_t>(k) * sizeof(gsim_hit);
+    return (raw + 15) / 16 * 16;
+}
+
+static int check_search_args(gsim_db* db, const uint32_t* queries, int metric)
+{
+    if (!db || !queries) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (!db->finalized) return fail(GSIM_ERR_STATE, "table not finalized (no rows on a GPU)");
+    if (metric != GSIM_METRIC_TANIMOTO && metric != GSIM_METRIC_TVERSKY) return fail(GSIM_ERR_INVALID, "unknown metric");
+    return GSIM_OK;
+}
+
+int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+                   float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    int rc = check_search_args(db, queries, metric);
+    if (rc != GSIM_OK) return rc;
+    if ((!hits && k && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
+    const size_t nsh = db->shards.size();
+    const size_t blk = gsim_result_block_bytes(k);
+    std::vector<gsim_hit> merged;
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
+        for (auto& s : db->shards) {
+            rc = ensure_result_capacity(s, k);
+            if (rc != GSIM_OK) return rc;
+            rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta,
+                               db->row_base + static_cast<uint32_t>(s.first_row), s.d_result);
+            if (rc != GSIM_OK) return rc;
+            GSIM_HIP(hipMemcpyAsync(s.h_result, s.d_result, blk, hipMemcpyDeviceToHost, s.stream));
+        }
+        uint64_t ap = 0;
+        merged.clear();
+        for (auto& s : db->shards) {
+            GSIM_HIP(hipSetDevice(s.device));
+            GSIM_HIP(hipStreamSynchronize(s.stream));
+            const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
+            const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+            ap += h->approx;
+            if (nsh == 1) {
+                std::memcpy(hits + static_cast<size_t>(q) * k, hh, sizeof(gsim_hit) * h->count);
+                counts[q] = h->count;
+            } else {
+                merged.insert(merged.end(), hh, hh + h->count);
+            }
+        }
+        if (nsh > 1) {
+            // FingerprintDB::search's host merge: std::sort + truncate (fingerprintdb_cuda.cu:363-380)
+            std::sort(merged.begin(), merged.end(), hit_before);
+            const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
+            std::memcpy(hits + static_cast<size_t>(q) * k, merged.data(), sizeof(gsim_hit) * n);
+            counts[q] = n;
+        }
+        if (approx) approx[q] = ap;
+    }
+    return GSIM_OK;
+}
+
+int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                          float beta, void* d_result)
+{
+    int rc = check_search_args(db, query, metric);
+    if (rc != GSIM_OK) return rc;
+    if (!d_result) return fail(GSIM_ERR_INVALID, "d_result is NULL");
+    if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "search_device needs a single-shard handle");
+    Shard& s = db->shards[0];
+    return enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base, d_result);
+}
+
+int gsim_merge_device(int device, void* hip_stream, const void* d_blocks, uint32_t nblocks, size_t block_bytes,
+                      uint32_t k, void* d_result)
+{
+    if (!d_blocks || !d_result || nblocks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
+    if (block_bytes < gsim_result_block_bytes(k)) return fail(GSIM_ERR_INVALID, "block_bytes too small for k");
+    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(gsim::launch_merge(d_blocks, nblocks, block_bytes, k, d_result, static_cast<hipStream_t>(hip_stream)));
+    return GSIM_OK;
+}
+
+// The reference's explicit host path, fingerprintdb_cuda.cpp:20-54: score every
+// row on all host threads (QtConcurrent::blockingMap -> std::thread here), then
+// top_results_bubble_sort (:92-103) and the first k.  Not a fallback: only this
+// entry point runs it.
+int gsim_db_search_cpu(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, gsim_hit* hits,
+                       uint32_t* counts)
+{
+    (void) cutoff; // ignored by the reference's CPU path
+    if (!db || !queries || (!hits && k) || !counts) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (!db->has_host_copy) return fail(GSIM_ERR_STATE, "search_cpu needs the host copy of the rows");
+    if (k > db->nrows) return fail(GSIM_ERR_INVALID, "search_cpu: k exceeds the row count");
+    const uint64_t n = db->nrows;
+    const uint32_t W = db->W;
+    std::vector<int> indices(n);
+    std::vector<float> scores(n);
+    std::vector<uint16_t> cm(n), pc(n);
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > n) nthreads = n ? static_cast<unsigned>(n) : 1;
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t* query = queries + static_cast<size_t>(q) * W;
+        auto work = [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t r = lo; r < hi; r++) {
+                const uint32_t* d = db->host_rows.data() + r * W;
+                int total = 0, common = 0;
+                int pd = 0;
+                for (uint32_t i = 0; i < W; i++) {
+                    const int p2 = __builtin_popcount(d[i]);
+                    total += __builtin_popcount(query[i]) + p2;
+                    pd += p2;
+                    common += __builtin_popcount(query[i] & d[i]);
+                }
+                scores[r] = static_cast<float>(common) / static_cast<float>(total - common);
+                cm[r] = static_cast<uint16_t>(common);
+                pc[r] = static_cast<uint16_t>(pd);
+                indices[r] = static_cast<int>(r);
+            }
+        };
+        std::vector<std::thread> pool;
+        const uint64_t per = (n + nthreads - 1) / nthreads;
+        for (unsigned t = 0; t < nthreads; t++) {
+            const uint64_t lo = per * t, hi = std::min<uint64_t>(lo + per, n);
+            if (lo < hi) pool.emplace_back(work, lo, hi);
+        }
+        for (auto& th : pool) th.join();
+        // partial bubble sort, strict '>' (stable)
+        for (uint32_t i = 0; i < k; i++) {
+            for (uint64_t j = n - 1; j > i; j--) {
+                if (scores[j] > scores[j - 1]) {
+                    std::swap(indices[j], indices[j - 1]);
+                    std::swap(scores[j], scores[j - 1]);
+                }
+            }
+        }
+        for (uint32_t i = 0; i < k; i++) {
+            gsim_hit& h = hits[static_cast<size_t>(q) * k + i];
+            h.row = static_cast<uint32_t>(indices[i]) + db->row_base;
+            h.score = scores[i];
+            h.common = cm[indices[i]];
+            h.popc_db = pc[indices[i]];
+        }
+        counts[q] = k;
+    }
+    return GSIM_OK;
+}
+
+int gsim_db_enable_timing(gsim_db* db, int enable)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    for (auto& s : db->shards) {
+        int rc = drain_timing(db, s);
+        if (rc != GSIM_OK) return rc;
+    }
+    db->timing = enable != 0;
+    db->acc = gsim_timing{};
+    return GSIM_OK;
+}
+
+int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
+{
+    if (!db || !out) return fail(GSIM_ERR_INVALID, "NULL argument");
+    for (auto& s : db->shards) {
+        int rc = drain_timing(db, s);
+        if (rc != GSIM_OK) return rc;
+    }
+    *out = db->acc;
+    return GSIM_OK;
+}
+
+int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint32_t a, uint32_t max_b,
+                           uint32_t max_c, float* out)
+{
+    if (!out) return fail(GSIM_ERR_INVALID, "out is NULL");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (device < 0 || device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    GSIM_HIP(hipSetDevice(device));
+    const size_t n = static_cast<size_t>(max_b + 1) * (max_c + 1);
+    float* d = nullptr;
+    GSIM_HIP(hipMalloc(&d, n * sizeof(float)));
+    hipError_t e = gsim::launch_score_table(metric, alpha, beta, a, max_b, max_c, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "score table");
+    return GSIM_OK;
+}
+
+} // extern "C"

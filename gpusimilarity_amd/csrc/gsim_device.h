@@ -1,0 +1,84 @@
+// gsim_device.h -- launch interface between the C-ABI host code (gsim_capi.cpp)
+// and the gfx950 kernels (gsim_device.hip).  Internal; not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gsim
+{
+
+// In-scan coarse histogram: linear bins over the score range [0, 1].
+constexpr int kScanBins = 1024;
+// Largest finalist count the single-workgroup LDS select handles.
+constexpr int kSelectCap = 8192;
+constexpr int kScanBlock = 256; // 4 wavefronts
+
+// Device-resident per-query state, zeroed before every scan.
+struct QueryState {
+    uint32_t ghist[kScanBins];   // candidates per coarse bin (bins >= each wave's final threshold)
+    unsigned long long kept;     // rows with score >= cutoff (cutoff > 0 only)
+    unsigned long long ncand;    // total candidates emitted by the scan
+    uint32_t nfinal;             // finalists appended by the compaction
+    uint32_t bstar;              // coarse bin of the k-th best score
+    uint32_t flags;              // reserved
+    uint32_t pad;
+};
+
+struct ScanGeometry {
+    uint32_t lanes_per_row; // 16-byte lanes per fingerprint (fp words / 4), 0 = generic path
+    uint32_t unroll;        // 16-byte loads in flight per lane
+    uint32_t chunk_rows;    // rows per wave iteration
+    uint32_t nwaves;        // wavefronts in the grid
+    uint32_t seg_cap;       // candidate slots per wavefront
+    uint64_t nchunks;
+};
+
+struct ScanArgs {
+    const void* rows;       // device, row-major uint32[nrows][W]
+    uint64_t nrows;
+    uint32_t W;             // words per fingerprint
+    const uint32_t* query;  // device, W words
+    uint32_t qpop;          // popc(query)
+    uint32_t k;
+    float cutoff;
+    int metric;
+    float alpha, beta;
+    unsigned long long* cand; // device, nwaves*seg_cap keys
+    uint32_t* seg_count;      // device, nwaves
+    QueryState* state;        // device
+};
+
+// Geometry of the scan grid for a table (host side, no device work).
+ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll);
+
+hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s);
+
+// Compaction of candidates at or above the k-th best coarse bin into `finalists`.
+hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned long long* finalists,
+                          uint32_t finalists_cap, hipStream_t s);
+
+// Final exact select + sort of the finalists (k <= kSelectCap, any finalist count);
+// writes {gsim_result_header; gsim_hit[k]}.
+hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap,
+                         uint32_t row_base, void* d_result, hipStream_t s);
+
+// Large-k path (k > kSelectCap): global-memory bitonic sort of all finalists.
+hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s);
+hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s);
+hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, uint32_t nkeys,
+                            uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags,
+                            void* d_result, hipStream_t s);
+
+// Merge of result blocks (multi-GPU gather).
+hipError_t launch_merge(const void* d_blocks, uint32_t nblocks, size_t block_bytes, uint32_t k,
+                        void* d_result, hipStream_t s);
+
+hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows,
+                           uint32_t W, hipStream_t s);
+
+hipError_t launch_score_table(int metric, float alpha, float beta, uint32_t a, uint32_t max_b,
+                              uint32_t max_c, float* d_out, hipStream_t s);
+
+} // namespace gsim

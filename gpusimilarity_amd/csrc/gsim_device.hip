@@ -1,0 +1,804 @@
+// gsim_device.hip -- gfx950 (MI355X / CDNA4) kernels of the fingerprint scan engine.
+//
+// Replaces the Thrust pipeline of the reference's FingerprintDB::search_storage
+// (fingerprintdb_cuda.cu:228-339: sequence / transform(TanimotoFunctor) /
+// remove_if / sort_by_key over ALL rows) with
+//
+//   K1 scan_kernel     one streaming pass over the table, 16 B per lane coalesced
+//                      loads (a wave64 load instruction = 1 KiB of consecutive
+//                      rows), AND+v_bcnt_u32_b32 popcounts, DPP reduction across
+//                      the lanes of a row, the reference's f32 divide, cutoff, and
+//                      an in-scan streaming top-k filter: every wavefront keeps a
+//                      private coarse score histogram in LDS and only rows at or
+//                      above its running k-th-best bin are written out
+//                      (candidates, 8 B each) -- no per-row score array exists.
+//   K2 compact_kernel  finds the coarse bin of the global k-th best score from
+//                      the merged histogram and keeps the candidates at or above it.
+//   K3 select_kernel   one workgroup: bitonic sort of the finalists' unique 64-bit
+//                      keys (score desc, row asc) in LDS, emits the first k rows
+//                      with their integer popcounts.
+//
+// This is HBM-bound bit arithmetic: no MFMA anywhere (the work is AND + popcount,
+// not a contraction).  Wave size is hard-wired to 64.
+#include "gsim_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gpusim_hip.h"
+
+namespace gsim
+{
+namespace
+{
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------
+// keys, bins, scores
+// ---------------------------------------------------------------------------
+
+// Order-preserving u32 image of a float (any sign): larger score <=> larger key.
+__device__ __forceinline__ uint32_t order_key(float s)
+{
+    const uint32_t b = __float_as_uint(s);
+    return b ^ (static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_score(uint32_t key)
+{
+    const uint32_t b = key ^ ((key & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(b);
+}
+
+// candidate key: (order_key(score) << 32) | ~row  -> descending key order is the
+// canonical result order (score desc, row asc); keys are unique.
+__device__ __forceinline__ u64 make_key(float s, uint32_t row)
+{
+    return (static_cast<u64>(order_key(s)) << 32) | static_cast<u64>(~row);
+}
+
+// Monotone (non-decreasing in score) coarse bin; the scaling is by a power of
+// two, hence exact.
+__device__ __forceinline__ uint32_t coarse_bin(float s)
+{
+    const float t = fminf(fmaxf(s, 0.0f), 1.0f) * static_cast<float>(kScanBins);
+    const uint32_t b = static_cast<uint32_t>(t);
+    return b < static_cast<uint32_t>(kScanBins) ? b : static_cast<uint32_t>(kScanBins - 1);
+}
+
+// The reference's arithmetic, fingerprintdb_cuda.cu:89-101:
+//   score = (float)common / (float)(total - common), total = popc(q) + popc(d)
+// one correctly rounded IEEE f32 divide.  Tversky (build-defined; oracle
+// gso_score_one is the twin): one rounding per operation, in this order.
+__device__ __forceinline__ float score_of(int metric, float alpha, float beta, uint32_t a, uint32_t b,
+                                          uint32_t c)
+{
+    if (metric == GSIM_METRIC_TVERSKY) {
+        const float t1 = __fmul_rn(alpha, static_cast<float>(static_cast<int>(a - c)));
+        const float t2 = __fmul_rn(beta, static_cast<float>(static_cast<int>(b - c)));
+        const float den = __fadd_rn(__fadd_rn(t1, t2), static_cast<float>(c));
+        return __fdiv_rn(static_cast<float>(c), den);
+    }
+    const int total = static_cast<int>(a + b);
+    return __fdiv_rn(static_cast<float>(static_cast<int>(c)),
+                     static_cast<float>(total - static_cast<int>(c)));
+}
+
+// fingerprintdb_cuda.cu:101  (NaN compares false -> 0)
+__device__ __forceinline__ float apply_cutoff(float s, float cutoff)
+{
+    return s >= cutoff ? s : 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// cross-lane helpers (wave64)
+// ---------------------------------------------------------------------------
+
+template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over each aligned group of LPR consecutive lanes; every lane of the group
+// ends up with the total.  DPP row operations up to 16 lanes.
+template <int LPR> __device__ __forceinline__ uint32_t group_sum(uint32_t v)
+{
+    if (LPR >= 2) v += dpp<0xB1>(v);  // quad_perm [1,0,3,2]
+    if (LPR >= 4) v += dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+    if (LPR >= 8) v += dpp<0x141>(v); // row_half_mirror
+    if (LPR >= 16) v += dpp<0x140>(v); // row_mirror
+    if (LPR >= 32) v += static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 16, 64));
+    if (LPR >= 64) v += static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_rank(u64 mask)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int d = 32; d > 0; d >>= 1) v += static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), d, 64));
+    return v;
+}
+
+// Largest bin B with sum_{b >= B} hist[b] >= k, and that sum.  When the whole
+// histogram holds fewer than k entries: B = 0 and the total.  One wavefront;
+// lane l owns bins [16 l, 16 l + 16).  k >= 1.
+__device__ __forceinline__ void find_threshold(const uint32_t* hist, uint32_t k, int lane, uint32_t& bin_out,
+                                               uint32_t& cnt_out)
+{
+    constexpr int PER = kScanBins / 64;
+    uint32_t h[PER];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        h[i] = hist[lane * PER + i];
+        s += h[i];
+    }
+    uint32_t incl = s; // suffix sum over lanes >= lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = static_cast<uint32_t>(__shfl_down(static_cast<int>(incl), d, 64));
+        if (lane + d < 64) incl += t;
+    }
+    const u64 m = __ballot(incl >= k);
+    if (m == 0) {
+        bin_out = 0;
+        cnt_out = static_cast<uint32_t>(__shfl(static_cast<int>(incl), 0, 64));
+        return;
+    }
+    const int L = 63 - __clzll(static_cast<long long>(m));
+    uint32_t acc = incl - s; // entries in lanes above this one
+    uint32_t bin = 0, cnt = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = PER - 1; i >= 0; i--) {
+        acc += h[i];
+        if (!found && acc >= k) {
+            found = true;
+            bin = static_cast<uint32_t>(lane * PER + i);
+            cnt = acc;
+        }
+    }
+    bin_out = static_cast<uint32_t>(__shfl(static_cast<int>(bin), L, 64));
+    cnt_out = static_cast<uint32_t>(__shfl(static_cast<int>(cnt), L, 64));
+}
+
+// ---------------------------------------------------------------------------
+// K1: the scan
+// ---------------------------------------------------------------------------
+
+// Streaming top-k filter state of one wavefront (all members wave-uniform
+// except `kept`).  Validity argument: `tau` is the k-th best coarse bin among
+// the rows THIS wave has seen, a subset of the table, so it never exceeds the
+// bin of the table's k-th best score; a row whose bin is below tau has a
+// strictly smaller score than k rows already seen and cannot be in the top-k.
+struct WaveFilter {
+    uint32_t* hist; // LDS, private to the wave
+    u64* seg;       // this wave's candidate segment
+    uint32_t k, tau, nge, trigger, step, cursor, kept;
+    float cutoff;
+    bool has_cutoff;
+
+    __device__ __forceinline__ void init(uint32_t* h, u64* s, uint32_t kk, float cut)
+    {
+        hist = h;
+        seg = s;
+        k = kk;
+        cutoff = cut;
+        has_cutoff = cut > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
+        tau = kk ? 0u : static_cast<uint32_t>(kScanBins);
+        nge = 0;
+        trigger = kk;
+        step = kk / 8 > 32 ? kk / 8 : 32;
+        cursor = 0;
+        kept = 0;
+    }
+
+    // One row per lane (or an inactive lane).
+    __device__ __forceinline__ void offer(bool active, uint32_t row, float raw_score, int lane)
+    {
+        const float s = apply_cutoff(raw_score, cutoff);
+        const bool keep = active && (!has_cutoff || s != 0.0f);
+        kept += keep ? 1u : 0u;
+        const uint32_t bin = coarse_bin(s);
+        const bool cand = keep && bin >= tau;
+        const u64 m = __ballot(cand);
+        if (m != 0) {
+            if (cand) {
+                seg[cursor + lane_rank(m)] = make_key(s, row);
+                atomicAdd(&hist[bin], 1u); // ds_add_u32: lanes of one wave may share a bin
+            }
+            const uint32_t n = static_cast<uint32_t>(__popcll(m));
+            cursor += n;
+            nge += n;
+            if (nge >= trigger) {
+                find_threshold(hist, k, lane, tau, nge);
+                trigger = nge + step;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(uint32_t w, const ScanArgs& a, int lane)
+    {
+        if (lane == 0) {
+            a.seg_count[w] = cursor;
+            if (cursor) atomicAdd(&a.state->ncand, static_cast<u64>(cursor));
+        }
+        // Bins at or above the final threshold are merged into the table-wide
+        // histogram.  It is exact for every bin >= max over waves of tau, which
+        // is all K2 needs (see compact_kernel).
+        for (int i = lane; i < kScanBins; i += 64) {
+            const uint32_t h = hist[i];
+            if (static_cast<uint32_t>(i) >= tau && h != 0) atomicAdd(&a.state->ghist[i], h);
+        }
+        if (has_cutoff) {
+            const uint32_t tot = wave_sum(kept);
+            if (lane == 0 && tot) atomicAdd(&a.state->kept, static_cast<u64>(tot));
+        }
+    }
+};
+
+// 16 bytes per lane; a wave64 instruction covers 1 KiB of consecutive table bytes.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
+{
+    return __builtin_nontemporal_load(p); // read once: keep it out of the caches' way
+}
+
+// LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads in flight per lane.
+// A wave iteration covers CH = U * 64 / LPR consecutive rows = U KiB of the table.
+template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_kernel(ScanArgs a, ScanGeometry g)
+{
+    __shared__ uint32_t s_hist[kScanBlock / 64][kScanBins];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wib);
+    uint32_t* hist = s_hist[wib];
+    for (int i = lane; i < kScanBins; i += 64) hist[i] = 0;
+
+    constexpr int RPL = 64 / LPR; // rows per load instruction
+    constexpr int CH = U * RPL;   // rows per wave iteration
+    constexpr int ROUNDS = (U + LPR - 1) / LPR;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+
+    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[sub];
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+
+    WaveFilter f;
+    f.init(hist, a.cand + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+
+    const u64 nfull = a.nrows / CH;
+    for (u64 c = w; c < g.nchunks; c += g.nwaves) {
+        const u64 row0 = c * CH;
+        const u32x4* p = db + row0 * LPR + lane;
+        const bool full = c < nfull;
+        u32x4 d[U];
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < U; j++) d[j] = stream_load(p + j * 64);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const u64 row = row0 + static_cast<u64>(j * RPL + grp);
+                d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
+            }
+        }
+        uint32_t v[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            // v_and + v_bcnt_u32_b32 (popcount with accumulate)
+            const uint32_t cc = __popc(d[j].x & q.x) + __popc(d[j].y & q.y) + __popc(d[j].z & q.z) +
+                                __popc(d[j].w & q.w);
+            const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
+            v[j] = group_sum<LPR>((cc << 16) + bb); // both sums < 2^16 (fp_bits <= 32768)
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            // lane (grp, sub) takes the row of load j = r*LPR + sub
+            uint32_t val = 0;
+#pragma unroll
+            for (int jj = 0; jj < U; jj++) {
+                if (jj / LPR == r) val = (sub == jj % LPR) ? v[jj] : val;
+            }
+            const int j = r * LPR + sub;
+            const u64 row = row0 + static_cast<u64>(j * RPL + grp);
+            const bool active = (j < U) && (full || row < a.nrows);
+            const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
+            f.offer(active, static_cast<uint32_t>(row), s, lane);
+        }
+    }
+    f.finish(w, a, lane);
+}
+
+// Any fingerprint width (W words, not a power-of-two number of 16-byte lanes):
+// one row per lane, word loop.  Correct for every W; not the tuned path.
+__global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, ScanGeometry g)
+{
+    __shared__ uint32_t s_hist[kScanBlock / 64][kScanBins];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wib);
+    uint32_t* hist = s_hist[wib];
+    for (int i = lane; i < kScanBins; i += 64) hist[i] = 0;
+    const uint32_t* __restrict__ db = reinterpret_cast<const uint32_t*>(a.rows);
+    WaveFilter f;
+    f.init(hist, a.cand + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+    for (u64 c = w; c < g.nchunks; c += g.nwaves) {
+        const u64 row = c * 64 + lane;
+        const bool active = row < a.nrows;
+        uint32_t cc = 0, bb = 0;
+        if (active) {
+            const uint32_t* r = db + row * a.W;
+            for (uint32_t i = 0; i < a.W; i++) {
+                const uint32_t x = r[i];
+                cc += __popc(x & a.query[i]);
+                bb += __popc(x);
+            }
+        }
+        const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc);
+        f.offer(active, static_cast<uint32_t>(row), s, lane);
+    }
+    f.finish(w, a, lane);
+}
+
+// ---------------------------------------------------------------------------
+// K2: compaction at the k-th best coarse bin
+// ---------------------------------------------------------------------------
+//
+// ghist[b] counts the candidates of the waves whose final threshold is <= b,
+// i.e. it under-counts bins below T = max_w tau_w and is exact at and above T.
+// The table's k-th best bin B* is >= T (every tau_w is a lower bound for it), so
+// the largest B with sum_{b>=B} ghist[b] >= k is exactly B*; every top-k row has
+// bin >= B* >= tau_w and was therefore emitted by its wave.
+__global__ __launch_bounds__(kScanBlock) void compact_kernel(ScanArgs a, ScanGeometry g, u64* finalists,
+                                                             uint32_t cap)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
+    const uint32_t n = a.seg_count[w];
+    if (n == 0 || a.k == 0) return;
+    uint32_t bstar, cnt;
+    find_threshold(a.state->ghist, a.k, lane, bstar, cnt);
+    const u64* seg = a.cand + static_cast<u64>(w) * g.seg_cap;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        u64 key = 0;
+        bool ok = false;
+        if (i < n) {
+            key = seg[i];
+            ok = coarse_bin(key_score(static_cast<uint32_t>(key >> 32))) >= bstar;
+        }
+        const u64 m = __ballot(ok);
+        if (m != 0) {
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&a.state->nfinal, static_cast<uint32_t>(__popcll(m)));
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if (ok) {
+                const uint32_t idx = pos + lane_rank(m);
+                if (idx < cap) finalists[idx] = key;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3: exact select + sort of the finalists, result emission
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ void emit_hit(const ScanArgs& a, u64 key, uint32_t row_base, gsim_hit* out)
+{
+    const uint32_t row = ~static_cast<uint32_t>(key);
+    const float s = key_score(static_cast<uint32_t>(key >> 32));
+    const uint32_t* r = reinterpret_cast<const uint32_t*>(a.rows) + static_cast<u64>(row) * a.W;
+    uint32_t cc = 0, bb = 0;
+    for (uint32_t i = 0; i < a.W; i++) {
+        const uint32_t x = r[i];
+        cc += __popc(x & a.query[i]);
+        bb += __popc(x);
+    }
+    gsim_hit h;
+    h.row = row + row_base;
+    h.score = s;
+    h.common = static_cast<uint16_t>(cc);
+    h.popc_db = static_cast<uint16_t>(bb);
+    *out = h;
+}
+
+__device__ __forceinline__ u64 approx_count(const ScanArgs& a)
+{
+    // fingerprintdb_cuda.cu:263-277: survivors when cutoff > 0, else all rows
+    return a.cutoff > 0.0f ? a.state->kept : a.nrows;
+}
+
+constexpr int kSelectThreads = 1024;
+
+// keys[0..n) in LDS, n a power of two: bitonic sort, descending.
+__device__ __forceinline__ void bitonic_desc_lds(u64* keys, uint32_t n, int tid, int nthreads)
+{
+    for (uint32_t size = 2; size <= n; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = tid; t < n / 2; t += nthreads) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 x = keys[lo], y = keys[hi];
+                if ((x < y) == desc) {
+                    keys[lo] = y;
+                    keys[hi] = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Dynamic LDS layout of select_kernel: kSelectCap keys, then a 256-bin digit
+// histogram and three words of control state.
+constexpr size_t kSelectLds = static_cast<size_t>(kSelectCap) * sizeof(u64) + 256 * sizeof(uint32_t) + 16;
+
+// One workgroup.  k <= kSelectCap.  Finalists <= kSelectCap: all of them go to
+// LDS.  More (heavy ties at the k-th score): an in-kernel MSD radix select over
+// the unique 64-bit keys finds the k-th largest key T, and exactly the k keys
+// >= T go to LDS.  Then a bitonic sort and the emission of the first k hits.
+__global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, const u64* finalists, uint32_t cap,
+                                                                uint32_t row_base, void* d_result)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    uint32_t* dhist = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kSelectCap) * sizeof(u64));
+    uint32_t* ctl = dhist + 256; // [0] digit, [1] remaining, [2] gather cursor
+    const int tid = threadIdx.x;
+    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
+    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+    uint32_t m2 = a.k ? a.state->nfinal : 0;
+    if (m2 > cap) m2 = cap; // cannot happen: cap covers every candidate slot
+    uint32_t nsel = m2;
+    if (m2 <= static_cast<uint32_t>(kSelectCap)) {
+        for (uint32_t i = tid; i < m2; i += kSelectThreads) keys[i] = finalists[i];
+    } else {
+        u64 prefix = 0;
+        if (tid == 0) ctl[1] = a.k;
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            if (tid < 256) dhist[tid] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < m2; i += kSelectThreads) {
+                const u64 key = finalists[i];
+                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&dhist[(key >> shift) & 0xFF], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t remaining = ctl[1], acc = 0;
+                int d = 255;
+                for (; d > 0; d--) {
+                    if (acc + dhist[d] >= remaining) break;
+                    acc += dhist[d];
+                }
+                ctl[0] = static_cast<uint32_t>(d);
+                ctl[1] = remaining - acc;
+            }
+            __syncthreads();
+            prefix = (prefix << 8) | ctl[0];
+            __syncthreads();
+        }
+        // prefix is now the k-th largest key; keys are unique -> exactly k keys >= it
+        if (tid == 0) ctl[2] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < m2; i += kSelectThreads) {
+            const u64 key = finalists[i];
+            if (key >= prefix) {
+                const uint32_t pos = atomicAdd(&ctl[2], 1u);
+                if (pos < static_cast<uint32_t>(kSelectCap)) keys[pos] = key;
+            }
+        }
+        __syncthreads();
+        nsel = ctl[2] < static_cast<uint32_t>(kSelectCap) ? ctl[2] : static_cast<uint32_t>(kSelectCap);
+    }
+    uint32_t n = 1;
+    while (n < nsel) n <<= 1;
+    __syncthreads();
+    for (uint32_t i = nsel + tid; i < n; i += kSelectThreads) keys[i] = 0ull;
+    bitonic_desc_lds(keys, n, tid, kSelectThreads);
+    const uint32_t nout = nsel < a.k ? nsel : a.k;
+    for (uint32_t i = tid; i < nout; i += kSelectThreads) emit_hit(a, keys[i], row_base, hits + i);
+    if (tid == 0) {
+        hdr->count = nout;
+        hdr->flags = m2 > static_cast<uint32_t>(kSelectCap) ? 1u : 0u;
+        hdr->approx = approx_count(a);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// large-k path (k > kSelectCap): bitonic sort of ALL finalists in global memory
+// (multi-launch), then emission of the first k.  Exact for any input.
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64 to)
+{
+    const u64 i = from + static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < to) keys[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void bitonic_step_kernel(u64* keys, uint32_t n, uint32_t size, uint32_t stride)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n / 2) return;
+    const uint32_t lo = 2 * t - (t & (stride - 1));
+    const uint32_t hi = lo + stride;
+    const bool desc = (lo & size) == 0;
+    const u64 x = keys[lo], y = keys[hi];
+    if ((x < y) == desc) {
+        keys[lo] = y;
+        keys[hi] = x;
+    }
+}
+
+__global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, uint32_t nkeys,
+                                                        uint32_t row_base, u64 approx_if_no_cutoff, uint32_t flags,
+                                                        void* d_result)
+{
+    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
+    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) emit_hit(a, sorted_keys[i], row_base, hits + i);
+    if (i == 0) {
+        hdr->count = nkeys;
+        hdr->flags = flags;
+        hdr->approx = a.cutoff > 0.0f ? a.state->kept : approx_if_no_cutoff;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// merge of per-shard result blocks (fingerprintdb_cuda.cu:363-380)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ const gsim_result_header* block_hdr(const void* blocks, size_t block_bytes, uint32_t i)
+{
+    return reinterpret_cast<const gsim_result_header*>(reinterpret_cast<const unsigned char*>(blocks) +
+                                                       static_cast<size_t>(i) * block_bytes);
+}
+
+// Every list is in canonical order and keys are unique across lists, so the
+// output position of an element is the number of elements that precede it:
+// its own index plus, for every other list, a binary search.
+__global__ __launch_bounds__(256) void merge_kernel(const void* blocks, uint32_t nblocks, size_t block_bytes,
+                                                    uint32_t k, void* d_result)
+{
+    gsim_result_header* ohdr = reinterpret_cast<gsim_result_header*>(d_result);
+    gsim_hit* out = reinterpret_cast<gsim_hit*>(ohdr + 1);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        u64 approx = 0, total = 0;
+        uint32_t flags = 0;
+        for (uint32_t i = 0; i < nblocks; i++) {
+            const gsim_result_header* h = block_hdr(blocks, block_bytes, i);
+            approx += h->approx;
+            total += h->count;
+            flags |= h->flags;
+        }
+        ohdr->count = total < k ? static_cast<uint32_t>(total) : k;
+        ohdr->flags = flags;
+        ohdr->approx = approx;
+    }
+    const uint32_t li = t / k, e = t % k;
+    if (li >= nblocks) return;
+    const gsim_result_header* mh = block_hdr(blocks, block_bytes, li);
+    if (e >= mh->count) return;
+    const gsim_hit* mine = reinterpret_cast<const gsim_hit*>(mh + 1);
+    const gsim_hit me = mine[e];
+    const u64 mykey = make_key(me.score, me.row);
+    uint32_t rank = e;
+    for (uint32_t j = 0; j < nblocks; j++) {
+        if (j == li) continue;
+        const gsim_result_header* h = block_hdr(blocks, block_bytes, j);
+        const gsim_hit* lst = reinterpret_cast<const gsim_hit*>(h + 1);
+        uint32_t lo = 0, hi = h->count; // first index whose key < mykey
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (make_key(lst[mid].score, lst[mid].row) > mykey) lo = mid + 1;
+            else hi = mid;
+        }
+        rank += lo;
+    }
+    if (rank < k) out[rank] = me;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic table generator (twin of oracle gso_synth_word)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ u64 splitmix64(u64 x)
+{
+    u64 z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ u64 stream_at(u64 seed, u64 n)
+{
+    return splitmix64(seed + n * 0x9E3779B97F4A7C15ull);
+}
+
+__global__ __launch_bounds__(256) void generate_kernel(uint32_t* rows, u64 seed, int kind, u64 first_row,
+                                                       u64 nwords, uint32_t W)
+{
+    const u64 stride = static_cast<u64>(gridDim.x) * blockDim.x;
+    for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const u64 ctr = first_row * W + i;
+        uint32_t word;
+        if (kind == GSIM_SYNTH_DENSE) {
+            word = static_cast<uint32_t>(stream_at(seed, ctr));
+        } else {
+            const u64 h0 = stream_at(seed, 2 * ctr), h1 = stream_at(seed, 2 * ctr + 1);
+            word = static_cast<uint32_t>(h0) & static_cast<uint32_t>(h0 >> 32) & static_cast<uint32_t>(h1) &
+                   static_cast<uint32_t>(h1 >> 32);
+        }
+        rows[i] = word;
+    }
+}
+
+__global__ __launch_bounds__(256) void score_table_kernel(int metric, float alpha, float beta, uint32_t a,
+                                                          uint32_t max_b, uint32_t max_c, float* out)
+{
+    const u64 n = static_cast<u64>(max_b + 1) * (max_c + 1);
+    const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = static_cast<uint32_t>(i / (max_b + 1)), b = static_cast<uint32_t>(i % (max_b + 1));
+    out[i] = score_of(metric, alpha, beta, a, b, c);
+}
+
+template <int LPR, int U> hipError_t launch_scan_t(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
+{
+    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    hipLaunchKernelGGL((scan_kernel<LPR, U>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------
+
+static bool is_pow2(uint32_t x)
+{
+    return x && !(x & (x - 1));
+}
+
+ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll)
+{
+    ScanGeometry g{};
+    const uint32_t lpr = (W % 4 == 0 && is_pow2(W / 4) && W / 4 <= 64) ? W / 4 : 0;
+    g.lanes_per_row = lpr;
+    if (lpr) {
+        if (unroll != 4 && unroll != 8 && unroll != 16) unroll = 8;
+        g.unroll = static_cast<uint32_t>(unroll);
+        g.chunk_rows = g.unroll * (64 / lpr);
+    } else {
+        g.unroll = 1;
+        g.chunk_rows = 64;
+    }
+    g.nchunks = (nrows + g.chunk_rows - 1) / g.chunk_rows;
+    uint64_t nw = static_cast<uint64_t>(num_cus) * static_cast<uint64_t>(waves_per_cu);
+    if (nw > g.nchunks) nw = g.nchunks;
+    if (nw < 1) nw = 1;
+    const uint32_t wpb = kScanBlock / 64;
+    nw = (nw + wpb - 1) / wpb * wpb;
+    g.nwaves = static_cast<uint32_t>(nw);
+    const uint64_t per = (g.nchunks + g.nwaves - 1) / g.nwaves;
+    g.seg_cap = static_cast<uint32_t>((per ? per : 1) * g.chunk_rows);
+    return g;
+}
+
+hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
+{
+#define GSIM_CASE(L, UU) \
+    if (g.lanes_per_row == L && g.unroll == UU) return launch_scan_t<L, UU>(a, g, s);
+    GSIM_CASE(8, 8)
+    GSIM_CASE(8, 4)
+    GSIM_CASE(8, 16)
+    GSIM_CASE(16, 8)
+    GSIM_CASE(16, 4)
+    GSIM_CASE(16, 16)
+    GSIM_CASE(1, 8)
+    GSIM_CASE(2, 8)
+    GSIM_CASE(4, 8)
+    GSIM_CASE(32, 8)
+    GSIM_CASE(64, 8)
+#undef GSIM_CASE
+    if (g.lanes_per_row != 0) return hipErrorInvalidValue;
+    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    hipLaunchKernelGGL(scan_generic_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned long long* finalists,
+                          uint32_t finalists_cap, hipStream_t s)
+{
+    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g, finalists, finalists_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap,
+                         uint32_t row_base, void* d_result, hipStream_t s)
+{
+    // per-device attribute: set on every launch (cheap, idempotent)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSelectLds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(kSelectThreads), kSelectLds, s, a, finalists, finalists_cap,
+                       row_base, d_result);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s)
+{
+    if (n_pow2 < 2) return hipSuccess;
+    const uint32_t nb = (n_pow2 / 2 + 255) / 256;
+    for (uint32_t size = 2; size <= n_pow2 && size != 0; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            hipLaunchKernelGGL(bitonic_step_kernel, dim3(nb), dim3(256), 0, s, keys, n_pow2, size, stride);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s)
+{
+    if (to <= from) return hipSuccess;
+    const uint64_t nb = (to - from + 255) / 256;
+    hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, keys, from, to);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, uint32_t nkeys,
+                            uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result,
+                            hipStream_t s)
+{
+    const uint32_t nb = nkeys ? (nkeys + 255) / 256 : 1;
+    hipLaunchKernelGGL(emit_hits_kernel, dim3(nb), dim3(256), 0, s, a, sorted_keys, nkeys, row_base,
+                       approx_if_no_cutoff, flags, d_result);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge(const void* d_blocks, uint32_t nblocks, size_t block_bytes, uint32_t k, void* d_result,
+                        hipStream_t s)
+{
+    const uint64_t nthreads = static_cast<uint64_t>(nblocks) * (k ? k : 1);
+    const uint32_t nb = static_cast<uint32_t>((nthreads + 255) / 256);
+    hipLaunchKernelGGL(merge_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, d_blocks, nblocks, block_bytes,
+                       k ? k : 1, d_result);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows, uint32_t W,
+                           hipStream_t s)
+{
+    const uint64_t nwords = nrows * W;
+    if (nwords == 0) return hipSuccess;
+    uint64_t nb = (nwords + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(generate_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s,
+                       reinterpret_cast<uint32_t*>(rows), seed, kind, first_row, nwords, W);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_table(int metric, float alpha, float beta, uint32_t a, uint32_t max_b, uint32_t max_c,
+                              float* d_out, hipStream_t s)
+{
+    const uint64_t n = static_cast<uint64_t>(max_b + 1) * (max_c + 1);
+    const uint32_t nb = static_cast<uint32_t>((n + 255) / 256);
+    hipLaunchKernelGGL(score_table_kernel, dim3(nb), dim3(256), 0, s, metric, alpha, beta, a, max_b, max_c, d_out);
+    return hipGetLastError();
+}
+
+} // namespace gsim

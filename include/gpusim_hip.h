@@ -1,0 +1,191 @@
+/* gpusim_hip.h -- C ABI of the MI355X-native fingerprint scan engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of schrodinger/gpusimilarity:
+ * "score every packed fingerprint of a table against a query (popcount
+ * Tanimoto / Tversky), apply a cutoff, return the exact top-k".  In the
+ * reference that path lives behind the C++ class gpusim::FingerprintDB
+ * (fingerprintdb_cuda.h:53-140), whose stated purpose is to keep CUDA types
+ * away from its callers (fingerprintdb_cuda.h:47, fingerprintdb_cuda.cpp:2-3).
+ * The reference has no FFI of its own; the entry points below are what a
+ * binding for that class would bind, one for each thing the class does with the
+ * device.  Host C++ (gpusimilarity_amd/csrc/host/fingerprintdb.h, the Qt-free
+ * twin of the reference class) reaches HIP only through these functions.
+ *
+ * Rules of the ABI: plain C, opaque handle, plain pointers and sizes, no HIP /
+ * STL / torch types, never throws, every call returns a status (0 = ok, < 0 =
+ * error, text via gsim_last_error()).  One search at a time per handle (the
+ * reference serialises searches behind a function-static mutex,
+ * fingerprintdb_cuda.cu:236, and its server is single threaded).
+ *
+ * Fingerprint layout: row-major uint32_t[nrows][fp_bits/32]; word i of a row is
+ * bytes 4i..4i+3 of the RDKit BitVectToBinaryText string read little-endian --
+ * the same pass-through reinterpretation as fingerprintdb_cuda.cu:117-126.
+ */
+#ifndef GPUSIM_HIP_H
+#define GPUSIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSIM_OK 0
+#define GSIM_ERR_INVALID (-1)   /* bad argument                                  */
+#define GSIM_ERR_NO_DEVICE (-2) /* no usable GPU / device index out of range     */
+#define GSIM_ERR_HIP (-3)       /* a HIP runtime call failed                     */
+#define GSIM_ERR_NOMEM (-4)     /* host or device allocation failed              */
+#define GSIM_ERR_STATE (-5)     /* call not valid in the handle's current state  */
+
+#define GSIM_METRIC_TANIMOTO 0 /* c / (a + b - c)          fingerprintdb_cuda.cu:89-103 */
+#define GSIM_METRIC_TVERSKY 1  /* c / (al*(a-c)+be*(b-c)+c) build extension (BASELINE config 5) */
+
+#define GSIM_SYNTH_SPARSE 0 /* bit density 1/16 (Morgan-like) */
+#define GSIM_SYNTH_DENSE 1  /* bit density 1/2                */
+
+typedef struct gsim_db gsim_db;
+
+/* One result row.  `row` is the index in the table (plus the handle's row base,
+ * see gsim_db_set_row_base) -- the ABI speaks row indices; SMILES / ID strings
+ * live above it (reference: m_smiles/m_ids lookups, fingerprintdb_cuda.cu:297-304).
+ * `score` is the float the reference would return; `common` = popc(q & row),
+ * `popc_db` = popc(row) are the integers it was computed from. */
+typedef struct {
+    uint32_t row;
+    float score;
+    uint16_t common;
+    uint16_t popc_db;
+} gsim_hit;
+
+/* Header of a device-resident result block written by gsim_db_search_device and
+ * gsim_merge_device: {gsim_result_header; gsim_hit hits[k];}. */
+typedef struct {
+    uint32_t count;  /* number of valid hits (<= k)                         */
+    uint32_t flags;  /* bit 0: block produced by the general (large) path   */
+    uint64_t approx; /* "approximate matching results", see gsim_db_search  */
+} gsim_result_header;
+
+/* Per-handle timing of the last searches, measured with HIP events on the
+ * stream the kernels were launched on (gsim_db_enable_timing). */
+typedef struct {
+    uint64_t queries;        /* searches accumulated since enable/reset           */
+    double scan_ms_sum;      /* sum of scan-kernel (dominant kernel) durations    */
+    double select_ms_sum;    /* sum of compaction + final select kernel durations */
+    uint64_t candidates_sum; /* rows that survived the in-scan threshold filter   */
+    uint64_t finalists_sum;  /* rows handed to the final select                   */
+} gsim_timing;
+
+/* ---- device enumeration / placement ------------------------------------- */
+/* get_gpu_count()            fingerprintdb_cuda.cu:40-52  */
+int gsim_device_count(int* count);
+/* get_gpu_free_memory(i)     fingerprintdb_cuda.cu:33-38  */
+int gsim_device_free_bytes(int device, size_t* free_bytes);
+/* get_available_gpu_memory() fingerprintdb_cuda.cu:401-413: sum of free bytes */
+int gsim_available_device_bytes(size_t* total_free_bytes);
+/* get_next_gpu(required)     fingerprintdb_cuda.cu:54-68: round-robin over the
+ * devices, skipping those without `required_bytes` free.  (The reference tests
+ * device i but returns the round-robin device -- a latent bug, :57-62; here the
+ * device that is returned is the one that was checked.)  GSIM_ERR_NO_DEVICE with
+ * no GPU, GSIM_ERR_NOMEM when none has room (reference: throws, :65-66). */
+int gsim_next_device(size_t required_bytes, int* device);
+
+/* ---- table lifecycle ------------------------------------------------------ */
+/* FingerprintDB::FingerprintDB   fingerprintdb_cuda.cu:133-166.  fp_bits must be
+ * a positive multiple of 32 (":140 ASSUMES INT-DIVISIBLE SIZE"), <= 32768. */
+int gsim_db_create(uint32_t fp_bits, gsim_db** out);
+/* FingerprintDBStorage ctor      fingerprintdb_cuda.cu:111-126: appends one slice
+ * of host rows (copied; the caller keeps its buffer).  Slices are concatenated in
+ * call order; global row = slice offset + local (getOffsetIndex, :128-131). */
+int gsim_db_add_rows(gsim_db* db, const uint32_t* rows, uint64_t nrows);
+/* FingerprintDB::copyToGPU(1)    fingerprintdb_cuda.cu:168-183: uploads the rows
+ * and allocates the search scratch.  ndevices == 1: the whole table goes to
+ * `device` (device < 0: gsim_next_device picks).  ndevices > 1: rows are split
+ * into ndevices contiguous shards on devices device .. device+ndevices-1
+ * (ndevices == 0: all devices).  The host copy is kept (reference keeps m_data,
+ * fingerprintdb_cuda.h:46) for gsim_db_row and gsim_db_search_cpu. */
+int gsim_db_finalize(gsim_db* db, int device, int ndevices);
+/* Synthetic table generated directly in HBM (no host copy): row r, word j =
+ * the counter-based generator of SURVEY.md 8d (oracle/gsim_oracle.c
+ * gso_synth_word is the CPU twin), rows first_row .. first_row+nrows-1.
+ * Replaces add_rows+finalize for benchmark tables that exceed host memory. */
+int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row,
+                     uint64_t nrows, int device);
+/* Borrow rows that already live in device memory (e.g. a torch tensor); the
+ * caller keeps ownership and must keep them alive.  16-byte aligned. */
+int gsim_db_attach_device_rows(gsim_db* db, const void* d_rows, uint64_t nrows,
+                               int device);
+int gsim_db_destroy(gsim_db* db);
+
+/* FingerprintDB::count()                  fingerprintdb_cuda.h:74  */
+uint64_t gsim_db_count(const gsim_db* db);
+/* FingerprintDB::getFingerprintBitcount() fingerprintdb_cuda.h:123-126 */
+uint32_t gsim_db_fp_bits(const gsim_db* db);
+/* FingerprintDB::getFingerprintDataSize() fingerprintdb_cuda.h:122 */
+size_t gsim_db_data_bytes(const gsim_db* db);
+/* FingerprintDB::getFingerprint(index)    fingerprintdb_cuda.cu:212-226 */
+int gsim_db_row(const gsim_db* db, uint64_t row, uint32_t* out_words);
+/* number of device shards the table was placed on (1 unless ndevices > 1) */
+int gsim_db_shard_count(const gsim_db* db);
+
+/* ---- search --------------------------------------------------------------- */
+/* FingerprintDB::search          fingerprintdb_cuda.cu:341-381 (+ search_storage
+ * :228-339).  For each of the nq queries (nq * fp_bits/32 words, host memory):
+ *   score(row) = metric(query, row); score = score >= cutoff ? score : 0  (:101;
+ *   NaN -> 0); rows kept = all rows when cutoff <= 0, else rows with score != 0
+ *   (:263-273); approx[q] = #kept (:272-277, :367-369); hits = the first
+ *   min(k, #kept) kept rows in the order (score desc, row asc) -- the set the
+ *   reference's sort_by_key returns, in canonical order (within a tie group the
+ *   reference's own order depends on heap addresses, :366).
+ * hits: caller-allocated nq*k entries, query q's hits at hits[q*k ..];
+ * counts[q] = number of valid hits; approx may be NULL.  alpha/beta are used by
+ * GSIM_METRIC_TVERSKY only. */
+int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
+                   float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
+                   uint32_t* counts, uint64_t* approx);
+/* FingerprintDB::search_cpu      fingerprintdb_cuda.cpp:20-54: the reference's
+ * explicit host path (TanimotoFunctorCPU on all host threads + the partial
+ * bubble sort of :92-103).  Same outputs as gsim_db_search, but reference
+ * semantics: cutoff is ignored, NaN scores are kept, approx is not written,
+ * and k > count is an error (the reference reads out of bounds).  Needs the host
+ * copy.  Never used by gsim_db_search -- there is no CPU fallback. */
+int gsim_db_search_cpu(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
+                       float cutoff, gsim_hit* hits, uint32_t* counts);
+
+/* ---- device-resident results (one process per GPU + RCCL gather) ---------- */
+/* All kernels of this handle are enqueued on `hip_stream` (a hipStream_t passed
+ * as void*; NULL = the handle's own stream). */
+int gsim_db_set_stream(gsim_db* db, void* hip_stream);
+/* Added to every returned row index: the shard's first global row. */
+int gsim_db_set_row_base(gsim_db* db, uint32_t row_base);
+/* bytes of one result block for top-k: sizeof(header) + k*sizeof(gsim_hit),
+ * rounded up to 16. */
+size_t gsim_result_block_bytes(uint32_t k);
+/* One query, single-shard handle: leaves {header; hits[k]} in device memory at
+ * d_result (gsim_result_block_bytes(k) bytes), enqueued on the handle's stream,
+ * no host synchronisation.  query is host memory (fp_bits/32 words). */
+int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff,
+                          int metric, float alpha, float beta, void* d_result);
+/* Merge nblocks result blocks (contiguous in device memory, block_bytes apart,
+ * e.g. the output of an RCCL all-gather) into one block holding the first k of
+ * their union in canonical order; approx = sum.  FingerprintDB::search's host
+ * merge, fingerprintdb_cuda.cu:363-380.  Enqueued on hip_stream of `device`. */
+int gsim_merge_device(int device, void* hip_stream, const void* d_blocks,
+                      uint32_t nblocks, size_t block_bytes, uint32_t k, void* d_result);
+
+/* ---- instrumentation ------------------------------------------------------ */
+int gsim_db_enable_timing(gsim_db* db, int enable); /* resets the accumulators */
+int gsim_db_get_timing(gsim_db* db, gsim_timing* out); /* synchronises the stream */
+/* score of every (common, popc_db) pair for a query of popcount a, computed ON
+ * THE DEVICE with the scan kernel's arithmetic: out[c * (max_b+1) + b].  Used
+ * by the parity tests to pin the f32 divide bit for bit. */
+int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint32_t a,
+                           uint32_t max_b, uint32_t max_c, float* out);
+
+const char* gsim_last_error(void);
+const char* gsim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUSIM_HIP_H */

@@ -1,0 +1,90 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/gpusim_hip.h declares, validates arguments, and fails LOUDLY (no CPU
+fallback) when there is no GPU.  No compute calls here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gpusimilarity_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "gpusim_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsim_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.load()
+    declared = header_symbols()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == declared
+
+
+def test_struct_layouts_match_header():
+    assert capi.HIT_DTYPE.itemsize == 12
+    assert capi.HEADER_DTYPE.itemsize == 16
+    assert capi.result_block_bytes(0) == 16
+    assert capi.result_block_bytes(1000) == 16 + 12000
+    assert capi.result_block_bytes(1) == 32  # rounded to 16
+
+
+def test_argument_validation():
+    L = capi.load()
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.gsim_db_create(1000, C.byref(h)) == -1  # not a multiple of 32
+    assert b"multiple of 32" in L.gsim_last_error()
+    assert L.gsim_db_create(0, C.byref(h)) == -1
+    assert L.gsim_db_create(1024, None) == -1
+    t = capi.Table(1024)
+    assert t.count() == 0 and t.fp_bits == 1024
+    t.add_rows(np.arange(64, dtype=np.uint32).reshape(2, 32))
+    assert t.count() == 2 and t.data_bytes() == 256
+    assert (t.row(1) == np.arange(32, 64, dtype=np.uint32)).all()
+    with pytest.raises(capi.GsimError):
+        t.row(2)
+    # searching a table that is not on a GPU is an error, never a CPU fallback
+    with pytest.raises(capi.GsimError) as e:
+        t.search(np.zeros(32, np.uint32), 5)
+    assert e.value.code == -5
+
+
+@pytest.mark.skipif(capi.device_count() > 0, reason="checks the no-GPU behaviour")
+def test_no_gpu_fails_loudly():
+    assert capi.device_count() == 0
+    assert capi.available_device_bytes() == 0
+    with pytest.raises(capi.GsimError) as e:
+        capi.next_device(1)
+    assert e.value.code == -2
+    t = capi.Table(1024)
+    t.add_rows(np.zeros((4, 32), np.uint32))
+    with pytest.raises(capi.GsimError) as e:
+        t.finalize(0, 1)
+    assert e.value.code == -2
+    with pytest.raises(capi.GsimError):
+        capi.Table(1024).generate(1, 0, 0, 10, 0)
+
+
+def test_search_cpu_entry_point_matches_reference_semantics():
+    """gsim_db_search_cpu is the reference's explicit host path (fingerprintdb_cuda.cpp:20-54);
+    it needs no GPU.  Checked against the oracle's restatement."""
+    import oracle_lib as O
+    from gpusimilarity_amd.fsim import read_fsim
+    fs = read_fsim(os.path.join(ROOT, "tests", "golden", "small.fsim"))
+    db = fs.rows()
+    t = capi.Table(1024).add_rows(db)
+    for qrow in (0, 3):
+        for k in (10, 15):
+            got = t.search_cpu(db[qrow], k)[0]
+            rows, sc = O.search_cpu(db[qrow], db, k)
+            assert list(got["row"]) == list(rows)
+            assert (got["score"].view(np.uint32) == sc.view(np.uint32)).all()
+    with pytest.raises(capi.GsimError):
+        t.search_cpu(db[0], 101)

@@ -1,0 +1,413 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden
+vectors.  Bar: bit-exact rows, integer popcounts, approx counts AND float score
+bit patterns (the only float op is one correctly rounded f32 divide).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpusimilarity_amd import capi
+from gpusimilarity_amd.fingerprintdb import FingerprintDB, get_gpu_count, get_next_gpu
+from gpusimilarity_amd.fsim import read_fsim
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_hits_equal(got, want, ctx=""):
+    assert len(got) == len(want), "%s: %d hits, oracle %d" % (ctx, len(got), len(want))
+    assert (got["row"] == want["row"]).all(), ctx
+    assert (bits(got["score"]) == bits(want["score"])).all(), ctx
+    assert (got["common"] == want["common"]).all(), ctx
+    assert (got["popc_db"] == want["popc_db"]).all(), ctx
+
+
+def make_table(db, device=0, ndevices=1):
+    t = capi.Table(db.shape[1] * 32)
+    t.add_rows(db)
+    t.finalize(device, ndevices)
+    return t
+
+
+def check_against_oracle(t, db, q, k, cutoff=0.0, ctx="", **kw):
+    hits, approx = t.search(q, k, cutoff, **kw)
+    okw = {}
+    if "metric" in kw:
+        okw = dict(metric=kw["metric"], alpha=kw.get("alpha", 1.0), beta=kw.get("beta", 1.0))
+    want, wapprox = O.search(q, db, k, cutoff, nthreads=8, **okw)
+    assert int(approx[0]) == wapprox, ctx
+    assert_hits_equal(hits[0], want, ctx)
+    return hits[0]
+
+
+# ---------------------------------------------------------------------------
+# the f32 divide, pinned bit for bit over the whole integer domain
+# ---------------------------------------------------------------------------
+
+def test_score_arithmetic_bit_exact():
+    L = O.lib()
+    for a in (0, 1, 37, 64, 512, 1024):
+        tab = capi.debug_score_table(capi.METRIC_TANIMOTO, 0.0, 0.0, a, 1100, 64 if a > 64 else a)
+        for c in range(tab.shape[0]):
+            for b in (0, 1, c, c + 1, 2 * c + 3, 77, 500, 1024, 1100):
+                if b > 1100:
+                    continue
+                ref = np.float32(L.gso_score_one(0, 0.0, 0.0, a, b, c))
+                got = tab[c, b]
+                assert bits(got) == bits(ref) or (np.isnan(got) and np.isnan(ref)), (a, b, c)
+    # dense sweep for one query popcount: every (c, b) pair
+    a = 48
+    tab = capi.debug_score_table(capi.METRIC_TANIMOTO, 0.0, 0.0, a, 2048, a)
+    cc, bb = np.meshgrid(np.arange(a + 1), np.arange(2049), indexing="ij")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = cc.astype(np.float32) / (a + bb - cc).astype(np.float32)
+    same = (bits(tab) == bits(ref)) | (np.isnan(tab) & np.isnan(ref))
+    assert same.all()
+    # Tversky: same expression order as the oracle
+    al, be = np.float32(0.3), np.float32(0.7)
+    tab = capi.debug_score_table(capi.METRIC_TVERSKY, al, be, 60, 300, 60)
+    for c in range(0, 61, 7):
+        for b in range(c, 301, 13):
+            ref = np.float32(L.gso_score_one(1, al, be, 60, b, c))
+            assert bits(tab[c, b]) == bits(ref) or (np.isnan(tab[c, b]) and np.isnan(ref)), (b, c)
+
+
+# ---------------------------------------------------------------------------
+# the reference's own tests (test/test_gpusim.cpp), through the FingerprintDB twin
+# ---------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def small_db():
+    fs = read_fsim(os.path.join(GOLD, "small.fsim"))
+    db = FingerprintDB(fs.fp_bitcount, fs.fp_count, fs.dbkey, fs.fp_blocks, list(fs.smiles), list(fs.ids))
+    db.copyToGPU(1, device=0)
+    return db, fs
+
+
+def test_ref_CompareGPUtoCPU(small_db):
+    """test_gpusim.cpp:29-69 -- rand()%20 == 3 in the reference's per-test process."""
+    db, fs = small_db
+    fp = db.getFingerprint(3)
+    for return_count in (10, 15):
+        gs, gi, gsc, _ = db.search(fp, "pass", return_count, 0.0)
+        cs, ci, csc = db.search_cpu(fp, "pass", return_count, 0.0)
+        assert len(gs) == return_count
+        assert gs == cs and gi == ci
+        assert (bits(gsc) == bits(csc)).all()
+    assert db.search(fp, "wrong-key", 10, 0.0) == ([], [], [], 0)  # fingerprintdb_cuda.cu:349-352
+
+
+def test_ref_TestSimilarityCutoff(small_db):
+    """test_gpusim.cpp:101-128 -- the reference's numeric known-answer test."""
+    db, fs = small_db
+    fp = db.getFingerprint(0)
+    for cutoff, n_ret, approx in zip((0, 0.1, 0.3, 0.4), (10, 10, 3, 1), (100, 86, 3, 1)):
+        smiles, ids, scores, ap = db.search(fp, "pass", 10, cutoff)
+        assert len(smiles) == n_ret
+        assert ap == approx
+    assert db.getID(3) == b"ZINC00000022"  # the id TestSearchMultiple pins (:97)
+
+
+def test_ref_getNextGPU():
+    """test_gpusim.cpp:168-181"""
+    n = get_gpu_count()
+    assert n >= 1
+    first = [get_next_gpu(1) for _ in range(n)]
+    second = [get_next_gpu(1) for _ in range(n)]
+    assert sorted(first) == list(range(n)) and first == second
+
+
+def test_golden_small_fsim(small_db):
+    db, fs = small_db
+    rows = fs.rows()
+    g = json.load(open(os.path.join(GOLD, "small_fsim_topk.json")))
+    for qe in g["queries"]:
+        for case in qe["cases"]:
+            h, ap = db.search_hits(rows[qe["query_row"]], case["k"], case["cutoff"])
+            assert ap == case["approx"]
+            assert [int(r) for r in h["row"]] == case["rows"]
+            assert ["%08x" % int(b) for b in bits(h["score"])] == case["score_bits"]
+            assert [int(c) for c in h["common"]] == case["common"]
+            assert [int(c) for c in h["popc_db"]] == case["popc_db"]
+
+
+def test_golden_synthetic_and_ties():
+    g = json.load(open(os.path.join(GOLD, "synthetic_topk.json")))
+    for tb in g["tables"]:
+        db = O.synth_rows(tb["seed"], tb["kind"], 0, tb["nrows"], tb["W"])
+        t = make_table(db)
+        for qe in tb["queries"]:
+            q = db[qe["query_row"]] if qe["kind"] == "db_row" else \
+                O.synth_rows(qe["fresh_seed"], tb["kind"], qe["fresh_row"], 1, tb["W"])[0]
+            for case in qe["cases"]:
+                h, ap = t.search(q, case["k"], case["cutoff"])
+                assert int(ap[0]) == case["approx"]
+                assert [int(r) for r in h[0]["row"]] == case["rows"]
+                assert ["%08x" % int(b) for b in bits(h[0]["score"])] == case["score_bits"]
+                assert [int(c) for c in h[0]["common"]] == case["common"]
+        t.close()
+    g = json.load(open(os.path.join(GOLD, "ties_topk.json")))
+    base = O.synth_rows(g["seed"], 0, 0, 4, 32)
+    db = np.ascontiguousarray(np.tile(base, (10, 1)))
+    t = make_table(db)
+    for case in g["cases"]:
+        h, ap = t.search(db[0], case["k"], case["cutoff"])
+        assert [int(r) for r in h[0]["row"]] == case["rows"] and int(ap[0]) == case["approx"]
+    nc = g["nan_cases"]
+    z = np.zeros((nc["nrows"], 32), dtype=np.uint32)
+    for r, (w, v) in nc["rows_hex_nonzero"].items():
+        z[int(r), w] = v
+    tz = make_table(z)
+    for case in nc["cases"]:
+        h, ap = tz.search(z[0], case["k"], case["cutoff"])
+        assert [int(r) for r in h[0]["row"]] == case["rows"] and int(ap[0]) == case["approx"]
+        assert ["%08x" % int(b) for b in bits(h[0]["score"])] == case["score_bits"]
+
+
+# ---------------------------------------------------------------------------
+# seeded tables vs the oracle
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,W,kind", [(200_000, 32, 0), (150_000, 32, 1), (60_000, 64, 0), (70_001, 16, 0),
+                                      (33_333, 8, 1), (20_000, 4, 0), (9_000, 128, 0), (3_000, 256, 1),
+                                      (5_000, 5, 0), (4_097, 33, 1), (10_000, 1, 1)])
+def test_seeded_tables_match_oracle(n, W, kind):
+    db = O.synth_rows(0x5EED0001 + W, kind, 0, n, W)
+    t = make_table(db)
+    for qi in range(2):
+        q = db[O.query_row(qi, n)]
+        for k, cutoff in ((1000, 0.0), (10, 0.0), (100, 0.15), (1, 0.0)):
+            check_against_oracle(t, db, q, k, cutoff, ctx="n=%d W=%d kind=%d q=%d k=%d c=%g" % (n, W, kind, qi, k, cutoff))
+    fresh = O.synth_rows(0x5EED0002, kind, 999, 1, W)[0]
+    check_against_oracle(t, db, fresh, 257, 0.0, ctx="fresh")
+    t.close()
+
+
+def test_ragged_and_edge_sizes():
+    W = 32
+    for n in (1, 7, 63, 64, 65, 511, 513, 4095, 4097):
+        db = O.synth_rows(0xE46E, 0, 0, n, W)
+        t = make_table(db)
+        for k in (0, 1, n, n + 5, 1000):
+            check_against_oracle(t, db, db[n // 2], k, 0.0, ctx="n=%d k=%d" % (n, k))
+            check_against_oracle(t, db, db[0], k, 0.05, ctx="n=%d k=%d cut" % (n, k))
+        t.close()
+    # empty table
+    t = capi.Table(1024)
+    t.add_rows(np.zeros((0, 32), np.uint32))
+    t.finalize(0, 1)
+    h, ap = t.search(np.ones(32, np.uint32), 10)
+    assert len(h[0]) == 0 and int(ap[0]) == 0
+
+
+def test_cutoff_semantics():
+    db = O.synth_rows(0xC0701, 0, 0, 50_000, 32)
+    t = make_table(db)
+    q = db[123]
+    for cutoff in (-1.0, 0.0, 1e-9, 0.05, 0.0999, 0.1, 0.5, 1.0, 1.0001, 5.0):
+        check_against_oracle(t, db, q, 300, np.float32(cutoff), ctx="cutoff=%g" % cutoff)
+    # all-zero query: every score is 0/0 = NaN or 0 -> 0 (fingerprintdb_cuda.cu:101)
+    z = np.zeros(32, np.uint32)
+    check_against_oracle(t, db, z, 50, 0.0, ctx="zero query")
+    check_against_oracle(t, db, z, 50, 0.2, ctx="zero query cut")
+
+
+def test_heavy_ties_force_radix_select():
+    """> SELECT_CAP finalists share the k-th score: the in-kernel radix select must
+    return the LOWEST row indices of the tie group (SURVEY App. C tie experiment)."""
+    base = O.synth_rows(0x71E5, 0, 0, 3, 32)
+    n = 40_000
+    db = np.ascontiguousarray(np.tile(base, (n // 3 + 1, 1))[:n])
+    t = make_table(db)
+    for k in (5, 100, 1000, 8192):
+        h = check_against_oracle(t, db, db[0], k, 0.0, ctx="ties k=%d" % k)
+        assert (h["row"] == np.arange(k) * 3).all()
+    # all rows identical AND equal to the query: one giant tie group
+    same = np.ascontiguousarray(np.tile(base[:1], (30_000, 1)))
+    t2 = make_table(same)
+    h = check_against_oracle(t2, same, same[0], 777, 0.5, ctx="all identical")
+    assert (h["row"] == np.arange(777)).all()
+
+
+def test_large_k_path():
+    db = O.synth_rows(0xB16, 0, 0, 120_000, 32)
+    t = make_table(db)
+    q = db[77]
+    for k in (8193, 20_000, 120_000, 200_000):
+        check_against_oracle(t, db, q, k, 0.0, ctx="large k=%d" % k)
+    check_against_oracle(t, db, q, 50_000, 0.04, ctx="large k cutoff")
+
+
+def test_tversky_matches_oracle():
+    for W, kind in ((64, 0), (32, 1)):
+        db = O.synth_rows(0x7E25, kind, 0, 80_000, W)
+        t = make_table(db)
+        q = db[4242]
+        for al, be in ((0.3, 0.7), (1.0, 1.0), (0.0, 1.0), (0.5, 0.5)):
+            check_against_oracle(t, db, q, 500, 0.0, ctx="tversky %g %g" % (al, be), metric=capi.METRIC_TVERSKY,
+                                 alpha=np.float32(al), beta=np.float32(be))
+        check_against_oracle(t, db, q, 500, 0.3, ctx="tversky cutoff", metric=capi.METRIC_TVERSKY,
+                             alpha=np.float32(0.3), beta=np.float32(0.7))
+        # Tversky(1,1) == Tanimoto bit for bit
+        a, _ = t.search(q, 500, 0.0)
+        b, _ = t.search(q, 500, 0.0, metric=capi.METRIC_TVERSKY, alpha=1.0, beta=1.0)
+        assert_hits_equal(a[0], b[0], "tversky(1,1)")
+
+
+def test_multi_query_batch():
+    db = O.synth_rows(0xBA7C4, 0, 0, 30_000, 32)
+    t = make_table(db)
+    qs = np.stack([db[O.query_row(i, 30_000)] for i in range(9)])
+    hits, approx = t.search(qs, 64, 0.0)
+    for i in range(9):
+        want, wap = O.search(qs[i], db, 64, 0.0)
+        assert_hits_equal(hits[i], want, "batch q=%d" % i)
+        assert int(approx[i]) == wap
+
+
+def test_generate_matches_oracle_generator():
+    for kind, W in ((0, 32), (1, 32), (0, 64), (1, 5)):
+        t = capi.Table(W * 32)
+        t.generate(0x5EED0001, kind, 1_000, 20_000, 0)
+        assert t.count() == 20_000
+        for r in (0, 1, 63, 64, 19_999, 7_777):
+            want = O.synth_rows(0x5EED0001, kind, 1_000 + r, 1, W)[0]
+            assert (t.row(r) == want).all()
+        db = O.synth_rows(0x5EED0001, kind, 1_000, 20_000, W)
+        check_against_oracle(t, db, db[5], 100, 0.0, ctx="generated table")
+        t.close()
+
+
+def test_device_result_blocks_and_merge():
+    """Shards as separate handles + gsim_merge_device == whole-table search
+    (the multi-GPU data path, exercised on one GPU)."""
+    import torch
+    n, W, k, G = 100_000, 32, 1000, 4
+    db = O.synth_rows(0x6A7E4, 0, 0, n, W)
+    whole = make_table(db)
+    q = db[31337]
+    blk = capi.result_block_bytes(k)
+    # a NON-default stream: the handle's kernels, the merge and torch's copies are
+    # all ordered on it (a NULL stream would select the handle's own stream)
+    st = torch.cuda.Stream(device=0)
+    torch.cuda.set_stream(st)
+    stream = st.cuda_stream
+    assert stream != 0
+    gathered = torch.zeros(G * blk, dtype=torch.uint8, device="cuda:0")
+    shards = []
+    per = n // G
+    for g in range(G):
+        t = make_table(db[g * per:(g + 1) * per])
+        t.set_stream(stream)
+        t.set_row_base(g * per)
+        shards.append(t)
+    for cutoff in (0.0, 0.08):
+        for g, t in enumerate(shards):
+            t.search_device(q, k, gathered.data_ptr() + g * blk, cutoff)
+        out = torch.zeros(blk, dtype=torch.uint8, device="cuda:0")
+        capi.merge_device(0, stream, gathered.data_ptr(), G, blk, k, out.data_ptr())
+        torch.cuda.synchronize()
+        hits, approx, flags = capi.parse_result_block(out.cpu().numpy().tobytes(), k)
+        want, wap = O.search(q, db, k, cutoff, nthreads=8)
+        assert approx == wap
+        assert_hits_equal(hits, want, "merged cutoff=%g" % cutoff)
+        # each shard's block alone equals the oracle on that shard
+        for g in range(G):
+            h, ap, _ = capi.parse_result_block(gathered[g * blk:(g + 1) * blk].cpu().numpy().tobytes(), k)
+            w2, _ = O.search(q, db[g * per:(g + 1) * per], k, cutoff, row_base=g * per)
+            assert_hits_equal(h, w2, "shard %d" % g)
+    wh, _ = whole.search(q, k, 0.0)
+    want, _ = O.search(q, db, k, 0.0, nthreads=8)
+    assert_hits_equal(wh[0], want, "whole")
+
+
+def test_attach_device_rows_borrowed_torch_tensor():
+    import torch
+    db = O.synth_rows(0xA77AC4, 0, 0, 40_000, 32)
+    ten = torch.from_numpy(db.view(np.int32)).to("cuda:0")
+    t = capi.Table(1024)
+    t.attach_device_rows(ten.data_ptr(), 40_000, 0)
+    check_against_oracle(t, db, db[9], 200, 0.0, ctx="attached")
+    assert (t.row(39_999) == db[39_999]).all()
+
+
+@pytest.mark.skipif(capi.device_count() < 2, reason="needs >= 2 GPUs in one process")
+def test_in_process_multi_device_shards():
+    db = O.synth_rows(0x5AAD, 0, 0, 300_001, 32)
+    t = make_table(db, device=0, ndevices=0)
+    assert t.shard_count() == capi.device_count()
+    for qi in range(3):
+        check_against_oracle(t, db, db[O.query_row(qi, len(db))], 1000, 0.0, ctx="multi-device")
+
+
+# ---------------------------------------------------------------------------
+# BASELINE-size properties (the oracle cannot scan these in seconds)
+# ---------------------------------------------------------------------------
+
+def verify_hits_by_regeneration(hits, q, seed, kind, W, first_row=0):
+    """Every returned row is regenerated on the CPU and rescored by the oracle."""
+    a = int(np.unpackbits(q.view(np.uint8)).sum())
+    L = O.lib()
+    for h in hits:
+        row = O.synth_rows(seed, kind, first_row + int(h["row"]), 1, W)[0]
+        c = int(np.unpackbits((row & q).view(np.uint8)).sum())
+        b = int(np.unpackbits(row.view(np.uint8)).sum())
+        assert (c, b) == (int(h["common"]), int(h["popc_db"]))
+        assert bits(np.float32(L.gso_score_one(0, 0, 0, a, b, c))) == bits(h["score"])
+
+
+def canonical_sorted(hits):
+    s, r = hits["score"], hits["row"].astype(np.int64)
+    return all((s[i] > s[i + 1]) or (s[i] == s[i + 1] and r[i] < r[i + 1]) for i in range(len(hits) - 1))
+
+
+@pytest.mark.parametrize("nrows", [1_000_000, 100_000_000])
+def test_baseline_sizes_properties(nrows):
+    W, k, seed = 32, 1000, 0x5EED0001
+    free = capi.device_free_bytes(0)
+    if free < nrows * 128 * 1.3:
+        pytest.skip("not enough free HBM")
+    t = capi.Table(1024)
+    t.generate(seed, capi.SYNTH_SPARSE, 0, nrows, 0)
+    qrow = O.query_row(0, nrows)
+    q = t.row(qrow)
+    assert (q == O.synth_rows(seed, 0, qrow, 1, W)[0]).all()
+    hits, approx = t.search(q, k, 0.0)
+    h = hits[0]
+    assert len(h) == k and int(approx[0]) == nrows
+    assert int(h["row"][0]) == qrow and h["score"][0] == np.float32(1.0)  # self hit
+    assert canonical_sorted(h)
+    verify_hits_by_regeneration(h[:64], q, seed, 0, W)
+    verify_hits_by_regeneration(h[-64:], q, seed, 0, W)
+    # idempotence
+    h2, _ = t.search(q, k, 0.0)
+    assert_hits_equal(h2[0], h, "repeat")
+    # prefix property: top-100 is the prefix of top-1000
+    h3, _ = t.search(q, 100, 0.0)
+    assert_hits_equal(h3[0], h[:100], "prefix")
+    # cutoff at the k-th score keeps exactly the rows scoring >= it
+    kth = h["score"][-1]
+    h4, ap4 = t.search(q, 5000, kth)
+    assert int(ap4[0]) == len(h4[0]) or len(h4[0]) == 5000
+    assert_hits_equal(h4[0][:k], h, "cutoff at k-th")
+    assert (h4[0]["score"] >= kth).all()
+    # an independent CPU check of the threshold on a slice of the table: no row of the
+    # first 2 M rows outside the result scores above the k-th score
+    m = min(nrows, 2_000_000)
+    sl = O.synth_rows(seed, 0, 0, m, W)
+    top, _ = O.search(q, sl, k, 0.0, nthreads=8)
+    mine = h[h["row"] < m]
+    better = top[(top["score"] > kth) | ((top["score"] == kth) & (top["row"] <= h["row"][-1]))]
+    assert_hits_equal(mine, better, "slice cross-check")
+    t.close()
