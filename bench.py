@@ -142,7 +142,17 @@ def main():
         merged = torch.zeros(blk, dtype=torch.uint8, device=dev) if world > 1 else None
     host_out = torch.zeros(blk, dtype=torch.uint8).pin_memory()
 
+    bufs = table.make_search_buffers(1, k)
+
+    def one_query_single(q):
+        # single GPU: the C ABI's synchronous entry point (FingerprintDB::search): scan ->
+        # compact -> select, the select kernel writes the hits into pinned host memory,
+        # the call returns when they are there
+        table.search_into(q, k, bufs)
+
     def one_query(q):
+        if world == 1:
+            return one_query_single(q)
         with torch.cuda.stream(stream):
             table.search_device(q, k, local_block.data_ptr())
             if world > 1:
@@ -158,7 +168,10 @@ def main():
         one_query(queries[i])
     # sanity on the last warm-up query: the self hit leads the result
     if args.warmup:
-        hits, approx, _ = capi.parse_result_block(host_out.numpy().tobytes(), k)
+        if world == 1:
+            hits, approx = bufs[0][0, :bufs[1][0]], int(bufs[2][0])
+        else:
+            hits, approx, _ = capi.parse_result_block(host_out.numpy().tobytes(), k)
         want_row = query_row(args.warmup - 1, total_rows)
         assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
             "self hit missing: %r" % (hits[:3],)

@@ -210,6 +210,18 @@ class Table:
                                      approx.ctypes.data_as(C.POINTER(C.c_uint64))))
         return [hits[i, :counts[i]].copy() for i in range(nq)], approx
 
+    def make_search_buffers(self, nq, k):
+        """Preallocated outputs for :meth:`search_into` (latency-sensitive callers)."""
+        return (np.zeros((nq, max(k, 1)), dtype=HIT_DTYPE), np.zeros(nq, dtype=np.uint32),
+                np.zeros(nq, dtype=np.uint64))
+
+    def search_into(self, queries, k, bufs, cutoff=0.0, metric=METRIC_TANIMOTO, alpha=1.0, beta=1.0):
+        """gsim_db_search into caller-owned buffers; queries must be a C-contiguous uint32 array."""
+        hits, counts, approx = bufs
+        check(self._L.gsim_db_search(self._h, _u32(queries), hits.shape[0], k, cutoff, metric, alpha, beta,
+                                     hits.ctypes.data_as(C.c_void_p), _u32(counts),
+                                     approx.ctypes.data_as(C.POINTER(C.c_uint64))))
+
     def search_cpu(self, queries, k, cutoff=0.0):
         q = np.ascontiguousarray(queries, dtype=np.uint32).reshape(-1, self.W)
         nq = q.shape[0]

@@ -67,8 +67,10 @@ struct Shard {
     uint32_t* d_query = nullptr;
     gsim::QueryState* d_state = nullptr;
     unsigned long long* d_cand = nullptr;
+    uint32_t* d_cand_cb = nullptr;
     uint32_t* d_seg_count = nullptr;
     unsigned long long* d_final = nullptr;
+    uint32_t* d_final_cb = nullptr;
     uint32_t final_cap = 0;
     void* d_result = nullptr;
     size_t result_bytes = 0;
@@ -79,10 +81,11 @@ struct Shard {
     uint32_t q_next = 0;
     unsigned char* h_result = nullptr;
     size_t h_result_bytes = 0;
-    gsim::QueryState* h_state = nullptr; // ring of kTimingRing entries (stats only)
+    gsim::QueryState* h_state = nullptr; // staging for the running totals
     // timing
     std::vector<hipEvent_t> ev; // 3 per slot
     uint32_t ev_used = 0;
+    unsigned long long base_ncand = 0, base_nfinal = 0; // device totals when timing was enabled
 };
 
 } // namespace
@@ -111,6 +114,8 @@ int free_shard(Shard& s)
     if (s.d_query) (void) hipFree(s.d_query);
     if (s.d_state) (void) hipFree(s.d_state);
     if (s.d_cand) (void) hipFree(s.d_cand);
+    if (s.d_cand_cb) (void) hipFree(s.d_cand_cb);
+    if (s.d_final_cb) (void) hipFree(s.d_final_cb);
     if (s.d_seg_count) (void) hipFree(s.d_seg_count);
     if (s.d_final) (void) hipFree(s.d_final);
     if (s.d_result) (void) hipFree(s.d_result);
@@ -140,23 +145,26 @@ int setup_shard(gsim_db* db, Shard& s)
     s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     GSIM_HIP(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
     s.stream = s.own_stream;
-    const int wpc = env_int("GSIM_SCAN_WAVES_PER_CU", 8);
+    const int wpc = env_int("GSIM_SCAN_WAVES_PER_CU", 4);
     const int unroll = env_int("GSIM_SCAN_UNROLL", 8);
     s.geo = gsim::scan_geometry(s.nrows, db->W, s.num_cus, wpc, unroll);
     const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(db->W) * 4));
     GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
+    GSIM_HIP(hipMemset(s.d_state, 0, sizeof(gsim::QueryState))); // the select kernel keeps it zero between queries
     GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
+    GSIM_HIP(hipMalloc(&s.d_cand_cb, static_cast<size_t>(slots) * 4));
     GSIM_HIP(hipMalloc(&s.d_seg_count, static_cast<size_t>(s.geo.nwaves) * 4));
     s.final_cap = next_pow2_u32(slots);
     GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
+    GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
     GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(db->W) * 4 * kQueryRing, hipHostMallocDefault));
     for (int i = 0; i < kQueryRing; i++) {
         hipEvent_t e;
         GSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         s.q_ev.push_back(e);
     }
-    GSIM_HIP(hipHostMalloc(&s.h_state, sizeof(gsim::QueryState) * kTimingRing, hipHostMallocDefault));
+    GSIM_HIP(hipHostMalloc(&s.h_state, sizeof(gsim::QueryState), hipHostMallocDefault));
     return GSIM_OK;
 }
 
@@ -186,25 +194,27 @@ uint32_t popcount_words(const uint32_t* q, uint32_t W)
     return a;
 }
 
-// Enqueue one query on one shard; the result block ends up at d_out (device).
-// Nothing here synchronises with the host unless k > kSelectCap.
+// Enqueue one query on one shard; the result block ends up at `out`, which is
+// device memory or device-visible pinned host memory (zero-copy).  The stream
+// carries three kernels: scan -> compact -> select.  The query is read by the scan
+// straight from a pinned ring slot (no upload op) and the select kernel re-zeroes
+// the per-query state (no memset op).  Nothing here synchronises with the host
+// unless k > kSelectCap.
 int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                  float beta, uint32_t row_base, void* d_out)
+                  float beta, uint32_t row_base, void* out)
 {
     GSIM_HIP(hipSetDevice(s.device));
     const uint32_t slot = s.q_next++ % kQueryRing;
     uint32_t* hq = s.h_query + static_cast<size_t>(slot) * db->W;
     GSIM_HIP(hipEventSynchronize(s.q_ev[slot])); // no-op unless 16 searches are still queued
     std::memcpy(hq, query, static_cast<size_t>(db->W) * 4);
-    GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(db->W) * 4, hipMemcpyHostToDevice, s.stream));
-    GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream));
-    GSIM_HIP(hipMemsetAsync(s.d_state, 0, sizeof(gsim::QueryState), s.stream));
 
     gsim::ScanArgs a{};
     a.rows = s.d_rows;
     a.nrows = s.nrows;
     a.W = db->W;
-    a.query = s.d_query;
+    a.query = hq; // hipHostMalloc memory: device-visible at the same address
+    a.query_dev = s.d_query;
     a.qpop = popcount_words(query, db->W);
     a.k = k;
     a.cutoff = cutoff;
@@ -212,8 +222,15 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
     a.alpha = alpha;
     a.beta = beta;
     a.cand = s.d_cand;
+    a.cand_cb = s.d_cand_cb;
     a.seg_count = s.d_seg_count;
     a.state = s.d_state;
+    a.debug = static_cast<uint32_t>(env_int("GSIM_DEBUG", 0));
+    if (s.geo.lanes_per_row == 0 || s.nrows == 0) {
+        // generic-width scan reads the query per word: give it a device copy
+        GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(db->W) * 4, hipMemcpyHostToDevice, s.stream));
+        a.query = s.d_query;
+    }
 
     hipEvent_t* ev = nullptr;
     if (db->timing && s.ev_used < kTimingRing) {
@@ -228,12 +245,13 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
     }
     if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
+    GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream)); // the ring slot is free once the scan has run
     if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
-    if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.final_cap, s.stream));
+    if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
     if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
-        GSIM_HIP(gsim::launch_select(a, s.d_final, s.final_cap, row_base, d_out, s.stream));
+        GSIM_HIP(gsim::launch_select(a, s.d_final, s.d_final_cb, s.final_cap, row_base, out, s.stream));
     } else {
-        // large k: sort every finalist in global memory (host reads the count)
+        // large k: sort every finalist in global memory (the host reads the count)
         uint32_t nfinal = 0;
         GSIM_HIP(hipMemcpyAsync(&nfinal, &s.d_state->nfinal, 4, hipMemcpyDeviceToHost, s.stream));
         GSIM_HIP(hipStreamSynchronize(s.stream));
@@ -242,12 +260,11 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
         GSIM_HIP(gsim::launch_fill_zero_keys(s.d_final, nfinal, np2, s.stream));
         GSIM_HIP(gsim::launch_bitonic_global(s.d_final, np2, s.stream));
         const uint32_t nout = nfinal < k ? nfinal : k;
-        GSIM_HIP(gsim::launch_emit_hits(a, s.d_final, nout, row_base, s.nrows, 1u, d_out, s.stream));
+        GSIM_HIP(gsim::launch_emit_hits(a, s.d_final, nout, row_base, s.nrows, 1u, out, s.stream));
+        GSIM_HIP(gsim::launch_reset_state(s.d_state, s.stream));
     }
     if (ev) {
         GSIM_HIP(hipEventRecord(ev[2], s.stream));
-        GSIM_HIP(hipMemcpyAsync(&s.h_state[s.ev_used], s.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost,
-                                s.stream));
         s.ev_used++;
     }
     return GSIM_OK;
@@ -265,11 +282,20 @@ int drain_timing(gsim_db* db, Shard& s)
         GSIM_HIP(hipEventElapsedTime(&sel, s.ev[3 * i + 1], s.ev[3 * i + 2]));
         db->acc.scan_ms_sum += scan;
         db->acc.select_ms_sum += sel;
-        db->acc.candidates_sum += s.h_state[i].ncand;
-        db->acc.finalists_sum += s.h_state[i].nfinal;
         db->acc.queries++;
     }
     s.ev_used = 0;
+    return GSIM_OK;
+}
+
+// Running candidate / finalist totals kept on the device by the select kernel.
+int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal)
+{
+    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(hipMemcpyAsync(s.h_state, s.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost, s.stream));
+    GSIM_HIP(hipStreamSynchronize(s.stream));
+    *ncand = s.h_state->ncand_sum;
+    *nfinal = s.h_state->nfinal_sum;
     return GSIM_OK;
 }
 
@@ -563,17 +589,16 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
     if (rc != GSIM_OK) return rc;
     if ((!hits && k && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
     const size_t nsh = db->shards.size();
-    const size_t blk = gsim_result_block_bytes(k);
     std::vector<gsim_hit> merged;
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
         for (auto& s : db->shards) {
             rc = ensure_result_capacity(s, k);
             if (rc != GSIM_OK) return rc;
+            // the select kernel writes the block straight into pinned host memory
             rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta,
-                               db->row_base + static_cast<uint32_t>(s.first_row), s.d_result);
+                               db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
             if (rc != GSIM_OK) return rc;
-            GSIM_HIP(hipMemcpyAsync(s.h_result, s.d_result, blk, hipMemcpyDeviceToHost, s.stream));
         }
         uint64_t ap = 0;
         merged.clear();
@@ -692,11 +717,17 @@ int gsim_db_search_cpu(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32
 int gsim_db_enable_timing(gsim_db* db, int enable)
 {
     if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    db->timing = enable != 0;
+    db->acc = gsim_timing{};
     for (auto& s : db->shards) {
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
+        unsigned long long c = 0, f = 0;
+        rc = read_totals(s, &c, &f);
+        if (rc != GSIM_OK) return rc;
+        s.base_ncand = c;
+        s.base_nfinal = f;
     }
-    db->timing = enable != 0;
     db->acc = gsim_timing{};
     return GSIM_OK;
 }
@@ -704,9 +735,16 @@ int gsim_db_enable_timing(gsim_db* db, int enable)
 int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
 {
     if (!db || !out) return fail(GSIM_ERR_INVALID, "NULL argument");
+    db->acc.candidates_sum = 0;
+    db->acc.finalists_sum = 0;
     for (auto& s : db->shards) {
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
+        unsigned long long c = 0, f = 0;
+        rc = read_totals(s, &c, &f);
+        if (rc != GSIM_OK) return rc;
+        db->acc.candidates_sum += c - s.base_ncand;
+        db->acc.finalists_sum += f - s.base_nfinal;
     }
     *out = db->acc;
     return GSIM_OK;

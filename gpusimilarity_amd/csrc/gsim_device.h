@@ -16,14 +16,19 @@ constexpr int kSelectCap = 8192;
 constexpr int kScanBlock = 256; // 4 wavefronts
 
 // Device-resident per-query state, zeroed before every scan.
+// Device-resident per-query state.  Zero when a query starts: allocated zeroed,
+// and the last workgroup of the select kernel re-zeroes it for the next query
+// (no per-query memset on the stream).
 struct QueryState {
-    uint32_t ghist[kScanBins];   // candidates per coarse bin (bins >= each wave's final threshold)
+    uint32_t ghist[kScanBins];   // candidates per coarse bin (bins >= each workgroup's final threshold)
     unsigned long long kept;     // rows with score >= cutoff (cutoff > 0 only)
     unsigned long long ncand;    // total candidates emitted by the scan
     uint32_t nfinal;             // finalists appended by the compaction
-    uint32_t bstar;              // coarse bin of the k-th best score
-    uint32_t flags;              // reserved
-    uint32_t pad;
+    uint32_t done;               // select-kernel workgroups that have finished (ticket)
+    // --- not reset per query: running totals for gsim_db_get_timing ---
+    unsigned long long ncand_sum;
+    unsigned long long nfinal_sum;
+    unsigned long long queries;
 };
 
 struct ScanGeometry {
@@ -39,15 +44,18 @@ struct ScanArgs {
     const void* rows;       // device, row-major uint32[nrows][W]
     uint64_t nrows;
     uint32_t W;             // words per fingerprint
-    const uint32_t* query;  // device, W words
+    const uint32_t* query;  // W words; device memory or device-visible pinned host memory (read once per wave)
+    uint32_t* query_dev;    // device copy for the kernels after the scan (the scan writes it when != query)
     uint32_t qpop;          // popc(query)
     uint32_t k;
     float cutoff;
     int metric;
     float alpha, beta;
     unsigned long long* cand; // device, nwaves*seg_cap keys
+    uint32_t* cand_cb;        // device, nwaves*seg_cap (common << 16 | popc_db), parallel to cand
     uint32_t* seg_count;      // device, nwaves
     QueryState* state;        // device
+    uint32_t debug;           // GSIM_DEBUG bits (experiments only; 0 in production)
 };
 
 // Geometry of the scan grid for a table (host side, no device work).
@@ -57,12 +65,14 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s);
 
 // Compaction of candidates at or above the k-th best coarse bin into `finalists`.
 hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned long long* finalists,
-                          uint32_t finalists_cap, hipStream_t s);
+                          uint32_t* finalists_cb, uint32_t finalists_cap, hipStream_t s);
 
 // Final exact select + sort of the finalists (k <= kSelectCap, any finalist count);
 // writes {gsim_result_header; gsim_hit[k]}.
-hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap,
-                         uint32_t row_base, void* d_result, hipStream_t s);
+hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, const uint32_t* finalists_cb,
+                         uint32_t finalists_cap, uint32_t row_base, void* d_result, hipStream_t s);
+// Re-zero the per-query part of the state (large-k path only; the select kernel does it otherwise).
+hipError_t launch_reset_state(QueryState* state, hipStream_t s);
 
 // Large-k path (k > kSelectCap): global-memory bitonic sort of all finalists.
 hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s);

@@ -171,35 +171,57 @@ __device__ __forceinline__ void find_threshold(const uint32_t* hist, uint32_t k,
 // K1: the scan
 // ---------------------------------------------------------------------------
 
-// Streaming top-k filter state of one wavefront (all members wave-uniform
-// except `kept`).  Validity argument: `tau` is the k-th best coarse bin among
-// the rows THIS wave has seen, a subset of the table, so it never exceeds the
-// bin of the table's k-th best score; a row whose bin is below tau has a
-// strictly smaller score than k rows already seen and cannot be in the top-k.
+// Streaming top-k filter shared by the wavefronts of one workgroup, in LDS.
+//
+// `hist` counts, per coarse bin, the rows this workgroup has emitted; `tau` is a
+// bin such that at least k rows seen by the workgroup have bin >= tau.  Those
+// rows are a subset of the table, so tau never exceeds the bin of the table's
+// k-th best score: a row whose bin is below tau scores strictly less than k
+// rows already seen and cannot be in the top-k.  All updates are monotone
+// (hist and tau only grow), which is what makes the sharing barrier-free: a
+// wave that scans `hist` while others add to it reads values <= the final
+// counts, so a bin B with sum_{b>=B} read[b] >= k is still a valid threshold; a
+// wave that compares against a stale (lower) tau only emits more than needed.
+struct BlockFilter {
+    uint32_t hist[kScanBins];
+    uint32_t tau;     // current threshold bin (monotone, atomicMax)
+    uint32_t nemit;   // candidates emitted by the workgroup so far
+    uint32_t trigger; // nemit value at which the threshold is recomputed next
+    uint32_t pad;
+};
+
+// Per-wave view of the filter (members wave-uniform except `kept`).
 struct WaveFilter {
-    uint32_t* hist; // LDS, private to the wave
-    u64* seg;       // this wave's candidate segment
-    uint32_t k, tau, nge, trigger, step, cursor, kept;
+    BlockFilter* sh;
+    u64* seg;         // this wave's private candidate segment (keys)
+    uint32_t* seg_cb; // ... and the popcounts the score came from (common << 16 | popc_db)
+    uint32_t k, tau, step, cursor, kept;
     float cutoff;
     bool has_cutoff;
 
-    __device__ __forceinline__ void init(uint32_t* h, u64* s, uint32_t kk, float cut)
+    __device__ __forceinline__ void init(BlockFilter* b, u64* s, uint32_t* scb, uint32_t kk, float cut)
     {
-        hist = h;
+        sh = b;
         seg = s;
+        seg_cb = scb;
         k = kk;
         cutoff = cut;
         has_cutoff = cut > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
         tau = kk ? 0u : static_cast<uint32_t>(kScanBins);
-        nge = 0;
-        trigger = kk;
         step = kk / 8 > 32 ? kk / 8 : 32;
         cursor = 0;
         kept = 0;
     }
 
+    // pick up a threshold raised by another wave of the workgroup
+    __device__ __forceinline__ void refresh()
+    {
+        const uint32_t t = __hip_atomic_load(&sh->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tau = t > tau ? t : tau;
+    }
+
     // One row per lane (or an inactive lane).
-    __device__ __forceinline__ void offer(bool active, uint32_t row, float raw_score, int lane)
+    __device__ __forceinline__ void offer(bool active, uint32_t row, float raw_score, uint32_t cb, int lane)
     {
         const float s = apply_cutoff(raw_score, cutoff);
         const bool keep = active && (!has_cutoff || s != 0.0f);
@@ -209,15 +231,26 @@ struct WaveFilter {
         const u64 m = __ballot(cand);
         if (m != 0) {
             if (cand) {
-                seg[cursor + lane_rank(m)] = make_key(s, row);
-                atomicAdd(&hist[bin], 1u); // ds_add_u32: lanes of one wave may share a bin
+                const uint32_t slot = cursor + lane_rank(m);
+                seg[slot] = make_key(s, row);
+                seg_cb[slot] = cb;
+                atomicAdd(&sh->hist[bin], 1u); // ds_add_u32
             }
             const uint32_t n = static_cast<uint32_t>(__popcll(m));
             cursor += n;
-            nge += n;
-            if (nge >= trigger) {
-                find_threshold(hist, k, lane, tau, nge);
-                trigger = nge + step;
+            uint32_t old = 0;
+            if (lane == 0) old = atomicAdd(&sh->nemit, n);
+            old = __builtin_amdgcn_readfirstlane(old);
+            const uint32_t trig = __hip_atomic_load(&sh->trigger, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old < trig && old + n >= trig) { // exactly one wave crosses a given trigger
+                uint32_t bin_k, cnt;
+                find_threshold(sh->hist, k, lane, bin_k, cnt);
+                if (lane == 0) {
+                    if (cnt >= k) atomicMax(&sh->tau, bin_k);
+                    const uint32_t now = __hip_atomic_load(&sh->nemit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&sh->trigger, now + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (cnt >= k && bin_k > tau) tau = bin_k;
             }
         }
     }
@@ -228,19 +261,36 @@ struct WaveFilter {
             a.seg_count[w] = cursor;
             if (cursor) atomicAdd(&a.state->ncand, static_cast<u64>(cursor));
         }
-        // Bins at or above the final threshold are merged into the table-wide
-        // histogram.  It is exact for every bin >= max over waves of tau, which
-        // is all K2 needs (see compact_kernel).
-        for (int i = lane; i < kScanBins; i += 64) {
-            const uint32_t h = hist[i];
-            if (static_cast<uint32_t>(i) >= tau && h != 0) atomicAdd(&a.state->ghist[i], h);
-        }
         if (has_cutoff) {
             const uint32_t tot = wave_sum(kept);
             if (lane == 0 && tot) atomicAdd(&a.state->kept, static_cast<u64>(tot));
         }
     }
 };
+
+__device__ __forceinline__ void block_filter_init(BlockFilter* sh, uint32_t k)
+{
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) sh->hist[i] = 0;
+    if (threadIdx.x == 0) {
+        sh->tau = k ? 0u : static_cast<uint32_t>(kScanBins);
+        sh->nemit = 0;
+        sh->trigger = k ? k : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+}
+
+// After every wave of the workgroup is done: bins at or above the final
+// threshold are merged into the table-wide histogram.  ghist is exact for
+// every bin >= max over workgroups of tau, which is all K2 needs.
+__device__ __forceinline__ void block_filter_flush(BlockFilter* sh, const ScanArgs& a)
+{
+    __syncthreads();
+    const uint32_t tau = sh->tau;
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) {
+        const uint32_t h = sh->hist[i];
+        if (static_cast<uint32_t>(i) >= tau && h != 0) atomicAdd(&a.state->ghist[i], h);
+    }
+}
 
 // 16 bytes per lane; a wave64 instruction covers 1 KiB of consecutive table bytes.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -250,85 +300,115 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
     return __builtin_nontemporal_load(p); // read once: keep it out of the caches' way
 }
 
-// LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads in flight per lane.
-// A wave iteration covers CH = U * 64 / LPR consecutive rows = U KiB of the table.
-template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_kernel(ScanArgs a, ScanGeometry g)
+// LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads per lane per chunk.
+// A chunk is CH = U * 64 / LPR consecutive rows = U KiB of the table; wave w takes
+// chunks w, w + nwaves, ...  The loads of the next chunk are issued before the
+// current one is reduced (register double buffer): 2U KiB in flight per wave.
+// The loop body over full chunks is branch-free up to the (rare) emit path, so the
+// compiler's s_waitcnt placement leaves the prefetch in flight during the reduce;
+// the table's last, partial chunk is handled once, outside the loop.
+template <int LPR, int U, bool FULL>
+__device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q, u64 row0, const ScanArgs& a,
+                                             WaveFilter& f, int lane)
 {
-    __shared__ uint32_t s_hist[kScanBlock / 64][kScanBins];
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wib);
-    uint32_t* hist = s_hist[wib];
-    for (int i = lane; i < kScanBins; i += 64) hist[i] = 0;
-
-    constexpr int RPL = 64 / LPR; // rows per load instruction
-    constexpr int CH = U * RPL;   // rows per wave iteration
+    constexpr int RPL = 64 / LPR;
     constexpr int ROUNDS = (U + LPR - 1) / LPR;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
+    uint32_t v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        // v_and + v_bcnt_u32_b32 (popcount with accumulate)
+        const uint32_t cc =
+            __popc(d[j].x & q.x) + __popc(d[j].y & q.y) + __popc(d[j].z & q.z) + __popc(d[j].w & q.w);
+        const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
+        v[j] = group_sum<LPR>((cc << 16) + bb); // both sums < 2^16 (fp_bits <= 32768)
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        // lane (grp, sub) takes the row of load j = r*LPR + sub
+        uint32_t val = 0;
+#pragma unroll
+        for (int jj = 0; jj < U; jj++) {
+            if (jj / LPR == r) val = (sub == jj % LPR) ? v[jj] : val;
+        }
+        const int j = r * LPR + sub;
+        const u64 row = row0 + static_cast<u64>(j * RPL + grp);
+        const bool active = (j < U) && (FULL || row < a.nrows);
+        const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
+        f.offer(active, static_cast<uint32_t>(row), s, val, lane);
+    }
+}
 
-    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[sub];
+template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_kernel(ScanArgs a, ScanGeometry g)
+{
+    __shared__ BlockFilter s_filter;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
+    block_filter_init(&s_filter, a.k);
+
+    constexpr int RPL = 64 / LPR; // rows per load instruction
+    constexpr int CH = U * RPL;   // rows per chunk
+    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
     const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    if (w == 0 && lane < LPR && a.query_dev != a.query) reinterpret_cast<u32x4*>(a.query_dev)[lane] = q;
 
     WaveFilter f;
-    f.init(hist, a.cand + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+    f.init(&s_filter, a.cand + static_cast<u64>(w) * g.seg_cap, a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k,
+           a.cutoff);
 
-    const u64 nfull = a.nrows / CH;
-    for (u64 c = w; c < g.nchunks; c += g.nwaves) {
-        const u64 row0 = c * CH;
-        const u32x4* p = db + row0 * LPR + lane;
-        const bool full = c < nfull;
-        u32x4 d[U];
-        if (full) {
+    const u64 nfull = a.nrows / CH; // chunks with all CH rows present
+    if (w < nfull) {
+        const u64 last = w + (nfull - 1 - w) / g.nwaves * g.nwaves; // this wave's last full chunk
+        u32x4 nxt[U];
+        {
+            const u32x4* p = db + static_cast<u64>(w) * (CH * LPR) + lane;
 #pragma unroll
-            for (int j = 0; j < U; j++) d[j] = stream_load(p + j * 64);
-        } else {
-#pragma unroll
-            for (int j = 0; j < U; j++) {
-                const u64 row = row0 + static_cast<u64>(j * RPL + grp);
-                d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
-            }
+            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
         }
-        uint32_t v[U];
+        for (u64 c = w;; c += g.nwaves) {
+            u32x4 d[U];
 #pragma unroll
-        for (int j = 0; j < U; j++) {
-            // v_and + v_bcnt_u32_b32 (popcount with accumulate)
-            const uint32_t cc = __popc(d[j].x & q.x) + __popc(d[j].y & q.y) + __popc(d[j].z & q.z) +
-                                __popc(d[j].w & q.w);
-            const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
-            v[j] = group_sum<LPR>((cc << 16) + bb); // both sums < 2^16 (fp_bits <= 32768)
-        }
+            for (int j = 0; j < U; j++) d[j] = nxt[j];
+            // prefetch; on the final trip it re-reads the last chunk (no branch in the body)
+            const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last;
+            const u32x4* p = db + cn * (CH * LPR) + lane;
 #pragma unroll
-        for (int r = 0; r < ROUNDS; r++) {
-            // lane (grp, sub) takes the row of load j = r*LPR + sub
-            uint32_t val = 0;
-#pragma unroll
-            for (int jj = 0; jj < U; jj++) {
-                if (jj / LPR == r) val = (sub == jj % LPR) ? v[jj] : val;
-            }
-            const int j = r * LPR + sub;
-            const u64 row = row0 + static_cast<u64>(j * RPL + grp);
-            const bool active = (j < U) && (full || row < a.nrows);
-            const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
-            f.offer(active, static_cast<uint32_t>(row), s, lane);
+            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
+            f.refresh();
+            reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
+            if (c == last) break;
         }
     }
+    if (nfull < g.nchunks && w == nfull % g.nwaves) { // the table's partial last chunk
+        const u64 row0 = nfull * CH;
+        const u32x4* p = db + row0 * LPR + lane;
+        const int grp = lane / LPR;
+        u32x4 d[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const u64 row = row0 + static_cast<u64>(j * RPL + grp);
+            d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
+        }
+        f.refresh();
+        reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
+    }
     f.finish(w, a, lane);
+    block_filter_flush(&s_filter, a);
 }
 
 // Any fingerprint width (W words, not a power-of-two number of 16-byte lanes):
 // one row per lane, word loop.  Correct for every W; not the tuned path.
 __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, ScanGeometry g)
 {
-    __shared__ uint32_t s_hist[kScanBlock / 64][kScanBins];
+    __shared__ BlockFilter s_filter;
     const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wib);
-    uint32_t* hist = s_hist[wib];
-    for (int i = lane; i < kScanBins; i += 64) hist[i] = 0;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
+    block_filter_init(&s_filter, a.k);
     const uint32_t* __restrict__ db = reinterpret_cast<const uint32_t*>(a.rows);
     WaveFilter f;
-    f.init(hist, a.cand + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+    f.init(&s_filter, a.cand + static_cast<u64>(w) * g.seg_cap, a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k,
+           a.cutoff);
     for (u64 c = w; c < g.nchunks; c += g.nwaves) {
         const u64 row = c * 64 + lane;
         const bool active = row < a.nrows;
@@ -341,48 +421,107 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
                 bb += __popc(x);
             }
         }
+        f.refresh();
         const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc);
-        f.offer(active, static_cast<uint32_t>(row), s, lane);
+        f.offer(active, static_cast<uint32_t>(row), s, (cc << 16) + bb, lane);
     }
     f.finish(w, a, lane);
+    block_filter_flush(&s_filter, a);
 }
 
 // ---------------------------------------------------------------------------
 // K2: compaction at the k-th best coarse bin
 // ---------------------------------------------------------------------------
 //
-// ghist[b] counts the candidates of the waves whose final threshold is <= b,
-// i.e. it under-counts bins below T = max_w tau_w and is exact at and above T.
-// The table's k-th best bin B* is >= T (every tau_w is a lower bound for it), so
-// the largest B with sum_{b>=B} ghist[b] >= k is exactly B*; every top-k row has
-// bin >= B* >= tau_w and was therefore emitted by its wave.
+// ghist[b] counts the candidates of the workgroups whose final threshold is <= b,
+// i.e. it under-counts bins below T = max over workgroups of tau and is exact at
+// and above T.  The table's k-th best bin B* is >= T (every tau is a lower bound
+// for it), so the largest B with sum_{b>=B} ghist[b] >= k is exactly B*; every
+// top-k row has bin >= B* >= its workgroup's tau and was therefore emitted.
+constexpr int kCompactStage = 1024; // finalists staged in LDS per workgroup
+
+// One wavefront per candidate segment, several loads in flight per lane.  The
+// survivors of a workgroup are staged in LDS and appended to `finalists` with ONE
+// global atomic per workgroup (a single hot word only sustains ~90 returning
+// atomics per microsecond); entries beyond the staging area (heavy ties) are
+// appended directly.
 __global__ __launch_bounds__(kScanBlock) void compact_kernel(ScanArgs a, ScanGeometry g, u64* finalists,
-                                                             uint32_t cap)
+                                                             uint32_t* finalists_cb, uint32_t cap)
 {
+    __shared__ u64 s_stage[kCompactStage];
+    __shared__ uint32_t s_stage_cb[kCompactStage];
+    __shared__ uint32_t s_n, s_base;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    const uint32_t n = a.seg_count[w];
-    if (n == 0 || a.k == 0) return;
-    uint32_t bstar, cnt;
-    find_threshold(a.state->ghist, a.k, lane, bstar, cnt);
-    const u64* seg = a.cand + static_cast<u64>(w) * g.seg_cap;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t i = base + lane;
-        u64 key = 0;
-        bool ok = false;
-        if (i < n) {
-            key = seg[i];
-            ok = coarse_bin(key_score(static_cast<uint32_t>(key >> 32))) >= bstar;
-        }
-        const u64 m = __ballot(ok);
-        if (m != 0) {
-            uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&a.state->nfinal, static_cast<uint32_t>(__popcll(m)));
-            pos = __builtin_amdgcn_readfirstlane(pos);
-            if (ok) {
-                const uint32_t idx = pos + lane_rank(m);
-                if (idx < cap) finalists[idx] = key;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t n = a.k ? a.seg_count[w] : 0;
+    if (n != 0) {
+        uint32_t bstar, cnt;
+        find_threshold(a.state->ghist, a.k, lane, bstar, cnt);
+        const u64* seg = a.cand + static_cast<u64>(w) * g.seg_cap;
+        const uint32_t* seg_cb = a.cand_cb + static_cast<u64>(w) * g.seg_cap;
+        constexpr int UN = 4; // independent loads in flight per lane
+        constexpr uint32_t STAGE = kCompactStage;
+        for (uint32_t base = 0; base < n; base += 64 * UN) {
+            u64 key[UN];
+            uint32_t cb[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const uint32_t i = base + u * 64 + lane;
+                key[u] = i < n ? seg[i] : 0ull;
+                cb[u] = i < n ? seg_cb[i] : 0u;
             }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const uint32_t i = base + u * 64 + lane;
+                const bool ok = i < n && coarse_bin(key_score(static_cast<uint32_t>(key[u] >> 32))) >= bstar;
+                const u64 m = __ballot(ok);
+                if (m != 0) {
+                    const uint32_t cntw = static_cast<uint32_t>(__popcll(m));
+                    uint32_t pos = 0;
+                    if (lane == 0) pos = atomicAdd(&s_n, cntw);
+                    pos = __builtin_amdgcn_readfirstlane(pos);
+                    const uint32_t e = pos + lane_rank(m); // slot in the workgroup's reservation order
+                    if (pos + cntw <= STAGE) {
+                        if (ok) {
+                            s_stage[e] = key[u];
+                            s_stage_cb[e] = cb[u];
+                        }
+                    } else {
+                        const uint32_t first_over = pos > STAGE ? pos : STAGE;
+                        uint32_t gpos = 0;
+                        if (lane == 0) gpos = atomicAdd(&a.state->nfinal, pos + cntw - first_over);
+                        gpos = __builtin_amdgcn_readfirstlane(gpos);
+                        if (ok) {
+                            if (e < STAGE) {
+                                s_stage[e] = key[u];
+                                s_stage_cb[e] = cb[u];
+                            } else {
+                                const uint32_t idx = gpos + (e - first_over);
+                                if (idx < cap) {
+                                    finalists[idx] = key[u];
+                                    finalists_cb[idx] = cb[u];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t reserved = s_n;
+    const uint32_t staged = reserved < static_cast<uint32_t>(kCompactStage) ? reserved
+                                                                             : static_cast<uint32_t>(kCompactStage);
+    if (staged == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&a.state->nfinal, staged);
+    __syncthreads();
+    const uint32_t gbase = s_base;
+    for (uint32_t i = threadIdx.x; i < staged; i += kScanBlock) {
+        if (gbase + i < cap) {
+            finalists[gbase + i] = s_stage[i];
+            finalists_cb[gbase + i] = s_stage_cb[i];
         }
     }
 }
@@ -397,10 +536,22 @@ __device__ __forceinline__ void emit_hit(const ScanArgs& a, u64 key, uint32_t ro
     const float s = key_score(static_cast<uint32_t>(key >> 32));
     const uint32_t* r = reinterpret_cast<const uint32_t*>(a.rows) + static_cast<u64>(row) * a.W;
     uint32_t cc = 0, bb = 0;
-    for (uint32_t i = 0; i < a.W; i++) {
-        const uint32_t x = r[i];
-        cc += __popc(x & a.query[i]);
-        bb += __popc(x);
+    if ((a.W & 3u) == 0) { // 16-byte loads, all issued before the first use
+        const uint4* r4 = reinterpret_cast<const uint4*>(r);
+        const uint4* q4 = reinterpret_cast<const uint4*>(a.query_dev);
+        const uint32_t n4 = a.W >> 2;
+#pragma unroll 8
+        for (uint32_t i = 0; i < n4; i++) {
+            const uint4 x = r4[i], y = q4[i];
+            cc += __popc(x.x & y.x) + __popc(x.y & y.y) + __popc(x.z & y.z) + __popc(x.w & y.w);
+            bb += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+        }
+    } else {
+        for (uint32_t i = 0; i < a.W; i++) {
+            const uint32_t x = r[i];
+            cc += __popc(x & a.query_dev[i]);
+            bb += __popc(x);
+        }
     }
     gsim_hit h;
     h.row = row + row_base;
@@ -416,7 +567,8 @@ __device__ __forceinline__ u64 approx_count(const ScanArgs& a)
     return a.cutoff > 0.0f ? a.state->kept : a.nrows;
 }
 
-constexpr int kSelectThreads = 1024;
+constexpr int kSelectThreads = 256;
+constexpr int kSelectBlocks = kSelectCap / kSelectThreads;
 
 // keys[0..n) in LDS, n a power of two: bitonic sort, descending.
 __device__ __forceinline__ void bitonic_desc_lds(u64* keys, uint32_t n, int tid, int nthreads)
@@ -440,79 +592,155 @@ __device__ __forceinline__ void bitonic_desc_lds(u64* keys, uint32_t n, int tid,
 }
 
 // Dynamic LDS layout of select_kernel: kSelectCap keys, then a 256-bin digit
-// histogram and three words of control state.
+// histogram and control words (heavy-tie path only).
 constexpr size_t kSelectLds = static_cast<size_t>(kSelectCap) * sizeof(u64) + 256 * sizeof(uint32_t) + 16;
 
-// One workgroup.  k <= kSelectCap.  Finalists <= kSelectCap: all of them go to
-// LDS.  More (heavy ties at the k-th score): an in-kernel MSD radix select over
-// the unique 64-bit keys finds the k-th largest key T, and exactly the k keys
-// >= T go to LDS.  Then a bitonic sort and the emission of the first k hits.
-__global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, const u64* finalists, uint32_t cap,
-                                                                uint32_t row_base, void* d_result)
+// Heavy ties (more than kSelectCap finalists): one workgroup runs an MSD radix
+// select over the unique 64-bit keys to find the k-th largest key T, gathers the
+// exactly-k keys >= T into LDS, sorts them and re-derives the popcounts from the
+// table.  k <= kSelectCap.
+__device__ void select_heavy(const ScanArgs& a, const u64* finalists, uint32_t m2, uint32_t row_base, u64* keys,
+                             uint32_t* dhist, uint32_t* ctl, gsim_result_header* hdr, gsim_hit* hits)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
-    uint32_t* dhist = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kSelectCap) * sizeof(u64));
-    uint32_t* ctl = dhist + 256; // [0] digit, [1] remaining, [2] gather cursor
     const int tid = threadIdx.x;
-    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
-    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
-    uint32_t m2 = a.k ? a.state->nfinal : 0;
-    if (m2 > cap) m2 = cap; // cannot happen: cap covers every candidate slot
-    uint32_t nsel = m2;
-    if (m2 <= static_cast<uint32_t>(kSelectCap)) {
-        for (uint32_t i = tid; i < m2; i += kSelectThreads) keys[i] = finalists[i];
-    } else {
-        u64 prefix = 0;
-        if (tid == 0) ctl[1] = a.k;
-        for (int pass = 0; pass < 8; pass++) {
-            const int shift = 56 - 8 * pass;
-            if (tid < 256) dhist[tid] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < m2; i += kSelectThreads) {
-                const u64 key = finalists[i];
-                if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&dhist[(key >> shift) & 0xFF], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t remaining = ctl[1], acc = 0;
-                int d = 255;
-                for (; d > 0; d--) {
-                    if (acc + dhist[d] >= remaining) break;
-                    acc += dhist[d];
-                }
-                ctl[0] = static_cast<uint32_t>(d);
-                ctl[1] = remaining - acc;
-            }
-            __syncthreads();
-            prefix = (prefix << 8) | ctl[0];
-            __syncthreads();
-        }
-        // prefix is now the k-th largest key; keys are unique -> exactly k keys >= it
-        if (tid == 0) ctl[2] = 0;
+    u64 prefix = 0;
+    if (tid == 0) ctl[1] = a.k;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        dhist[tid] = 0; // kSelectThreads == 256 bins
         __syncthreads();
         for (uint32_t i = tid; i < m2; i += kSelectThreads) {
             const u64 key = finalists[i];
-            if (key >= prefix) {
-                const uint32_t pos = atomicAdd(&ctl[2], 1u);
-                if (pos < static_cast<uint32_t>(kSelectCap)) keys[pos] = key;
-            }
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&dhist[(key >> shift) & 0xFF], 1u);
         }
         __syncthreads();
-        nsel = ctl[2] < static_cast<uint32_t>(kSelectCap) ? ctl[2] : static_cast<uint32_t>(kSelectCap);
+        if (tid == 0) {
+            uint32_t remaining = ctl[1], acc = 0;
+            int d = 255;
+            for (; d > 0; d--) {
+                if (acc + dhist[d] >= remaining) break;
+                acc += dhist[d];
+            }
+            ctl[0] = static_cast<uint32_t>(d);
+            ctl[1] = remaining - acc;
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | ctl[0];
+        __syncthreads();
     }
+    // prefix is the k-th largest key; keys are unique -> exactly k keys >= it
+    if (tid == 0) ctl[2] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m2; i += kSelectThreads) {
+        const u64 key = finalists[i];
+        if (key >= prefix) {
+            const uint32_t pos = atomicAdd(&ctl[2], 1u);
+            if (pos < static_cast<uint32_t>(kSelectCap)) keys[pos] = key;
+        }
+    }
+    __syncthreads();
+    const uint32_t nsel = ctl[2] < static_cast<uint32_t>(kSelectCap) ? ctl[2] : static_cast<uint32_t>(kSelectCap);
     uint32_t n = 1;
     while (n < nsel) n <<= 1;
-    __syncthreads();
     for (uint32_t i = nsel + tid; i < n; i += kSelectThreads) keys[i] = 0ull;
     bitonic_desc_lds(keys, n, tid, kSelectThreads);
     const uint32_t nout = nsel < a.k ? nsel : a.k;
     for (uint32_t i = tid; i < nout; i += kSelectThreads) emit_hit(a, keys[i], row_base, hits + i);
     if (tid == 0) {
         hdr->count = nout;
-        hdr->flags = m2 > static_cast<uint32_t>(kSelectCap) ? 1u : 0u;
+        hdr->flags = 1u;
         hdr->approx = approx_count(a);
     }
+}
+
+// K3.  kSelectBlocks workgroups.  Usual case (finalists <= kSelectCap): every
+// finalist's output position is its rank = the number of finalists with a larger
+// key (keys are unique); each workgroup holds all keys in LDS and ranks 256 of
+// them by a broadcast-read counting loop -- no sort, no data movement, the hit
+// (row, score, common, popc_db) goes straight from registers to its slot.  The
+// result block may live in device memory or in pinned host memory (zero-copy).
+// The last workgroup to finish folds the query's counters into the running
+// totals and re-zeroes the per-query state for the next query.
+__global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, const u64* finalists,
+                                                                const uint32_t* finalists_cb, uint32_t cap,
+                                                                uint32_t row_base, void* d_result)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    uint32_t* dhist = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kSelectCap) * sizeof(u64));
+    uint32_t* ctl = dhist + 256; // [0] digit, [1] remaining, [2] gather cursor, [3] last-workgroup flag
+    const int tid = threadIdx.x;
+    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
+    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+    uint32_t m2 = a.k ? a.state->nfinal : 0;
+    if (m2 > cap) m2 = cap; // cannot happen: cap covers every candidate slot
+    if (m2 <= static_cast<uint32_t>(kSelectCap)) {
+        const uint32_t first = blockIdx.x * kSelectThreads;
+        if (first < m2) {
+            const uint32_t npad = (m2 + 1u) & ~1u;
+            for (uint32_t i = tid; i < npad; i += kSelectThreads) keys[i] = i < m2 ? finalists[i] : 0ull;
+            __syncthreads();
+            const uint32_t i = first + tid;
+            if (i < m2) {
+                const u64 mine = keys[i];
+                uint32_t rank = 0;
+                const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);
+#pragma unroll 4
+                for (uint32_t j = 0; j < npad / 2; j++) { // ds_read_b128 broadcast: two keys per read
+                    const ulonglong2 kk = k2[j];
+                    rank += (kk.x > mine) ? 1u : 0u;
+                    rank += (kk.y > mine) ? 1u : 0u;
+                }
+                if (rank < a.k) {
+                    const uint32_t cb = finalists_cb[i];
+                    gsim_hit h;
+                    h.row = ~static_cast<uint32_t>(mine) + row_base;
+                    h.score = key_score(static_cast<uint32_t>(mine >> 32));
+                    h.common = static_cast<uint16_t>(cb >> 16);
+                    h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
+                    hits[rank] = h;
+                }
+            }
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            hdr->count = m2 < a.k ? m2 : a.k;
+            hdr->flags = 0;
+            hdr->approx = approx_count(a);
+        }
+    } else if (blockIdx.x == 0) {
+        select_heavy(a, finalists, m2, row_base, keys, dhist, ctl, hdr, hits);
+    }
+    // ticket: the last workgroup resets the state (all others are done reading it)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) ctl[3] = (atomicAdd(&a.state->done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (ctl[3]) {
+        if (tid == 0) {
+            a.state->ncand_sum += a.state->ncand;
+            a.state->nfinal_sum += a.state->nfinal;
+            a.state->queries += 1;
+            a.state->kept = 0;
+            a.state->ncand = 0;
+            a.state->nfinal = 0;
+            a.state->done = 0;
+        }
+        for (int i = tid; i < kScanBins; i += kSelectThreads) a.state->ghist[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st)
+{
+    if (threadIdx.x == 0) {
+        st->ncand_sum += st->ncand;
+        st->nfinal_sum += st->nfinal;
+        st->queries += 1;
+        st->kept = 0;
+        st->ncand = 0;
+        st->nfinal = 0;
+        st->done = 0;
+    }
+    for (int i = threadIdx.x; i < kScanBins; i += 256) st->ghist[i] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -721,22 +949,29 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
 }
 
 hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned long long* finalists,
-                          uint32_t finalists_cap, hipStream_t s)
+                          uint32_t* finalists_cb, uint32_t finalists_cap, hipStream_t s)
 {
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g, finalists, finalists_cap);
+    hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g, finalists, finalists_cb,
+                       finalists_cap);
     return hipGetLastError();
 }
 
-hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap,
-                         uint32_t row_base, void* d_result, hipStream_t s)
+hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, const uint32_t* finalists_cb,
+                         uint32_t finalists_cap, uint32_t row_base, void* d_result, hipStream_t s)
 {
     // per-device attribute: set on every launch (cheap, idempotent)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSelectLds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(kSelectThreads), kSelectLds, s, a, finalists, finalists_cap,
-                       row_base, d_result);
+    hipLaunchKernelGGL(select_kernel, dim3(kSelectBlocks), dim3(kSelectThreads), kSelectLds, s, a, finalists,
+                       finalists_cb, finalists_cap, row_base, d_result);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset_state(QueryState* state, hipStream_t s)
+{
+    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(256), 0, s, state);
     return hipGetLastError();
 }
 
