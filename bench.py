@@ -69,7 +69,7 @@ def cpu_baseline(fp_bits, k, kind, budget_s=12.0):
     import oracle_lib as O
     W = fp_bits // 32
     cores = os.cpu_count() or 1
-    n = 2_000_000
+    n = 8_000_000  # 1 GB of fingerprints: larger than the host's last-level caches
     db = O.synth_rows(DB_SEED, kind, 0, n, W)
     q = db[query_row(0, n)]
     use_ref = O.ref_lib() is not None
@@ -86,7 +86,7 @@ def cpu_baseline(fp_bits, k, kind, budget_s=12.0):
         run()
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 200:
+        if el > budget_s or reps >= 1000:
             break
     return {"value": n * reps / el, "unit": "fingerprints/s", "cores": cores,
             "kind": "reference" if use_ref else "port",
@@ -194,6 +194,17 @@ def main():
         elapsed = float(t.item())
     tm = table.timing()
 
+    # HBM traffic of the scan kernel from the committed PMC pass (rocprofv3 cannot run inside bench.py):
+    # measured bytes / algorithmic bytes, applied to this run's algorithmic bytes
+    traffic_ratio, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            pm = json.load(f)
+        if pm["fp_bits"] == args.fp_bits:
+            traffic_ratio, traffic_src = pm["ratio"], pm["source"]
+    except Exception:
+        pass
+
     if rank == 0:
         steps = args.steps
         ms = 1e3 * elapsed / steps
@@ -222,7 +233,9 @@ def main():
             "roofline": {
                 "kernel": "scan_kernel<8,8>" if args.fp_bits == 1024 else "scan_kernel",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (traffic_ratio * algo_bytes) if traffic_ratio else None, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src,
                 "scan_ms_avg": scan_ms, "select_ms_avg": tm["select_ms_sum"] / max(1, tm["queries"]),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "candidates_per_query": tm["candidates_sum"] / max(1, tm["queries"]),

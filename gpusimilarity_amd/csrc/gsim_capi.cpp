@@ -77,7 +77,8 @@ struct Shard {
     // pinned host staging; queries go through a ring so that back-to-back
     // asynchronous searches never overwrite a query whose upload is still queued
     uint32_t* h_query = nullptr; // kQueryRing slots of W words
-    std::vector<hipEvent_t> q_ev; // upload-done event per slot
+    std::vector<hipEvent_t> q_ev; // scan-done event per slot (asynchronous searches)
+    bool q_pending[kQueryRing] = {};
     uint32_t q_next = 0;
     unsigned char* h_result = nullptr;
     size_t h_result_bytes = 0;
@@ -201,12 +202,15 @@ uint32_t popcount_words(const uint32_t* q, uint32_t W)
 // the per-query state (no memset op).  Nothing here synchronises with the host
 // unless k > kSelectCap.
 int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                  float beta, uint32_t row_base, void* out)
+                  float beta, uint32_t row_base, void* out, bool caller_syncs)
 {
     GSIM_HIP(hipSetDevice(s.device));
     const uint32_t slot = s.q_next++ % kQueryRing;
     uint32_t* hq = s.h_query + static_cast<size_t>(slot) * db->W;
-    GSIM_HIP(hipEventSynchronize(s.q_ev[slot])); // no-op unless 16 searches are still queued
+    if (s.q_pending[slot]) { // only set by asynchronous searches
+        GSIM_HIP(hipEventSynchronize(s.q_ev[slot]));
+        s.q_pending[slot] = false;
+    }
     std::memcpy(hq, query, static_cast<size_t>(db->W) * 4);
 
     gsim::ScanArgs a{};
@@ -245,7 +249,10 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
     }
     if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
-    GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream)); // the ring slot is free once the scan has run
+    if (!caller_syncs) { // the ring slot is free once the scan has run
+        GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream));
+        s.q_pending[slot] = true;
+    }
     if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
     if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
@@ -296,6 +303,19 @@ int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal)
     GSIM_HIP(hipStreamSynchronize(s.stream));
     *ncand = s.h_state->ncand_sum;
     *nfinal = s.h_state->nfinal_sum;
+    return GSIM_OK;
+}
+
+// Wait for a stream: poll for a short while (a query takes ~2 ms and the blocking
+// wait's interrupt wake-up costs 10-20 us), then block.
+int wait_stream(hipStream_t st)
+{
+    for (int i = 0; i < 200000; i++) {
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return GSIM_OK;
+        if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
+    }
+    GSIM_HIP(hipStreamSynchronize(st));
     return GSIM_OK;
 }
 
@@ -597,14 +617,15 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             if (rc != GSIM_OK) return rc;
             // the select kernel writes the block straight into pinned host memory
             rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta,
-                               db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
+                               db->row_base + static_cast<uint32_t>(s.first_row), s.h_result, true);
             if (rc != GSIM_OK) return rc;
         }
         uint64_t ap = 0;
         merged.clear();
         for (auto& s : db->shards) {
             GSIM_HIP(hipSetDevice(s.device));
-            GSIM_HIP(hipStreamSynchronize(s.stream));
+            rc = wait_stream(s.stream);
+            if (rc != GSIM_OK) return rc;
             const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
             const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
             ap += h->approx;
@@ -635,7 +656,7 @@ int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float 
     if (!d_result) return fail(GSIM_ERR_INVALID, "d_result is NULL");
     if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "search_device needs a single-shard handle");
     Shard& s = db->shards[0];
-    return enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base, d_result);
+    return enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base, d_result, false);
 }
 
 int gsim_merge_device(int device, void* hip_stream, const void* d_blocks, uint32_t nblocks, size_t block_bytes,

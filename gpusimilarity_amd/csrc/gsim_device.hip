@@ -683,6 +683,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
             const uint32_t i = first + tid;
             if (i < m2) {
                 const u64 mine = keys[i];
+                const uint32_t cb = finalists_cb[i]; // issued before the counting loop
                 uint32_t rank = 0;
                 const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);
 #pragma unroll 4
@@ -692,7 +693,6 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
                     rank += (kk.y > mine) ? 1u : 0u;
                 }
                 if (rank < a.k) {
-                    const uint32_t cb = finalists_cb[i];
                     gsim_hit h;
                     h.row = ~static_cast<uint32_t>(mine) + row_base;
                     h.score = key_score(static_cast<uint32_t>(mine >> 32));
