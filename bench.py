@@ -30,6 +30,7 @@ import torch  # noqa: E402  (first: one HIP runtime in the process, see capi.loa
 import torch.distributed as dist  # noqa: E402
 
 from gpusimilarity_amd import capi  # noqa: E402
+from gpusimilarity_amd.sharded import ShardedSearch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 DB_SEED = 0x5EED0001
@@ -104,6 +105,8 @@ def main():
     ap.add_argument("--fp-bits", type=int, default=1024)
     ap.add_argument("--kind", choices=["sparse", "dense"], default="sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded-path", action="store_true",
+                    help="run the N>1 code path (device result blocks, all-gather, device merge) even at N=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,8 +120,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     R = args.rows_per_gpu or (100_000_000 if world == 1 else 125_000_000)
@@ -133,45 +137,40 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     table.set_stream(stream.cuda_stream)
 
-    blk = capi.result_block_bytes(k)
     nq = args.warmup + args.steps
     queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(nq)]
-    with torch.cuda.stream(stream):
-        local_block = torch.zeros(blk, dtype=torch.uint8, device=dev)
-        gathered = torch.zeros(blk * world, dtype=torch.uint8, device=dev) if world > 1 else None
-        merged = torch.zeros(blk, dtype=torch.uint8, device=dev) if world > 1 else None
-    host_out = torch.zeros(blk, dtype=torch.uint8).pin_memory()
-
+    sharded_path = world > 1 or args.force_sharded_path
     bufs = table.make_search_buffers(1, k)
+    ss = None
+    if sharded_path:
+        def local_search(q, kk, block):
+            table.search_device(q, kk, block.data_ptr())  # enqueued on `stream`, result stays in HBM
 
-    def one_query_single(q):
-        # single GPU: the C ABI's synchronous entry point (FingerprintDB::search): scan ->
-        # compact -> select, the select kernel writes the hits into pinned host memory,
-        # the call returns when they are there
-        table.search_into(q, k, bufs)
+        with torch.cuda.stream(stream):
+            ss = ShardedSearch(local_search, k, dev, stream_ptr=stream.cuda_stream)
 
     def one_query(q):
-        if world == 1:
-            return one_query_single(q)
+        if not sharded_path:
+            # single GPU: the C ABI's synchronous entry point (FingerprintDB::search): scan ->
+            # compact -> select, the select kernel writes the hits into pinned host memory,
+            # the call returns when they are there
+            table.search_into(q, k, bufs)
+            return
         with torch.cuda.stream(stream):
-            table.search_device(q, k, local_block.data_ptr())
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, local_block)  # RCCL over xGMI: k*12 B per GPU
-                capi.merge_device(local_rank, stream.cuda_stream, gathered.data_ptr(), world, blk, k,
-                                  merged.data_ptr())
-                host_out.copy_(merged, non_blocking=True)
-            else:
-                host_out.copy_(local_block, non_blocking=True)
+            ss.enqueue(q)  # local top-k -> RCCL all-gather (k*12+16 B per GPU) -> rank merge -> D2H
         stream.synchronize()  # the query is done when its k hits are in host memory
+
+    def last_result():
+        if not sharded_path:
+            return bufs[0][0, :bufs[1][0]], int(bufs[2][0])
+        hits, approx, _ = ss.result()
+        return hits, approx
 
     for i in range(args.warmup):
         one_query(queries[i])
     # sanity on the last warm-up query: the self hit leads the result
     if args.warmup:
-        if world == 1:
-            hits, approx = bufs[0][0, :bufs[1][0]], int(bufs[2][0])
-        else:
-            hits, approx, _ = capi.parse_result_block(host_out.numpy().tobytes(), k)
+        hits, approx = last_result()
         want_row = query_row(args.warmup - 1, total_rows)
         assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
             "self hit missing: %r" % (hits[:3],)
@@ -179,13 +178,13 @@ def main():
 
     table.enable_timing(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, nq):
         one_query(queries[i])
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -250,7 +249,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "fingerprints/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

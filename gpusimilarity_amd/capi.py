@@ -44,7 +44,8 @@ EXPORTS = [
     "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_generate", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
     "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
-    "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_enable_timing",
+    "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_merge_host",
+    "gsim_db_enable_timing",
     "gsim_db_get_timing", "gsim_debug_score_table", "gsim_last_error", "gsim_version",
 ]
 
@@ -90,6 +91,7 @@ def load():
         "gsim_result_block_bytes": (C.c_size_t, [C.c_uint32]),
         "gsim_db_search_device": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float, vp]),
         "gsim_merge_device": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
+        "gsim_merge_host": (C.c_int, [vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
         "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
@@ -254,6 +256,24 @@ class Table:
 def merge_device(device, stream_ptr, d_blocks_ptr, nblocks, block_bytes, k, d_result_ptr):
     check(load().gsim_merge_device(device, C.c_void_p(stream_ptr), C.c_void_p(d_blocks_ptr), nblocks, block_bytes, k,
                                    C.c_void_p(d_result_ptr)))
+
+
+def merge_host(blocks: bytes, nblocks: int, block_bytes: int, k: int) -> bytes:
+    """gsim_merge_host on a bytes object holding nblocks result blocks."""
+    src = (C.c_ubyte * len(blocks)).from_buffer_copy(blocks)
+    out = (C.c_ubyte * result_block_bytes(k))()
+    check(load().gsim_merge_host(C.cast(src, C.c_void_p), nblocks, block_bytes, k, C.cast(out, C.c_void_p)))
+    return bytes(out)
+
+
+def make_result_block(hits: np.ndarray, approx: int, k: int, flags: int = 0) -> bytes:
+    """Serialise (hits, approx) as one result block of capacity k."""
+    hdr = np.zeros(1, dtype=HEADER_DTYPE)
+    hdr["count"], hdr["flags"], hdr["approx"] = len(hits), flags, approx
+    body = np.zeros(k, dtype=HIT_DTYPE)
+    body[:len(hits)] = hits
+    raw = hdr.tobytes() + body.tobytes()
+    return raw + b"\0" * (result_block_bytes(k) - len(raw))
 
 
 def parse_result_block(buf: bytes, k: int):

@@ -669,6 +669,36 @@ int gsim_merge_device(int device, void* hip_stream, const void* d_blocks, uint32
     return GSIM_OK;
 }
 
+int gsim_merge_host(const void* blocks, uint32_t nblocks, size_t block_bytes, uint32_t k, void* result)
+{
+    if (!blocks || !result || nblocks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
+    if (block_bytes < sizeof(gsim_result_header)) return fail(GSIM_ERR_INVALID, "block_bytes too small");
+    std::vector<gsim_hit> all;
+    uint64_t approx = 0;
+    uint32_t flags = 0;
+    for (uint32_t i = 0; i < nblocks; i++) {
+        const unsigned char* b = static_cast<const unsigned char*>(blocks) + static_cast<size_t>(i) * block_bytes;
+        gsim_result_header h;
+        std::memcpy(&h, b, sizeof(h));
+        if (sizeof(h) + static_cast<size_t>(h.count) * sizeof(gsim_hit) > block_bytes)
+            return fail(GSIM_ERR_INVALID, "result block count exceeds block_bytes");
+        const size_t old = all.size();
+        all.resize(old + h.count);
+        if (h.count) std::memcpy(all.data() + old, b + sizeof(h), static_cast<size_t>(h.count) * sizeof(gsim_hit));
+        approx += h.approx;
+        flags |= h.flags;
+    }
+    std::sort(all.begin(), all.end(), hit_before);
+    gsim_result_header out;
+    out.count = static_cast<uint32_t>(std::min<size_t>(all.size(), k));
+    out.flags = flags;
+    out.approx = approx;
+    std::memcpy(result, &out, sizeof(out));
+    if (out.count)
+        std::memcpy(static_cast<unsigned char*>(result) + sizeof(out), all.data(), sizeof(gsim_hit) * out.count);
+    return GSIM_OK;
+}
+
 // The reference's explicit host path, fingerprintdb_cuda.cpp:20-54: score every
 // row on all host threads (QtConcurrent::blockingMap -> std::thread here), then
 // top_results_bubble_sort (:92-103) and the first k.  Not a fallback: only this

@@ -173,6 +173,12 @@ int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float 
 int gsim_merge_device(int device, void* hip_stream, const void* d_blocks,
                       uint32_t nblocks, size_t block_bytes, uint32_t k, void* d_result);
 
+/* Host twin of gsim_merge_device for result blocks that are in host memory (the
+ * in-process multi-device path, and the gloo/CPU tests of the gather+merge
+ * logic): std::sort + truncate exactly as fingerprintdb_cuda.cu:363-380. */
+int gsim_merge_host(const void* blocks, uint32_t nblocks, size_t block_bytes, uint32_t k,
+                    void* result);
+
 /* ---- instrumentation ------------------------------------------------------ */
 int gsim_db_enable_timing(gsim_db* db, int enable); /* resets the accumulators */
 int gsim_db_get_timing(gsim_db* db, gsim_timing* out); /* synchronises the stream */
