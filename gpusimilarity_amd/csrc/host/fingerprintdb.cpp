@@ -1,0 +1,160 @@
+// fingerprintdb.cpp -- gpusim::FingerprintDB over the C ABI.  See fingerprintdb.h.
+#include "fingerprintdb.h"
+
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+
+#include "../../../include/gpusim_hip.h"
+
+namespace gpusim
+{
+
+namespace
+{
+[[noreturn]] void throw_last(const char* what)
+{
+    throw std::runtime_error(std::string(what) + ": " + gsim_last_error());
+}
+} // namespace
+
+unsigned int get_gpu_count()
+{
+    int n = 0;
+    gsim_device_count(&n);
+    return static_cast<unsigned int>(n);
+}
+
+unsigned int get_next_gpu(size_t required_memory)
+{
+    int dev = 0;
+    if (gsim_next_device(required_memory, &dev) != GSIM_OK) {
+        // reference message, fingerprintdb_cuda.cu:65-66
+        throw std::runtime_error("Can't find a GPU with enough memory to copy data.");
+    }
+    return static_cast<unsigned int>(dev);
+}
+
+size_t get_available_gpu_memory()
+{
+    size_t b = 0;
+    gsim_available_device_bytes(&b);
+    return b;
+}
+
+FingerprintDB::FingerprintDB(int fp_bitcount, int fp_count, const std::string& dbkey,
+                             std::vector<std::vector<char>>& data, std::vector<char*>& smiles_vector,
+                             std::vector<char*>& ids_vector)
+    : m_dbkey(dbkey)
+{
+    m_fp_intsize = fp_bitcount / static_cast<int>(sizeof(int) * 8);
+    m_total_count = fp_count;
+    if (gsim_db_create(static_cast<uint32_t>(fp_bitcount), &m_db) != GSIM_OK) throw_last("FingerprintDB");
+    const size_t row_bytes = static_cast<size_t>(fp_bitcount / CHAR_BIT);
+    long current_fp_count = 0;
+    for (auto& dataset : data) {
+        const uint64_t rows = row_bytes ? dataset.size() / row_bytes : 0;
+        if (gsim_db_add_rows(m_db, reinterpret_cast<const uint32_t*>(dataset.data()), rows) != GSIM_OK) {
+            gsim_db_destroy(m_db);
+            m_db = nullptr;
+            throw_last("FingerprintDB");
+        }
+        current_fp_count += static_cast<long>(rows);
+    }
+    if (current_fp_count != m_total_count) {
+        gsim_db_destroy(m_db);
+        m_db = nullptr;
+        throw std::runtime_error("Mismatch between FP count and data, potential database corruption.");
+    }
+    m_total_data_size = static_cast<size_t>(m_total_count) * static_cast<size_t>(m_fp_intsize) * sizeof(int);
+    std::fprintf(stderr, "Database loaded with %d molecules\n", m_total_count);
+    m_smiles.swap(smiles_vector);
+    m_ids.swap(ids_vector);
+}
+
+FingerprintDB::~FingerprintDB()
+{
+    if (m_db) gsim_db_destroy(m_db);
+}
+
+void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices)
+{
+    if (fold_factor != 1) {
+        throw std::invalid_argument("fingerprint folding is not part of this build (the unfolded table must fit in HBM)");
+    }
+    m_fold_factor = 1;
+    if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
+    m_on_gpu = true;
+}
+
+Fingerprint FingerprintDB::getFingerprint(unsigned int index) const
+{
+    Fingerprint output(static_cast<size_t>(m_fp_intsize));
+    if (gsim_db_row(m_db, index, reinterpret_cast<uint32_t*>(output.data())) != GSIM_OK) throw_last("getFingerprint");
+    return output;
+}
+
+void FingerprintDB::search(const Fingerprint& query, const std::string& dbkey, unsigned int max_return_count,
+                           float similarity_cutoff, std::vector<char*>& results_smiles,
+                           std::vector<char*>& results_ids, std::vector<float>& results_scores,
+                           unsigned long& approximate_result_count) const
+{
+    if (dbkey != m_dbkey) {
+        std::fprintf(stderr, "Key check failed, returning empty results\n");
+        return;
+    }
+    if (static_cast<int>(query.size()) != m_fp_intsize) throw std::invalid_argument("query has the wrong width");
+    std::vector<gsim_hit> hits(max_return_count ? max_return_count : 1);
+    uint32_t count = 0;
+    uint64_t approx = 0;
+    if (gsim_db_search(m_db, reinterpret_cast<const uint32_t*>(query.data()), 1, max_return_count, similarity_cutoff,
+                       GSIM_METRIC_TANIMOTO, 0.f, 0.f, hits.data(), &count, &approx) != GSIM_OK)
+        throw_last("search");
+    approximate_result_count = static_cast<unsigned long>(approx);
+    for (uint32_t i = 0; i < count; i++) {
+        results_scores.push_back(hits[i].score);
+        results_smiles.push_back(m_smiles[hits[i].row]);
+        results_ids.push_back(m_ids[hits[i].row]);
+    }
+}
+
+void FingerprintDB::search_cpu(const Fingerprint& query, const std::string& dbkey, unsigned int max_return_count,
+                               float similarity_cutoff, std::vector<char*>& results_smiles,
+                               std::vector<char*>& results_ids, std::vector<float>& results_scores,
+                               unsigned long& approximate_result_count) const
+{
+    (void) approximate_result_count; // fingerprintdb_cuda.cpp:39 "not giving approximate total count back"
+    if (dbkey != m_dbkey) {
+        std::fprintf(stderr, "Key check failed, returning empty results\n");
+        return;
+    }
+    if (static_cast<int>(query.size()) != m_fp_intsize) throw std::invalid_argument("query has the wrong width");
+    // the reference indexes indices[i] for i < max_return_count even past the table (UB); clamp instead
+    const unsigned int k = max_return_count < count() ? max_return_count : count();
+    std::vector<gsim_hit> hits(k ? k : 1);
+    uint32_t n = 0;
+    if (gsim_db_search_cpu(m_db, reinterpret_cast<const uint32_t*>(query.data()), 1, k, similarity_cutoff, hits.data(),
+                           &n) != GSIM_OK)
+        throw_last("search_cpu");
+    for (uint32_t i = 0; i < n; i++) {
+        results_smiles.push_back(m_smiles[hits[i].row]);
+        results_ids.push_back(m_ids[hits[i].row]);
+        results_scores.push_back(hits[i].score);
+    }
+}
+
+void top_results_bubble_sort(std::vector<int>& indices, std::vector<float>& scores, int number_required)
+{
+    const int count = static_cast<int>(indices.size());
+    for (int i = 0; i < number_required; i++) {
+        for (int j = count - 1; j > i; j--) {
+            if (scores[j] > scores[j - 1]) {
+                std::swap(indices[j], indices[j - 1]);
+                std::swap(scores[j], scores[j - 1]);
+            }
+        }
+    }
+}
+
+} // namespace gpusim
