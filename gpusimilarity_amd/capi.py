@@ -13,7 +13,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsim_hip.so")
+# GSIM_LIB: alternative build of the same ABI (kernel ablation experiments only)
+LIB_PATH = os.environ.get("GSIM_LIB") or os.path.join(_HERE, "libgsim_hip.so")
 
 OK = 0
 METRIC_TANIMOTO = 0

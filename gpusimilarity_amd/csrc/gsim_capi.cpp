@@ -64,6 +64,7 @@ struct Shard {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr; // the stream in use (own or caller's)
     gsim::ScanGeometry geo{};
+    int sample_chunks = 4; // chunks per scan wave scored by the sample kernel (0 = off)
     uint32_t* d_query = nullptr;
     gsim::QueryState* d_state = nullptr;
     unsigned long long* d_cand = nullptr;
@@ -149,6 +150,7 @@ int setup_shard(gsim_db* db, Shard& s)
     const int wpc = env_int("GSIM_SCAN_WAVES_PER_CU", 4);
     const int unroll = env_int("GSIM_SCAN_UNROLL", 8);
     s.geo = gsim::scan_geometry(s.nrows, db->W, s.num_cus, wpc, unroll);
+    s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
     const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(db->W) * 4));
     GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
@@ -247,6 +249,8 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
         }
         ev = &s.ev[3 * s.ev_used];
     }
+    if (s.nrows > 0 && s.sample_chunks > 0)
+        GSIM_HIP(gsim::launch_sample(a, s.geo, static_cast<uint32_t>(s.sample_chunks), s.stream));
     if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
     if (!caller_syncs) { // the ring slot is free once the scan has run

@@ -25,6 +25,8 @@ struct QueryState {
     unsigned long long ncand;    // total candidates emitted by the scan
     uint32_t nfinal;             // finalists appended by the compaction
     uint32_t done;               // select-kernel workgroups that have finished (ticket)
+    uint32_t gtau;               // table-wide threshold bin shared by all workgroups of the scan (monotone)
+    uint32_t pad0;
     // --- not reset per query: running totals for gsim_db_get_timing ---
     unsigned long long ncand_sum;
     unsigned long long nfinal_sum;
@@ -61,6 +63,8 @@ struct ScanArgs {
 // Geometry of the scan grid for a table (host side, no device work).
 ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll);
 
+// Optional K0: starting threshold from a strided sample of chunks_per_wave chunks per scan wave.
+hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s);
 hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s);
 
 // Compaction of candidates at or above the k-th best coarse bin into `finalists`.

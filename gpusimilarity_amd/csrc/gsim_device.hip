@@ -124,20 +124,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
-// Largest bin B with sum_{b >= B} hist[b] >= k, and that sum.  When the whole
-// histogram holds fewer than k entries: B = 0 and the total.  One wavefront;
-// lane l owns bins [16 l, 16 l + 16).  k >= 1.
-__device__ __forceinline__ void find_threshold(const uint32_t* hist, uint32_t k, int lane, uint32_t& bin_out,
-                                               uint32_t& cnt_out)
+// Largest bin B with sum_{b >= B} count[b] >= k, and that sum; the whole histogram
+// holds fewer than k entries: B = 0 and the total.  One wavefront; lane l holds the
+// counts of bins [PER l, PER l + PER) in h[] and their sum in s.  k >= 1.
+template <int PER>
+__device__ __forceinline__ void threshold_from_counts(const uint32_t (&h)[PER], uint32_t s, uint32_t k, int lane,
+                                                      uint32_t& bin_out, uint32_t& cnt_out)
 {
-    constexpr int PER = kScanBins / 64;
-    uint32_t h[PER];
-    uint32_t s = 0;
-#pragma unroll
-    for (int i = 0; i < PER; i++) {
-        h[i] = hist[lane * PER + i];
-        s += h[i];
-    }
     uint32_t incl = s; // suffix sum over lanes >= lane
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -167,57 +160,173 @@ __device__ __forceinline__ void find_threshold(const uint32_t* hist, uint32_t k,
     cnt_out = static_cast<uint32_t>(__shfl(static_cast<int>(cnt), L, 64));
 }
 
+__device__ __forceinline__ void find_threshold(const uint32_t* hist, uint32_t k, int lane, uint32_t& bin_out,
+                                               uint32_t& cnt_out)
+{
+    constexpr int PER = kScanBins / 64;
+    uint32_t h[PER];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        h[i] = hist[lane * PER + i];
+        s += h[i];
+    }
+    threshold_from_counts<PER>(h, s, k, lane, bin_out, cnt_out);
+}
+
 // ---------------------------------------------------------------------------
 // K1: the scan
 // ---------------------------------------------------------------------------
 
-// Streaming top-k filter shared by the wavefronts of one workgroup, in LDS.
+// 16 bytes per lane; a wave64 instruction covers 1 KiB of consecutive table bytes.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Streaming top-k filter.
 //
-// `hist` counts, per coarse bin, the rows this workgroup has emitted; `tau` is a
-// bin such that at least k rows seen by the workgroup have bin >= tau.  Those
-// rows are a subset of the table, so tau never exceeds the bin of the table's
-// k-th best score: a row whose bin is below tau scores strictly less than k
-// rows already seen and cannot be in the top-k.  All updates are monotone
-// (hist and tau only grow), which is what makes the sharing barrier-free: a
-// wave that scans `hist` while others add to it reads values <= the final
-// counts, so a bin B with sum_{b>=B} read[b] >= k is still a valid threshold; a
-// wave that compares against a stale (lower) tau only emits more than needed.
+// Every workgroup keeps, in LDS, a histogram `hist` of the coarse bins of the rows
+// it has EMITTED (written out as candidates).  From time to time a wave pushes the
+// not-yet-pushed part of it into the table-wide histogram `ghist` (global memory,
+// device-scope atomics), re-reads `ghist` and derives a threshold bin: the largest
+// bin B with at least k counted rows at or above it.  The threshold is published
+// with atomicMax (`gtau`) and every wave of every workgroup picks it up on its next
+// chunk.  A row is emitted only if bin(score) >= the wave's current threshold.
+//
+// Why this is exact: `ghist` only ever counts distinct rows of the table that have
+// really been scanned, so "k counted rows at or above B" implies that the table's
+// k-th best score lies in a bin >= B; a row in a lower bin scores strictly less than
+// k other rows and cannot be in the top-k.  Everything is monotone (counts and
+// thresholds only grow), so there are no barriers and no ordering requirements:
+// a stale (lower) threshold only emits more than necessary, a histogram read while
+// others add to it only under-counts.  On a random table the number of emitted rows
+// falls from N to roughly k * ln(N / k) + (#workgroups * first push).
+constexpr int kStage = 128; // staged candidates per wave (a flush is triggered above 64)
+
 struct BlockFilter {
-    uint32_t hist[kScanBins];
-    uint32_t tau;     // current threshold bin (monotone, atomicMax)
-    uint32_t nemit;   // candidates emitted by the workgroup so far
-    uint32_t trigger; // nemit value at which the threshold is recomputed next
-    uint32_t pad;
+    uint32_t hist[kScanBins];    // rows emitted by this workgroup, per coarse bin
+    uint32_t flushed[kScanBins]; // part of hist already added to ghist
+    uint32_t tau;                // workgroup's copy of the threshold bin (monotone)
+    uint32_t nemit;              // candidates emitted by the workgroup so far
+    uint32_t trigger;            // nemit value at which the next push / re-read happens
+    uint32_t lock;               // one pusher at a time
+    // Per-wave staging of emitted candidates.  Candidates go to LDS (ds_write, lgkmcnt) and
+    // reach global memory in bursts of >= 64: a global store inside the streaming loop would be
+    // waited for by the loop's next s_waitcnt vmcnt(0) (gfx950 has one counter for loads and
+    // stores) -- measured at ~0.36 us per emitting iteration.
+    u64 stage_key[kScanBlock / 64][kStage];
+    uint32_t stage_cb[kScanBlock / 64][kStage];
 };
+
+// first push after this many emitted rows per workgroup (then geometrically)
+constexpr uint32_t kFirstPush = 64;
 
 // Per-wave view of the filter (members wave-uniform except `kept`).
 struct WaveFilter {
     BlockFilter* sh;
+    QueryState* st;
     u64* seg;         // this wave's private candidate segment (keys)
     uint32_t* seg_cb; // ... and the popcounts the score came from (common << 16 | popc_db)
-    uint32_t k, tau, step, cursor, kept;
+    u64* stg_key;     // this wave's LDS staging area
+    uint32_t* stg_cb;
+    uint32_t k, tau, step, cursor, staged, kept;
     float cutoff;
     bool has_cutoff;
 
-    __device__ __forceinline__ void init(BlockFilter* b, u64* s, uint32_t* scb, uint32_t kk, float cut)
+    __device__ __forceinline__ void init(BlockFilter* b, QueryState* state, u64* s, uint32_t* scb, uint32_t kk,
+                                         float cut)
     {
         sh = b;
+        stg_key = b->stage_key[threadIdx.x >> 6];
+        stg_cb = b->stage_cb[threadIdx.x >> 6];
+        staged = 0;
+        st = state;
         seg = s;
         seg_cb = scb;
         k = kk;
         cutoff = cut;
         has_cutoff = cut > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
-        tau = kk ? 0u : static_cast<uint32_t>(kScanBins);
+        tau = kk ? state->gtau : static_cast<uint32_t>(kScanBins); // gtau: 0, or set by sample_kernel
+#if defined(GSIM_ABLATE) && GSIM_ABLATE >= 11
+        tau = GSIM_FIXED_TAU; // ablations 11-13: fixed threshold bin, no pushes; 14: fixed start, then adaptive
+#endif
         step = kk / 8 > 32 ? kk / 8 : 32;
         cursor = 0;
         kept = 0;
     }
 
-    // pick up a threshold raised by another wave of the workgroup
-    __device__ __forceinline__ void refresh()
+    // device-coherent read of the table-wide threshold (issued a chunk ahead of its use)
+    __device__ __forceinline__ uint32_t load_gtau() const
+    {
+        return __hip_atomic_load(&st->gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // pick up a threshold raised by another wave (same workgroup: LDS; any workgroup: g)
+    __device__ __forceinline__ void refresh(uint32_t g, int lane)
     {
         const uint32_t t = __hip_atomic_load(&sh->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         tau = t > tau ? t : tau;
+        if (g > tau) { // raised by another workgroup: hand it to the other waves of this one through LDS
+            tau = g;
+            if (lane == 0) atomicMax(&sh->tau, g);
+        }
+    }
+
+    // Push this workgroup's new counts into ghist, derive the threshold from ghist.
+    __device__ __forceinline__ void push_and_rethreshold(int lane)
+    {
+        constexpr int PER = kScanBins / 64;
+        uint32_t locked = 0;
+        if (lane == 0) locked = atomicExch(&sh->lock, 1u);
+        locked = __builtin_amdgcn_readfirstlane(locked);
+        if (locked == 0) {
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const uint32_t b = static_cast<uint32_t>(lane * PER + i);
+                const uint32_t h = __hip_atomic_load(&sh->hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t fl = sh->flushed[b];
+                if (b >= tau && h > fl) {
+                    atomicAdd(&st->ghist[b], h - fl);
+                    sh->flushed[b] = h;
+                }
+            }
+            if (lane == 0) __hip_atomic_store(&sh->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // threshold from the table-wide histogram: device-coherent (sc1) 16-byte buffer
+        // loads, 4 per lane -- 1024 separate 4-byte sc1 loads cost ~20 us per push
+        uint32_t h[PER];
+        uint32_t s = 0;
+        {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(st->ghist, 0, kScanBins * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < PER / 4; i++) {
+                const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * PER * 4 + i * 16, 0, /*sc1*/ 16);
+                h[4 * i + 0] = v4.x;
+                h[4 * i + 1] = v4.y;
+                h[4 * i + 2] = v4.z;
+                h[4 * i + 3] = v4.w;
+                s += v4.x + v4.y + v4.z + v4.w;
+            }
+        }
+        uint32_t bin_k, cnt;
+        threshold_from_counts<PER>(h, s, k, lane, bin_k, cnt);
+        if (cnt >= k) {
+            if (lane == 0) {
+                atomicMax(&st->gtau, bin_k);
+                atomicMax(&sh->tau, bin_k);
+            }
+            tau = bin_k > tau ? bin_k : tau;
+        }
+    }
+
+    // staged candidates -> this wave's global segment, coalesced
+    __device__ __forceinline__ void flush_stage(int lane)
+    {
+        for (uint32_t i = lane; i < staged; i += 64) {
+            seg[cursor + i] = stg_key[i];
+            seg_cb[cursor + i] = stg_cb[i];
+        }
+        cursor += staged;
+        staged = 0;
     }
 
     // One row per lane (or an inactive lane).
@@ -229,34 +338,49 @@ struct WaveFilter {
         const uint32_t bin = coarse_bin(s);
         const bool cand = keep && bin >= tau;
         const u64 m = __ballot(cand);
+#if defined(GSIM_ABLATE) && GSIM_ABLATE == 4
+        asm volatile("" ::"s"(m)); // ablation 4: the filter's fast path only (no emission code)
+        return;
+#endif
         if (m != 0) {
             if (cand) {
-                const uint32_t slot = cursor + lane_rank(m);
-                seg[slot] = make_key(s, row);
-                seg_cb[slot] = cb;
+                const uint32_t slot = staged + lane_rank(m);
+                stg_key[slot] = make_key(s, row);
+                stg_cb[slot] = cb;
+#if !(defined(GSIM_ABLATE) && (GSIM_ABLATE == 5 || GSIM_ABLATE == 11))
                 atomicAdd(&sh->hist[bin], 1u); // ds_add_u32
+#endif
             }
             const uint32_t n = static_cast<uint32_t>(__popcll(m));
-            cursor += n;
+            staged += n;
+            if (staged > 64) flush_stage(lane);
+#if defined(GSIM_ABLATE) && (GSIM_ABLATE == 5 || GSIM_ABLATE == 6 || GSIM_ABLATE == 11 || GSIM_ABLATE == 12)
+            return;
+#endif
             uint32_t old = 0;
             if (lane == 0) old = atomicAdd(&sh->nemit, n);
             old = __builtin_amdgcn_readfirstlane(old);
             const uint32_t trig = __hip_atomic_load(&sh->trigger, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if defined(GSIM_ABLATE) && (GSIM_ABLATE == 7 || GSIM_ABLATE == 13)
+            asm volatile("" ::"s"(old), "s"(trig));
+            return;
+#endif
             if (old < trig && old + n >= trig) { // exactly one wave crosses a given trigger
-                uint32_t bin_k, cnt;
-                find_threshold(sh->hist, k, lane, bin_k, cnt);
+                push_and_rethreshold(lane);
                 if (lane == 0) {
-                    if (cnt >= k) atomicMax(&sh->tau, bin_k);
+                    // next push after 50 % more emitted rows (at least `step`): a handful of pushes per
+                    // workgroup and query; the emission rate falls as the threshold rises
                     const uint32_t now = __hip_atomic_load(&sh->nemit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&sh->trigger, now + step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t inc = now / 2 > step ? now / 2 : step;
+                    __hip_atomic_store(&sh->trigger, now + inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (cnt >= k && bin_k > tau) tau = bin_k;
             }
         }
     }
 
     __device__ __forceinline__ void finish(uint32_t w, const ScanArgs& a, int lane)
     {
+        if (staged) flush_stage(lane);
         if (lane == 0) {
             a.seg_count[w] = cursor;
             if (cursor) atomicAdd(&a.state->ncand, static_cast<u64>(cursor));
@@ -268,32 +392,34 @@ struct WaveFilter {
     }
 };
 
-__device__ __forceinline__ void block_filter_init(BlockFilter* sh, uint32_t k)
+__device__ __forceinline__ void block_filter_init(BlockFilter* sh, uint32_t k, uint32_t tau0)
 {
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) sh->hist[i] = 0;
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) {
+        sh->hist[i] = 0;
+        sh->flushed[i] = 0;
+    }
     if (threadIdx.x == 0) {
-        sh->tau = k ? 0u : static_cast<uint32_t>(kScanBins);
+        sh->tau = k ? tau0 : static_cast<uint32_t>(kScanBins);
         sh->nemit = 0;
-        sh->trigger = k ? k : 0xFFFFFFFFu;
+        sh->trigger = k ? (k < kFirstPush ? k : kFirstPush) : 0xFFFFFFFFu;
+        sh->lock = 0;
     }
     __syncthreads();
 }
 
-// After every wave of the workgroup is done: bins at or above the final
-// threshold are merged into the table-wide histogram.  ghist is exact for
-// every bin >= max over workgroups of tau, which is all K2 needs.
+// After every wave of the workgroup is done: whatever has not been pushed yet goes
+// into the table-wide histogram, for the bins at or above the final threshold.
+// ghist is then exact for every bin >= the largest threshold any wave used, which is
+// all K2 needs (see compact_kernel).
 __device__ __forceinline__ void block_filter_flush(BlockFilter* sh, const ScanArgs& a)
 {
     __syncthreads();
     const uint32_t tau = sh->tau;
     for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) {
-        const uint32_t h = sh->hist[i];
-        if (static_cast<uint32_t>(i) >= tau && h != 0) atomicAdd(&a.state->ghist[i], h);
+        const uint32_t h = sh->hist[i], fl = sh->flushed[i];
+        if (static_cast<uint32_t>(i) >= tau && h > fl) atomicAdd(&a.state->ghist[i], h - fl);
     }
 }
-
-// 16 bytes per lane; a wave64 instruction covers 1 KiB of consecutive table bytes.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
 {
@@ -307,14 +433,23 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
 // The loop body over full chunks is branch-free up to the (rare) emit path, so the
 // compiler's s_waitcnt placement leaves the prefetch in flight during the reduce;
 // the table's last, partial chunk is handled once, outside the loop.
-template <int LPR, int U, bool FULL>
+template <int LPR, int U, bool FULL, typename Filter>
 __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q, u64 row0, const ScanArgs& a,
-                                             WaveFilter& f, int lane)
+                                             Filter& f, int lane)
 {
     constexpr int RPL = 64 / LPR;
     constexpr int ROUNDS = (U + LPR - 1) / LPR;
     const int sub = lane % LPR;
     const int grp = lane / LPR;
+#if defined(GSIM_ABLATE) && GSIM_ABLATE == 1
+    // ablation 1: loads only (one XOR per dword keeps them alive)
+    u32x4 x = d[0];
+#pragma unroll
+    for (int j = 1; j < U; j++) x ^= d[j];
+    asm volatile("" ::"v"(x.x ^ x.y ^ x.z ^ x.w ^ q.x));
+    (void) row0; (void) a; (void) f; (void) grp; (void) sub;
+    return;
+#endif
     uint32_t v[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
@@ -332,10 +467,20 @@ __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q
         for (int jj = 0; jj < U; jj++) {
             if (jj / LPR == r) val = (sub == jj % LPR) ? v[jj] : val;
         }
+#if defined(GSIM_ABLATE) && GSIM_ABLATE == 2
+        asm volatile("" ::"v"(val)); // ablation 2: + popcounts and the DPP reduction
+        (void) row0; (void) a; (void) f; (void) grp;
+        continue;
+#endif
         const int j = r * LPR + sub;
         const u64 row = row0 + static_cast<u64>(j * RPL + grp);
         const bool active = (j < U) && (FULL || row < a.nrows);
         const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
+#if defined(GSIM_ABLATE) && GSIM_ABLATE == 3
+        asm volatile("" ::"v"(s), "v"(active)); // ablation 3: + the score
+        (void) f;
+        continue;
+#endif
         f.offer(active, static_cast<uint32_t>(row), s, val, lane);
     }
 }
@@ -345,7 +490,7 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
     __shared__ BlockFilter s_filter;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    block_filter_init(&s_filter, a.k);
+    block_filter_init(&s_filter, a.k, a.state->gtau);
 
     constexpr int RPL = 64 / LPR; // rows per load instruction
     constexpr int CH = U * RPL;   // rows per chunk
@@ -354,8 +499,11 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
     if (w == 0 && lane < LPR && a.query_dev != a.query) reinterpret_cast<u32x4*>(a.query_dev)[lane] = q;
 
     WaveFilter f;
-    f.init(&s_filter, a.cand + static_cast<u64>(w) * g.seg_cap, a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k,
-           a.cutoff);
+    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
+           a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+    uint32_t gt = 0; // table-wide threshold, loaded ahead of its use
+    uint32_t trip = 0;
+    const uint32_t wib = w % (kScanBlock / 64);
 
     const u64 nfull = a.nrows / CH; // chunks with all CH rows present
     if (w < nfull) {
@@ -375,7 +523,16 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
             const u32x4* p = db + cn * (CH * LPR) + lane;
 #pragma unroll
             for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
-            f.refresh();
+            f.refresh(gt, lane);
+            // The workgroup polls the table-wide threshold every 8th chunk while it moves fast
+            // (first 64 chunks), then every 32nd, then every 128th; the waves take turns so that
+            // no single wave pays for all polls.  A poll is one more entry in the loop's vmcnt
+            // queue: its latency is exposed whenever it exceeds the prefetch's (~1 us each).
+            {
+                const uint32_t period = trip < 64u ? 8u : (trip < 512u ? 32u : 128u);
+                if ((trip & (period - 1u)) == 0 && ((trip / period) & (kScanBlock / 64 - 1)) == wib) gt = f.load_gtau();
+                trip++;
+            }
             reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
             if (c == last) break;
         }
@@ -390,11 +547,87 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
             const u64 row = row0 + static_cast<u64>(j * RPL + grp);
             d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
         }
-        f.refresh();
+        f.refresh(f.load_gtau(), lane);
         reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
     }
     f.finish(w, a, lane);
     block_filter_flush(&s_filter, a);
+}
+
+// K0 sample_kernel: a valid starting threshold for the scan.
+//
+// The scan's filter starts from "emit everything" and needs a few exchanges through
+// the table-wide histogram before it prunes; with every workgroup in that state at
+// once, the start-up costs ~60 us.  This kernel scores a strided sample of the table
+// (nsample chunks, evenly spaced), histograms ALL sampled rows (no emission), and its
+// last workgroup publishes tau0 = the largest bin with >= k sampled rows at or above
+// it.  The sample is a subset of the table, so tau0 is a valid lower bound of the
+// table's k-th best bin.  The histogram is zeroed again: the scan re-reads the
+// sampled rows (<0.3 % extra traffic) and counts them itself.
+struct SampleFilter {
+    uint32_t* hist; // workgroup's LDS histogram
+    float cutoff;
+    bool has_cutoff;
+    __device__ __forceinline__ void offer(bool active, uint32_t, float raw_score, uint32_t, int)
+    {
+        const float s = apply_cutoff(raw_score, cutoff);
+        if (active && (!has_cutoff || s != 0.0f)) atomicAdd(&hist[coarse_bin(s)], 1u);
+    }
+};
+
+template <int LPR, int U>
+__global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t nsample, u64 stride_chunks)
+{
+    __shared__ uint32_t s_hist[kScanBins];
+    __shared__ uint32_t s_last;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
+    __syncthreads();
+    constexpr int CH = U * (64 / LPR);
+    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    SampleFilter f;
+    f.hist = s_hist;
+    f.cutoff = a.cutoff;
+    f.has_cutoff = a.cutoff > 0.0f;
+    const uint32_t nw = gridDim.x * (kScanBlock / 64);
+    for (uint32_t i = w; i < nsample; i += nw) {
+        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
+        const u32x4* p = db + c * (CH * LPR) + lane;
+        u32x4 d[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) d[j] = p[j * 64]; // plain loads: the scan re-reads these lines
+        reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock)
+        if (s_hist[i]) atomicAdd(&a.state->ghist[i], s_hist[i]);
+    // ticket: the last workgroup turns the histogram into tau0 and clears it
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&a.state->done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 64) {
+        constexpr int PER = kScanBins / 64;
+        uint32_t h[PER];
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            h[i] = __hip_atomic_load(&a.state->ghist[lane * PER + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += h[i];
+        }
+        uint32_t bin_k, cnt;
+        threshold_from_counts<PER>(h, s, a.k, lane, bin_k, cnt);
+        if (lane == 0) {
+            a.state->gtau = (a.k && cnt >= a.k) ? bin_k : 0u;
+            a.state->done = 0;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) a.state->ghist[i] = 0;
 }
 
 // Any fingerprint width (W words, not a power-of-two number of 16-byte lanes):
@@ -404,11 +637,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
     __shared__ BlockFilter s_filter;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    block_filter_init(&s_filter, a.k);
+    block_filter_init(&s_filter, a.k, a.state->gtau);
     const uint32_t* __restrict__ db = reinterpret_cast<const uint32_t*>(a.rows);
     WaveFilter f;
-    f.init(&s_filter, a.cand + static_cast<u64>(w) * g.seg_cap, a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k,
-           a.cutoff);
+    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
+           a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
     for (u64 c = w; c < g.nchunks; c += g.nwaves) {
         const u64 row = c * 64 + lane;
         const bool active = row < a.nrows;
@@ -421,7 +654,7 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
                 bb += __popc(x);
             }
         }
-        f.refresh();
+        f.refresh((c / g.nwaves) % 8 == 0 ? f.load_gtau() : 0u, lane);
         const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc);
         f.offer(active, static_cast<uint32_t>(row), s, (cc << 16) + bb, lane);
     }
@@ -433,11 +666,11 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
 // K2: compaction at the k-th best coarse bin
 // ---------------------------------------------------------------------------
 //
-// ghist[b] counts the candidates of the workgroups whose final threshold is <= b,
-// i.e. it under-counts bins below T = max over workgroups of tau and is exact at
-// and above T.  The table's k-th best bin B* is >= T (every tau is a lower bound
-// for it), so the largest B with sum_{b>=B} ghist[b] >= k is exactly B*; every
-// top-k row has bin >= B* >= its workgroup's tau and was therefore emitted.
+// After the scan, ghist[b] is the exact number of table rows in bin b for every
+// b >= T, T = the largest threshold any wave used, and an under-count below T.  The
+// table's k-th best bin B* is >= T (every threshold is a lower bound for it), so the
+// largest B with sum_{b>=B} ghist[b] >= k is exactly B*; every top-k row has
+// bin >= B* >= the threshold its wave compared it with and was therefore emitted.
 constexpr int kCompactStage = 1024; // finalists staged in LDS per workgroup
 
 // One wavefront per candidate segment, several loads in flight per lane.  The
@@ -724,6 +957,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
             a.state->ncand = 0;
             a.state->nfinal = 0;
             a.state->done = 0;
+            a.state->gtau = 0;
         }
         for (int i = tid; i < kScanBins; i += kSelectThreads) a.state->ghist[i] = 0;
     }
@@ -739,6 +973,7 @@ __global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st)
         st->ncand = 0;
         st->nfinal = 0;
         st->done = 0;
+        st->gtau = 0;
     }
     for (int i = threadIdx.x; i < kScanBins; i += 256) st->ghist[i] = 0;
 }
@@ -924,6 +1159,40 @@ ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_pe
     const uint64_t per = (g.nchunks + g.nwaves - 1) / g.nwaves;
     g.seg_cap = static_cast<uint32_t>((per ? per : 1) * g.chunk_rows);
     return g;
+}
+
+template <int LPR, int U>
+hipError_t launch_sample_t(const ScanArgs& a, uint32_t nsample, uint64_t stride, uint32_t nblocks, hipStream_t s)
+{
+    hipLaunchKernelGGL((sample_kernel<LPR, U>), dim3(nblocks), dim3(kScanBlock), 0, s, a, nsample, stride);
+    return hipGetLastError();
+}
+
+// Starting threshold from a strided sample (specialised widths, large tables only).
+hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s)
+{
+    if (g.lanes_per_row == 0 || a.k == 0 || chunks_per_wave == 0) return hipSuccess;
+    const uint64_t nfull = a.nrows / g.chunk_rows;
+    const uint64_t want = static_cast<uint64_t>(g.nwaves) * chunks_per_wave;
+    if (nfull < want * 16) return hipSuccess; // small table: the scan's own warm-up is cheaper
+    const uint64_t stride = nfull / want;
+    const uint32_t nsample = static_cast<uint32_t>(want);
+    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+#define GSIM_CASE(L, UU) \
+    if (g.lanes_per_row == L && g.unroll == UU) return launch_sample_t<L, UU>(a, nsample, stride, nblocks, s);
+    GSIM_CASE(8, 8)
+    GSIM_CASE(8, 4)
+    GSIM_CASE(8, 16)
+    GSIM_CASE(16, 8)
+    GSIM_CASE(16, 4)
+    GSIM_CASE(16, 16)
+    GSIM_CASE(1, 8)
+    GSIM_CASE(2, 8)
+    GSIM_CASE(4, 8)
+    GSIM_CASE(32, 8)
+    GSIM_CASE(64, 8)
+#undef GSIM_CASE
+    return hipSuccess;
 }
 
 hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
