@@ -42,7 +42,8 @@ _lib = None
 
 EXPORTS = [
     "gsim_device_count", "gsim_device_free_bytes", "gsim_available_device_bytes", "gsim_next_device",
-    "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_generate", "gsim_db_attach_device_rows",
+    "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor",
+    "gsim_fold_fingerprint", "gsim_db_generate", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
     "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_merge_host",
@@ -76,6 +77,9 @@ def load():
         "gsim_db_create": (C.c_int, [C.c_uint32, C.POINTER(vp)]),
         "gsim_db_add_rows": (C.c_int, [vp, u32p, C.c_uint64]),
         "gsim_db_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
+        "gsim_db_set_fold_factor": (C.c_int, [vp, C.c_uint32]),
+        "gsim_db_fold_factor": (C.c_uint32, [vp]),
+        "gsim_fold_fingerprint": (C.c_int, [u32p, C.c_uint32, C.c_uint32, u32p]),
         "gsim_db_generate": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
         "gsim_db_attach_device_rows": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
         "gsim_db_destroy": (C.c_int, [vp]),
@@ -161,6 +165,13 @@ class Table:
         rows = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1, self.W)
         check(self._L.gsim_db_add_rows(self._h, _u32(rows), rows.shape[0]))
         return self
+
+    def set_fold_factor(self, fold_factor: int):
+        check(self._L.gsim_db_set_fold_factor(self._h, fold_factor))
+        return self
+
+    def fold_factor(self) -> int:
+        return int(self._L.gsim_db_fold_factor(self._h))
 
     def finalize(self, device: int = 0, ndevices: int = 1):
         check(self._L.gsim_db_finalize(self._h, device, ndevices))
@@ -252,6 +263,13 @@ class Table:
         t = GsimTiming()
         check(self._L.gsim_db_get_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in GsimTiming._fields_}
+
+
+def fold_fingerprint(fp, fold_factor: int) -> np.ndarray:
+    fp = np.ascontiguousarray(fp, dtype=np.uint32)
+    out = np.zeros(len(fp) // fold_factor, dtype=np.uint32)
+    check(load().gsim_fold_fingerprint(_u32(fp), len(fp), fold_factor, _u32(out)))
+    return out
 
 
 def merge_device(device, stream_ptr, d_blocks_ptr, nblocks, block_bytes, k, d_result_ptr):

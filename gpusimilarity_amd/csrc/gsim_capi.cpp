@@ -59,6 +59,7 @@ struct Shard {
     int num_cus = 256;
     uint64_t first_row = 0; // offset inside the handle's table
     uint64_t nrows = 0;
+    uint32_t W = 0;         // words per row ON THE DEVICE (table width / fold factor)
     void* d_rows = nullptr;
     bool owns_rows = false;
     hipStream_t own_stream = nullptr;
@@ -100,6 +101,9 @@ struct gsim_db {
     bool has_host_copy = false;
     bool finalized = false;
     std::vector<Shard> shards;
+    std::vector<uint64_t> slice_first; // first row of every add_rows slice (reference: one storage each)
+    uint32_t fold_requested = 1;       // gsim_db_set_fold_factor
+    uint32_t fold = 1;                 // effective factor (divides W), fixed at finalize
     uint32_t row_base = 0;
     bool timing = false;
     gsim_timing acc{};
@@ -149,10 +153,11 @@ int setup_shard(gsim_db* db, Shard& s)
     s.stream = s.own_stream;
     const int wpc = env_int("GSIM_SCAN_WAVES_PER_CU", 4);
     const int unroll = env_int("GSIM_SCAN_UNROLL", 8);
-    s.geo = gsim::scan_geometry(s.nrows, db->W, s.num_cus, wpc, unroll);
+    if (s.W == 0) s.W = db->W;
+    s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, unroll);
     s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
     const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
-    GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(db->W) * 4));
+    GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(s.W) * 4));
     GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
     GSIM_HIP(hipMemset(s.d_state, 0, sizeof(gsim::QueryState))); // the select kernel keeps it zero between queries
     GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
@@ -161,7 +166,7 @@ int setup_shard(gsim_db* db, Shard& s)
     s.final_cap = next_pow2_u32(slots);
     GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
     GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
-    GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(db->W) * 4 * kQueryRing, hipHostMallocDefault));
+    GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(s.W) * 4 * kQueryRing, hipHostMallocDefault));
     for (int i = 0; i < kQueryRing; i++) {
         hipEvent_t e;
         GSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -208,20 +213,20 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
 {
     GSIM_HIP(hipSetDevice(s.device));
     const uint32_t slot = s.q_next++ % kQueryRing;
-    uint32_t* hq = s.h_query + static_cast<size_t>(slot) * db->W;
+    uint32_t* hq = s.h_query + static_cast<size_t>(slot) * s.W;
     if (s.q_pending[slot]) { // only set by asynchronous searches
         GSIM_HIP(hipEventSynchronize(s.q_ev[slot]));
         s.q_pending[slot] = false;
     }
-    std::memcpy(hq, query, static_cast<size_t>(db->W) * 4);
+    std::memcpy(hq, query, static_cast<size_t>(s.W) * 4); // `query` is already folded for a folded table
 
     gsim::ScanArgs a{};
     a.rows = s.d_rows;
     a.nrows = s.nrows;
-    a.W = db->W;
+    a.W = s.W;
     a.query = hq; // hipHostMalloc memory: device-visible at the same address
     a.query_dev = s.d_query;
-    a.qpop = popcount_words(query, db->W);
+    a.qpop = popcount_words(query, s.W);
     a.k = k;
     a.cutoff = cutoff;
     a.metric = metric;
@@ -234,7 +239,7 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
     a.debug = static_cast<uint32_t>(env_int("GSIM_DEBUG", 0));
     if (s.geo.lanes_per_row == 0 || s.nrows == 0) {
         // generic-width scan reads the query per word: give it a device copy
-        GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(db->W) * 4, hipMemcpyHostToDevice, s.stream));
+        GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(s.W) * 4, hipMemcpyHostToDevice, s.stream));
         a.query = s.d_query;
     }
 
@@ -330,8 +335,124 @@ bool hit_before(const gsim_hit& x, const gsim_hit& y)
     return x.row < y.row;
 }
 
+// FoldFingerprintFunctorCPU (calculation_functors.cpp:22-41): bit `pos` of the fingerprint is
+// OR-ed into bit `pos % (32 * Wf)`; since 32 * Wf is a multiple of 32 that is word (w % Wf), same
+// bit -- i.e. the F consecutive blocks of Wf words are OR-ed together.
+void fold_row(const uint32_t* row, uint32_t W, uint32_t F, uint32_t* out)
+{
+    const uint32_t Wf = W / F;
+    for (uint32_t j = 0; j < Wf; j++) out[j] = 0;
+    for (uint32_t w = 0; w < W; w++) out[w % Wf] |= row[w];
+}
+
+// fold_data (fingerprintdb_cuda.cpp:56-69) over a row range, on all host threads
+void fold_rows_mt(const uint32_t* rows, uint64_t nrows, uint32_t W, uint32_t F, uint32_t* out)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > nrows) nt = nrows ? static_cast<unsigned>(nrows) : 1;
+    const uint32_t Wf = W / F;
+    const uint64_t per = (nrows + nt - 1) / nt;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t lo = per * t, hi = std::min<uint64_t>(lo + per, nrows);
+        if (lo >= hi) break;
+        pool.emplace_back([=] {
+            for (uint64_t r = lo; r < hi; r++) fold_row(rows + r * W, W, F, out + r * Wf);
+        });
+    }
+    for (auto& th : pool) th.join();
+}
+
 std::mutex g_rr_mutex;
 int g_next_device = 0;
+
+// Search of a folded table, fingerprintdb_cuda.cu:228-339 with m_fold_factor > 1, per storage:
+// folded query vs folded rows on the GPU for the k*F*(int)log2(2F) best FOLDED scores (:284-287),
+// re-score those with the full fingerprints on the host (:307-314), stable partial bubble sort
+// (:315), keep min(k, .) and stop at the first re-scored value below the cutoff (:317-331);
+// then FingerprintDB::search's merge over the storages (:363-380).
+int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, gsim_hit* hits,
+                  uint32_t* counts, uint64_t* approx)
+{
+    const uint32_t F = db->fold, W = db->W, Wf = W / F;
+    int lg = 0;
+    while ((1u << (lg + 1)) <= 2 * F) lg++;
+    const uint64_t want = static_cast<uint64_t>(k) * F * static_cast<uint64_t>(lg);
+    std::vector<uint32_t> fq(Wf);
+    std::vector<gsim_hit> merged;
+    std::vector<int> idx;
+    std::vector<float> sc;
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t* query = queries + static_cast<size_t>(q) * W;
+        fold_row(query, W, F, fq.data());
+        const uint32_t qa = popcount_words(query, W);
+        std::vector<uint32_t> kshard(db->shards.size());
+        for (size_t i = 0; i < db->shards.size(); i++) {
+            Shard& s = db->shards[i];
+            kshard[i] = static_cast<uint32_t>(std::min<uint64_t>(want, s.nrows));
+            int rc = ensure_result_capacity(s, kshard[i]);
+            if (rc != GSIM_OK) return rc;
+            rc = enqueue_query(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result, true);
+            if (rc != GSIM_OK) return rc;
+        }
+        uint64_t ap = 0;
+        merged.clear();
+        for (size_t i = 0; i < db->shards.size(); i++) {
+            Shard& s = db->shards[i];
+            GSIM_HIP(hipSetDevice(s.device));
+            int rc = wait_stream(s.stream);
+            if (rc != GSIM_OK) return rc;
+            const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
+            const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+            ap += h->approx;
+            const uint32_t n = h->count;
+            idx.resize(n);
+            sc.resize(n);
+            std::vector<uint16_t> cm(n), pc(n);
+            for (uint32_t j = 0; j < n; j++) { // tanimoto_similarity_cpu on the FULL fingerprints (:387-399)
+                const uint32_t* d = db->host_rows.data() + (s.first_row + hh[j].row) * W;
+                int total = 0, common = 0, pd = 0;
+                for (uint32_t w = 0; w < W; w++) {
+                    const int p2 = __builtin_popcount(d[w]);
+                    pd += p2;
+                    total += __builtin_popcount(query[w]) + p2;
+                    common += __builtin_popcount(query[w] & d[w]);
+                }
+                (void) qa;
+                idx[j] = static_cast<int>(j);
+                sc[j] = static_cast<float>(common) / static_cast<float>(total - common);
+                cm[j] = static_cast<uint16_t>(common);
+                pc[j] = static_cast<uint16_t>(pd);
+            }
+            // top_results_bubble_sort(indices, scores, k): stable, strict '>'
+            for (uint32_t a = 0; a < k && a < n; a++) {
+                for (uint32_t b = n - 1; b > a; b--) {
+                    if (sc[b] > sc[b - 1]) {
+                        std::swap(idx[b], idx[b - 1]);
+                        std::swap(sc[b], sc[b - 1]);
+                    }
+                }
+            }
+            const uint32_t keep = std::min(k, n);
+            for (uint32_t a = 0; a < keep; a++) {
+                if (sc[a] < cutoff) break;
+                gsim_hit o;
+                o.row = db->row_base + static_cast<uint32_t>(s.first_row) + hh[idx[a]].row;
+                o.score = sc[a];
+                o.common = cm[idx[a]];
+                o.popc_db = pc[idx[a]];
+                merged.push_back(o);
+            }
+        }
+        if (db->shards.size() > 1) std::stable_sort(merged.begin(), merged.end(), hit_before);
+        const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
+        if (n) std::memcpy(hits + static_cast<size_t>(q) * k, merged.data(), sizeof(gsim_hit) * n);
+        counts[q] = n;
+        if (approx) approx[q] = ap;
+    }
+    return GSIM_OK;
+}
 
 } // namespace
 
@@ -429,12 +550,36 @@ int gsim_db_add_rows(gsim_db* db, const uint32_t* rows, uint64_t nrows)
     if (db->finalized) return fail(GSIM_ERR_STATE, "table already finalized");
     if (db->nrows + nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
     try {
+        db->slice_first.push_back(db->nrows);
         db->host_rows.insert(db->host_rows.end(), rows, rows + nrows * db->W);
     } catch (const std::bad_alloc&) {
         return fail(GSIM_ERR_NOMEM, "out of host memory");
     }
     db->nrows += nrows;
     db->has_host_copy = true;
+    return GSIM_OK;
+}
+
+int gsim_db_set_fold_factor(gsim_db* db, uint32_t fold_factor)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    if (db->finalized) return fail(GSIM_ERR_STATE, "table already finalized");
+    if (fold_factor == 0 || fold_factor > db->W) return fail(GSIM_ERR_INVALID, "fold factor out of range");
+    db->fold_requested = fold_factor;
+    return GSIM_OK;
+}
+
+uint32_t gsim_db_fold_factor(const gsim_db* db)
+{
+    return db ? db->fold : 0;
+}
+
+int gsim_fold_fingerprint(const uint32_t* fingerprint, uint32_t words, uint32_t fold_factor, uint32_t* out)
+{
+    if (!fingerprint || !out) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (fold_factor == 0 || words == 0 || words % fold_factor != 0)
+        return fail(GSIM_ERR_INVALID, "fold factor must divide the word count");
+    fold_row(fingerprint, words, fold_factor, out);
     return GSIM_OK;
 }
 
@@ -450,6 +595,43 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
         if (device < 0) device = 0;
     }
     if (ndevices < 0) return fail(GSIM_ERR_INVALID, "ndevices < 0");
+    // copyToGPU's factor adjustment, fingerprintdb_cuda.cu:170-173
+    db->fold = db->fold_requested ? db->fold_requested : 1;
+    while (db->W % db->fold != 0) db->fold++;
+    if (db->fold > 1) {
+        // Folded table (fingerprintdb_cuda.cu:184-194): every add_rows slice is one storage with
+        // its own candidate list, placed round-robin like get_next_gpu (:54-68, :186-188).
+        if (!db->has_host_copy) return fail(GSIM_ERR_STATE, "folding needs the host copy of the rows");
+        const uint32_t Wf = db->W / db->fold;
+        const size_t nsl = db->slice_first.size();
+        db->shards.resize(nsl);
+        std::vector<uint32_t> folded;
+        for (size_t i = 0; i < nsl; i++) {
+            Shard& s = db->shards[i];
+            s.first_row = db->slice_first[i];
+            s.nrows = (i + 1 < nsl ? db->slice_first[i + 1] : db->nrows) - s.first_row;
+            s.W = Wf;
+            const size_t bytes = static_cast<size_t>(s.nrows) * Wf * 4;
+            if (device < 0 || ndevices != 1) {
+                int d = 0;
+                int rc = gsim_next_device(bytes, &d);
+                if (rc != GSIM_OK) return rc;
+                s.device = (device >= 0 && ndevices > 1) ? device + (d % ndevices) : d;
+            } else {
+                s.device = device;
+            }
+            folded.resize(static_cast<size_t>(s.nrows) * Wf);
+            fold_rows_mt(db->host_rows.data() + s.first_row * db->W, s.nrows, db->W, db->fold, folded.data());
+            GSIM_HIP(hipSetDevice(s.device));
+            GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
+            s.owns_rows = true;
+            if (bytes) GSIM_HIP(hipMemcpy(s.d_rows, folded.data(), bytes, hipMemcpyHostToDevice));
+            int rc = setup_shard(db, s);
+            if (rc != GSIM_OK) return rc;
+        }
+        db->finalized = true;
+        return GSIM_OK;
+    }
     const size_t row_bytes = static_cast<size_t>(db->W) * 4;
     if (ndevices == 1 && device < 0) {
         int rc = gsim_next_device(static_cast<size_t>(db->nrows) * row_bytes, &device);
@@ -614,6 +796,10 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
     if ((!hits && k && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
     const size_t nsh = db->shards.size();
     std::vector<gsim_hit> merged;
+    if (db->fold > 1) {
+        if (metric != GSIM_METRIC_TANIMOTO) return fail(GSIM_ERR_INVALID, "folded tables support Tanimoto only");
+        return search_folded(db, queries, nq, k, cutoff, hits, counts, approx);
+    }
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
         for (auto& s : db->shards) {

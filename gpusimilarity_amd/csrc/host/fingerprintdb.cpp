@@ -80,11 +80,9 @@ FingerprintDB::~FingerprintDB()
 
 void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices)
 {
-    if (fold_factor != 1) {
-        throw std::invalid_argument("fingerprint folding is not part of this build (the unfolded table must fit in HBM)");
-    }
-    m_fold_factor = 1;
+    if (fold_factor > 1 && gsim_db_set_fold_factor(m_db, fold_factor) != GSIM_OK) throw_last("copyToGPU");
     if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
+    m_fold_factor = static_cast<int>(gsim_db_fold_factor(m_db));
     m_on_gpu = true;
 }
 

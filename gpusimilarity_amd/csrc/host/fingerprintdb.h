@@ -36,9 +36,10 @@ class FingerprintDB
     FingerprintDB(const FingerprintDB&) = delete;
     FingerprintDB& operator=(const FingerprintDB&) = delete;
 
-    // fingerprintdb_cuda.cu:168-195.  fold_factor must be 1 in this build (folding is
-    // a "next" row; 288 GB of HBM hold the unfolded table).  ndevices: 1 = one GPU
-    // (round-robin placement like get_next_gpu), 0 = shard over all GPUs.
+    // fingerprintdb_cuda.cu:168-195.  fold_factor > 1: the GPU holds an OR-folded copy and
+    // search() is the reference's approximate folded search (candidates re-scored with the
+    // full fingerprints).  ndevices: 1 = one GPU (round-robin placement like
+    // get_next_gpu), 0 = shard over all GPUs.
     void copyToGPU(unsigned int fold_factor, int ndevices = 1);
 
     unsigned int count() const { return static_cast<unsigned int>(m_total_count); }

@@ -58,8 +58,8 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
         m_databases[base_name(database_fname)] = fps;
     }
 
-    // gpusim.cpp:121-151: does everything fit?  The reference folds when it does not;
-    // this build keeps fingerprints unfolded and refuses instead.
+    // gpusim.cpp:121-163: does everything fit?  If not (or if --gpu_bitcount asks for it) the
+    // tables are folded exactly as the reference does.
     size_t total_db_memory = 0;
     unsigned int max_compounds_in_db = 0;
     int max_fp_bitcount = 0;
@@ -87,12 +87,11 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
             }
             fold_factor = arg_fold_factor;
         }
-        if (fold_factor > 1) {
-            throw std::invalid_argument("databases need folding by " + std::to_string(fold_factor) +
-                                        " to fit; fingerprint folding is not part of this build");
-        }
         std::fprintf(stderr, "Putting graphics card data up.\n");
-        for (auto& kv : m_databases) kv.second->copyToGPU(1, ndevices);
+        if (fold_factor > 1) {
+            std::fprintf(stderr, "Folding databases by at least %u to fit in gpu memory\n", fold_factor);
+        }
+        for (auto& kv : m_databases) kv.second->copyToGPU(fold_factor, ndevices);
         std::fprintf(stderr, "Finished putting graphics card data up.\n");
     }
     std::fprintf(stderr, "Ready for searches.\n");

@@ -21,8 +21,8 @@ class GPUSimServer
   public:
     // gpusim.cpp:87-171.  open_socket = false builds the server without binding
     // /tmp/gpusimilarity (in-process use, like the reference's unit tests).
-    // gpu_bitcount: the reference's folding request (:144-151); only "no folding"
-    // (0 or >= the widest table) is accepted by this build.
+    // gpu_bitcount: the reference's folding request (:144-151): fold factor =
+    // widest fingerprint / gpu_bitcount.
     // ndevices: GPUs a table is sharded over (1 = one GPU per table, round-robin;
     // 0 = every table over all GPUs).
     explicit GPUSimServer(const std::vector<std::string>& database_fnames, int gpu_bitcount = 0,

@@ -61,12 +61,14 @@ class FingerprintDB:
         self._on_gpu = False
 
     def copyToGPU(self, fold_factor: int = 1, device: int = -1, ndevices: int = 1):
-        """fingerprintdb_cuda.cu:168-195.  Folding (fold_factor > 1) is out of scope
-        for this build: the unfolded table must fit in HBM."""
-        if fold_factor != 1:
-            raise NotImplementedError("fingerprint folding is not part of this build; 288 GB of HBM per GPU "
-                                      "hold 2.25 G unfolded 1024-bit fingerprints")
+        """fingerprintdb_cuda.cu:168-195.  fold_factor > 1 keeps an OR-folded copy on the
+        GPU and makes search() the reference's approximate folded search (re-scored with
+        the full fingerprints); the effective factor is the smallest one >= fold_factor
+        that divides the word count (:170-173)."""
+        if fold_factor > 1:
+            self._table.set_fold_factor(fold_factor)
         self._table.finalize(device, ndevices)
+        self.m_fold_factor = self._table.fold_factor()
         self._on_gpu = True
 
     def count(self) -> int:

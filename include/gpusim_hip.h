@@ -105,6 +105,20 @@ int gsim_db_add_rows(gsim_db* db, const uint32_t* rows, uint64_t nrows);
  * (ndevices == 0: all devices).  The host copy is kept (reference keeps m_data,
  * fingerprintdb_cuda.h:46) for gsim_db_row and gsim_db_search_cpu. */
 int gsim_db_finalize(gsim_db* db, int device, int ndevices);
+/* FingerprintDB::copyToGPU(fold_factor > 1)  fingerprintdb_cuda.cu:168-195 + fold_data
+ * fingerprintdb_cuda.cpp:56-69: call before gsim_db_finalize.  The table is then kept
+ * on the GPU OR-folded to fp_bits / F bits (F = the smallest factor >= fold_factor that
+ * divides the word count, :170-173), one shard per add_rows slice (one reference
+ * "storage" each).  gsim_db_search on a folded table is the reference's approximate
+ * search: the k*F*(int)log2(2F) best folded scores per storage (:284-287) are
+ * re-scored with the full fingerprints from the host copy (:307-331).  Tanimoto only.
+ * Not needed on MI355X for capacity (288 GB hold 2.25 G unfolded 1024-bit rows). */
+int gsim_db_set_fold_factor(gsim_db* db, uint32_t fold_factor);
+uint32_t gsim_db_fold_factor(const gsim_db* db);
+/* FoldFingerprintFunctorCPU (calculation_functors.cpp:22-41) for one fingerprint of
+ * `words` 32-bit words: out receives words / fold_factor words (host function). */
+int gsim_fold_fingerprint(const uint32_t* fingerprint, uint32_t words, uint32_t fold_factor,
+                          uint32_t* out);
 /* Synthetic table generated directly in HBM (no host copy): row r, word j =
  * the counter-based generator of SURVEY.md 8d (oracle/gsim_oracle.c
  * gso_synth_word is the CPU twin), rows first_row .. first_row+nrows-1.

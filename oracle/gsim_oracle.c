@@ -348,3 +348,77 @@ void gso_fold(const int* unfolded, int unfolded_intsize, int factor, int* folded
         folded[np / 32] = (int) ((unsigned) folded[np / 32] | (on << b));
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* folding                                                                   */
+/* ------------------------------------------------------------------------- */
+
+void gso_fold_rows(const uint32_t* rows, uint64_t nrows, uint32_t W, int factor, uint32_t* folded)
+{
+    const uint32_t Wf = W / (uint32_t) factor;
+    memset(folded, 0, (size_t) nrows * Wf * 4);
+    for (uint64_t r = 0; r < nrows; r++) {
+        gso_fold((const int*) (rows + r * W), (int) W, factor, (int*) (folded + r * Wf));
+    }
+}
+
+/* fingerprintdb_cuda.cu:170-173 */
+int gso_effective_fold_factor(uint32_t W, int requested)
+{
+    int f = requested;
+    while (W % (uint32_t) f != 0) f++;
+    return f;
+}
+
+int gso_search_folded(const uint32_t* query, const uint32_t* db, uint64_t nrows, uint32_t W,
+                      int fold_factor, uint32_t k, float cutoff, uint32_t row_base,
+                      gso_hit* hits, uint32_t* nhits, uint64_t* approx)
+{
+    const int F = fold_factor;
+    const uint32_t Wf = W / (uint32_t) F;
+    uint32_t* fdb = (uint32_t*) malloc((size_t) (nrows ? nrows : 1) * Wf * 4);
+    uint32_t* fq = (uint32_t*) calloc(Wf, 4);
+    if (!fdb || !fq) return -1;
+    gso_fold_rows(db, nrows, W, F, fdb);
+    gso_fold((const int*) query, (int) W, F, (int*) fq);
+    /* fingerprintdb_cuda.cu:284-287: results_to_consider = min(survivors, k * F * (int)log2(2F)) */
+    int lg = 0;
+    while ((1 << (lg + 1)) <= 2 * F) lg++;
+    const uint64_t want = (uint64_t) k * (uint64_t) F * (uint64_t) lg;
+    const uint32_t R = want > nrows ? (uint32_t) nrows : (uint32_t) want;
+    gso_hit* cand = (gso_hit*) malloc(sizeof(gso_hit) * (R ? R : 1));
+    uint32_t ncand = 0;
+    uint64_t surv = 0;
+    gso_search(fq, fdb, nrows, Wf, R, cutoff, GSO_METRIC_TANIMOTO, 0.f, 0.f, 0, 1, cand, &ncand, &surv);
+    /* re-score with the full fingerprints, in candidate order */
+    int* idx = (int*) malloc(sizeof(int) * (ncand ? ncand : 1));
+    float* sc = (float*) malloc(sizeof(float) * (ncand ? ncand : 1));
+    const uint32_t a = query_popc(query, W);
+    for (uint32_t i = 0; i < ncand; i++) {
+        uint32_t c, b;
+        row_counts(query, db + (uint64_t) cand[i].row * W, W, &c, &b);
+        idx[i] = (int) cand[i].row;
+        sc[i] = gso_score_one(GSO_METRIC_TANIMOTO, 0.f, 0.f, a, b, c);
+    }
+    gso_bubble_sort(idx, sc, (int) ncand, (int) k); /* :315 */
+    uint32_t n = k < ncand ? k : ncand;
+    uint32_t out = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (sc[i] < cutoff) break; /* :321-325 */
+        uint32_t c, b;
+        row_counts(query, db + (uint64_t) idx[i] * W, W, &c, &b);
+        hits[out].row = (uint32_t) idx[i] + row_base;
+        hits[out].score = sc[i];
+        hits[out].common = (uint16_t) c;
+        hits[out].popc_db = (uint16_t) b;
+        out++;
+    }
+    *nhits = out;
+    if (approx) *approx = surv;
+    free(idx);
+    free(sc);
+    free(cand);
+    free(fdb);
+    free(fq);
+    return 0;
+}

@@ -89,6 +89,21 @@ int gso_search_cpu(const uint32_t* query, const uint32_t* db, uint64_t nrows,
  * folded must be zero-initialised by the caller (as fold_data does, :60-61). */
 void gso_fold(const int* unfolded, int unfolded_intsize, int factor, int* folded);
 
+/* fold_data (fingerprintdb_cuda.cpp:56-69): every row folded by `factor`. */
+void gso_fold_rows(const uint32_t* rows, uint64_t nrows, uint32_t W, int factor, uint32_t* folded);
+/* copyToGPU's adjustment (fingerprintdb_cuda.cu:170-173): smallest factor >= requested
+ * that divides the word count. */
+int gso_effective_fold_factor(uint32_t W, int requested);
+/* Folded search of ONE storage, fingerprintdb_cuda.cu:228-339 with m_fold_factor > 1:
+ * folded query vs folded rows (cutoff applied to the FOLDED score, :258-273), canonical
+ * top-R with R = k * F * (int)log2(2F) (:284-287), re-score those R rows with the full
+ * fingerprints (:307-314, tanimoto_similarity_cpu :387-399), stable partial bubble sort
+ * (:315), keep the first min(k, R) and stop at the first re-scored value < cutoff
+ * (:317-331).  approx = number of folded survivors (:272-277).  Rows get row_base added. */
+int gso_search_folded(const uint32_t* query, const uint32_t* db, uint64_t nrows, uint32_t W,
+                      int fold_factor, uint32_t k, float cutoff, uint32_t row_base,
+                      gso_hit* hits, uint32_t* nhits, uint64_t* approx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,8 +70,40 @@ def lib():
                                      C.POINTER(C.c_float)]
         L.gso_fold.restype = None
         L.gso_fold.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.gso_fold_rows.restype = None
+        L.gso_fold_rows.argtypes = [_u32p, C.c_uint64, C.c_uint32, C.c_int, _u32p]
+        L.gso_effective_fold_factor.restype = C.c_int
+        L.gso_effective_fold_factor.argtypes = [C.c_uint32, C.c_int]
+        L.gso_search_folded.restype = C.c_int
+        L.gso_search_folded.argtypes = [_u32p, _u32p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_float,
+                                        C.c_uint32, C.c_void_p, _u32p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
+
+
+def fold_rows(db, factor):
+    db = np.ascontiguousarray(db, dtype=np.uint32)
+    n, W = db.shape
+    out = np.zeros((n, W // factor), dtype=np.uint32)
+    lib().gso_fold_rows(_ptr(db, C.c_uint32), n, W, factor, _ptr(out, C.c_uint32))
+    return out
+
+
+def effective_fold_factor(W, requested):
+    return int(lib().gso_effective_fold_factor(W, requested))
+
+
+def search_folded(query, db, fold_factor, k, cutoff=0.0, row_base=0):
+    db = np.ascontiguousarray(db, dtype=np.uint32)
+    query = np.ascontiguousarray(query, dtype=np.uint32)
+    n, W = db.shape
+    hits = np.zeros(max(1, k), dtype=HIT_DTYPE)
+    nh = C.c_uint32(0)
+    ap = C.c_uint64(0)
+    rc = lib().gso_search_folded(_ptr(query, C.c_uint32), _ptr(db, C.c_uint32), n, W, fold_factor, k, cutoff, row_base,
+                                 hits.ctypes.data_as(C.c_void_p), C.byref(nh), C.byref(ap))
+    assert rc == 0
+    return hits[:nh.value].copy(), int(ap.value)
 
 
 def synth_rows(seed, kind, first_row, nrows, W):

@@ -88,3 +88,19 @@ def test_search_cpu_entry_point_matches_reference_semantics():
             assert (got["score"].view(np.uint32) == sc.view(np.uint32)).all()
     with pytest.raises(capi.GsimError):
         t.search_cpu(db[0], 101)
+
+
+def test_fold_fingerprint_kat():
+    """test/test_gpusim.cpp:148-166 (FoldFingerprint) through the ABI's host fold."""
+    assert list(capi.fold_fingerprint([32, 24, 11, 7], 2)) == [43, 31]
+    assert list(capi.fold_fingerprint([32, 24, 11, 7], 4)) == [63]
+    import oracle_lib as O
+    rng = np.random.default_rng(5)
+    fp = rng.integers(0, 2**32, size=64, dtype=np.uint64).astype(np.uint32)
+    for f in (2, 4, 8, 16):
+        assert (capi.fold_fingerprint(fp, f) == O.fold(fp.view(np.int32), f).view(np.uint32)).all()
+    with pytest.raises(capi.GsimError):
+        capi.fold_fingerprint(fp, 3)
+    t = capi.Table(1024)
+    with pytest.raises(capi.GsimError):
+        t.set_fold_factor(0)

@@ -411,3 +411,71 @@ def test_baseline_sizes_properties(nrows):
     better = top[(top["score"] > kth) | ((top["score"] == kth) & (top["row"] <= h["row"][-1]))]
     assert_hits_equal(mine, better, "slice cross-check")
     t.close()
+
+
+def test_sampled_threshold_and_adversarial_row_orders():
+    """6 M rows: large enough for the sample kernel (starting threshold) to run.  The
+    same rows in random, score-ascending (every row beats the running threshold: the
+    filter's worst case, all rows become candidates) and score-descending order."""
+    n, W, k = 6_000_000, 32, 1000
+    db = O.synth_rows(0xAD7E, 0, 0, n, W)
+    q = db[O.query_row(3, n)].copy()
+    raw, _, _ = O.tanimoto_raw(q, db)
+    orders = {"random": None, "ascending": np.argsort(raw, kind="stable"), "descending": np.argsort(-raw, kind="stable")}
+    for name, perm in orders.items():
+        tab = db if perm is None else np.ascontiguousarray(db[perm])
+        t = make_table(tab)
+        for kk, cutoff in ((k, 0.0), (10, 0.0), (k, 0.12)):
+            check_against_oracle(t, tab, q, kk, cutoff, ctx="%s k=%d cutoff=%g" % (name, kk, cutoff))
+        fresh = O.synth_rows(0x5EED0002, 0, 4242, 1, W)[0]
+        check_against_oracle(t, tab, fresh, k, 0.0, ctx="%s fresh query" % name)
+        t.close()
+
+
+def test_folded_search_matches_reference_semantics():
+    """copyToGPU(fold_factor > 1): approximate search on OR-folded fingerprints, re-scored
+    with the full ones (fingerprintdb_cuda.cu:184-194, 284-331), one candidate list per
+    storage, merged as FingerprintDB::search does (:363-380)."""
+    n, W = 60_000, 32
+    db = O.synth_rows(0xF01D, 0, 0, n, W)
+    for requested in (2, 3, 4, 8):
+        F = O.effective_fold_factor(W, requested)
+        t = capi.Table(W * 32).set_fold_factor(requested)
+        t.add_rows(db)
+        t.finalize(0, 1)
+        assert t.fold_factor() == F
+        for qi, (k, cutoff) in enumerate(((20, 0.0), (100, 0.0), (50, 0.15), (10, 0.3))):
+            q = db[O.query_row(qi, n)]
+            hits, approx = t.search(q, k, cutoff)
+            want, wap = O.search_folded(q, db, F, k, cutoff)
+            assert int(approx[0]) == wap
+            assert_hits_equal(hits[0], want, "fold %d k=%d cutoff=%g" % (F, k, cutoff))
+        t.close()
+    # three storages (three add_rows slices): per-storage candidate lists, then merge
+    F, k = 4, 30
+    t = capi.Table(W * 32).set_fold_factor(F)
+    cuts = [0, 25_000, 31_000, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        t.add_rows(db[a:b])
+    t.finalize(0, 1)
+    assert t.shard_count() == 3
+    q = db[4321]
+    hits, approx = t.search(q, k, 0.0)
+    parts, ap = [], 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        h, c = O.search_folded(q, db[a:b], F, k, 0.0, row_base=a)
+        parts.append(h)
+        ap += c
+    want = O.merge_hits(parts, k)
+    assert int(approx[0]) == ap
+    assert_hits_equal(hits[0], want, "three storages")
+    # the FingerprintDB twin
+    fs = read_fsim(os.path.join(GOLD, "small.fsim"))
+    fdb = FingerprintDB(fs.fp_bitcount, fs.fp_count, fs.dbkey, fs.fp_blocks, list(fs.smiles), list(fs.ids))
+    fdb.copyToGPU(2, device=0)
+    rows = fs.rows()
+    h, ap = fdb.search_hits(rows[3], 10, 0.0)
+    want, wap = O.search_folded(rows[3], rows, 2, 10, 0.0)
+    assert ap == wap
+    assert_hits_equal(h, want, "small.fsim folded")
+    assert int(h["row"][0]) == 3 and h["score"][0] == 1.0
