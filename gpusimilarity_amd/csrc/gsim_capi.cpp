@@ -89,6 +89,26 @@ struct Shard {
     std::vector<hipEvent_t> ev; // 3 per slot
     uint32_t ev_used = 0;
     unsigned long long base_ncand = 0, base_nfinal = 0; // device totals when timing was enabled
+    // multi-query batches (allocated on first use)
+    gsim::ScanGeometry bgeo{};
+    uint32_t bq_cap = 0;          // queries the batch buffers hold
+    uint32_t bseg_cap = 0;
+    uint32_t* d_bqueries = nullptr;
+    uint32_t* d_bqpop = nullptr;
+    gsim::BatchQueryState* d_bstate = nullptr;
+    unsigned long long* d_bcand = nullptr;
+    uint32_t* d_bcand_cb = nullptr;
+    uint32_t* d_bcand_q = nullptr;
+    uint32_t* d_bseg_count = nullptr;
+    unsigned long long* d_bfin_key = nullptr;
+    uint32_t* d_bfin_cb = nullptr;
+    uint32_t* d_bflags = nullptr; // [0] overflow flags, [1] ticket
+    gsim::BatchRare* d_brare = nullptr;
+    gsim::BatchRare* h_brare = nullptr; // pinned
+    uint32_t* h_bflags = nullptr;
+    uint32_t* h_bqueries = nullptr; // pinned staging: queries + popcounts
+    unsigned char* h_bresult = nullptr;
+    size_t h_bresult_bytes = 0;
 };
 
 } // namespace
@@ -128,6 +148,21 @@ int free_shard(Shard& s)
     if (s.h_query) (void) hipHostFree(s.h_query);
     if (s.h_result) (void) hipHostFree(s.h_result);
     if (s.h_state) (void) hipHostFree(s.h_state);
+    if (s.d_bqueries) (void) hipFree(s.d_bqueries);
+    if (s.d_bqpop) (void) hipFree(s.d_bqpop);
+    if (s.d_bstate) (void) hipFree(s.d_bstate);
+    if (s.d_bcand) (void) hipFree(s.d_bcand);
+    if (s.d_bcand_cb) (void) hipFree(s.d_bcand_cb);
+    if (s.d_bcand_q) (void) hipFree(s.d_bcand_q);
+    if (s.d_bseg_count) (void) hipFree(s.d_bseg_count);
+    if (s.d_bfin_key) (void) hipFree(s.d_bfin_key);
+    if (s.d_bfin_cb) (void) hipFree(s.d_bfin_cb);
+    if (s.d_bflags) (void) hipFree(s.d_bflags);
+    if (s.d_brare) (void) hipFree(s.d_brare);
+    if (s.h_brare) (void) hipHostFree(s.h_brare);
+    if (s.h_bflags) (void) hipHostFree(s.h_bflags);
+    if (s.h_bqueries) (void) hipHostFree(s.h_bqueries);
+    if (s.h_bresult) (void) hipHostFree(s.h_bresult);
     for (auto e : s.ev) (void) hipEventDestroy(e);
     for (auto e : s.q_ev) (void) hipEventDestroy(e);
     if (s.own_stream) (void) hipStreamDestroy(s.own_stream);
@@ -366,6 +401,148 @@ void fold_rows_mt(const uint32_t* rows, uint64_t nrows, uint32_t W, uint32_t F, 
 
 std::mutex g_rr_mutex;
 int g_next_device = 0;
+
+constexpr uint32_t kBatchMaxQ = 256; // queries per batch call on a shard (larger requests are split)
+
+// Buffers of the multi-query path, sized for kBatchMaxQ queries and result blocks of k hits.
+int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
+{
+    GSIM_HIP(hipSetDevice(s.device));
+    if (s.bq_cap == 0) {
+        const int wpc = env_int("GSIM_BATCH_WAVES_PER_CU", 12);
+        s.bgeo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, 8);
+        const uint64_t nchunks = (s.nrows + 63) / 64;
+        uint64_t nw = static_cast<uint64_t>(s.num_cus) * static_cast<uint64_t>(wpc);
+        if (nw > nchunks) nw = nchunks ? nchunks : 1;
+        nw = (nw + 3) / 4 * 4;
+        s.bgeo.nwaves = static_cast<uint32_t>(nw);
+        // candidate slots per wave: the worst case (every pair a candidate) when that is small,
+        // else 64 Ki entries; a wave that needs more sets the overflow flag and the host falls back
+        const uint64_t rows_per_wave = ((nchunks + nw - 1) / nw) * 64 + 256; // chunks are 64 x (1..4) rows
+        uint64_t cap = rows_per_wave * gsim::kBQ;
+        const uint64_t lim = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP", 65536));
+        if (cap > lim) cap = lim;
+        if (cap < 256) cap = 256;
+        s.bseg_cap = static_cast<uint32_t>(cap);
+        const size_t slots = static_cast<size_t>(nw) * cap;
+        GSIM_HIP(hipMalloc(&s.d_bqueries, static_cast<size_t>(kBatchMaxQ) * s.W * 4));
+        GSIM_HIP(hipMalloc(&s.d_bqpop, kBatchMaxQ * 4));
+        GSIM_HIP(hipMalloc(&s.d_bstate, sizeof(gsim::BatchQueryState) * kBatchMaxQ));
+        GSIM_HIP(hipMalloc(&s.d_bcand, slots * 8));
+        GSIM_HIP(hipMalloc(&s.d_bcand_cb, slots * 4));
+        GSIM_HIP(hipMalloc(&s.d_bcand_q, slots * 4));
+        GSIM_HIP(hipMalloc(&s.d_bseg_count, nw * 4));
+        GSIM_HIP(hipMalloc(&s.d_bfin_key, static_cast<size_t>(kBatchMaxQ) * gsim::kSelectCap * 8));
+        GSIM_HIP(hipMalloc(&s.d_bfin_cb, static_cast<size_t>(kBatchMaxQ) * gsim::kSelectCap * 4));
+        GSIM_HIP(hipMalloc(&s.d_bflags, 16));
+        GSIM_HIP(hipMalloc(&s.d_brare, sizeof(gsim::BatchRare)));
+        GSIM_HIP(hipHostMalloc(&s.h_brare, sizeof(gsim::BatchRare), hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(&s.h_bflags, 16, hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(&s.h_bqueries, static_cast<size_t>(kBatchMaxQ) * (s.W + 1) * 4, hipHostMallocDefault));
+        s.bq_cap = kBatchMaxQ;
+    }
+    const size_t need = gsim_result_block_bytes(k) * kBatchMaxQ;
+    if (need > s.h_bresult_bytes) {
+        if (s.h_bresult) GSIM_HIP(hipHostFree(s.h_bresult));
+        s.h_bresult = nullptr;
+        GSIM_HIP(hipHostMalloc(&s.h_bresult, need, hipHostMallocDefault));
+        s.h_bresult_bytes = need;
+    }
+    return GSIM_OK;
+}
+
+// Enqueue nq (<= kBatchMaxQ) queries on one shard: ceil(nq / kBQ) passes over the table, the
+// result blocks land in s.h_bresult (pinned).  No host synchronisation.
+int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+                  float alpha, float beta, uint32_t row_base)
+{
+    int rc = ensure_batch_buffers(db, s, k);
+    if (rc != GSIM_OK) return rc;
+    GSIM_HIP(hipSetDevice(s.device));
+    const size_t qbytes = static_cast<size_t>(nq) * s.W * 4;
+    std::memcpy(s.h_bqueries, queries, qbytes);
+    uint32_t* hp = s.h_bqueries + static_cast<size_t>(nq) * s.W;
+    for (uint32_t q = 0; q < nq; q++) hp[q] = popcount_words(queries + static_cast<size_t>(q) * s.W, s.W);
+    GSIM_HIP(hipMemcpyAsync(s.d_bqueries, s.h_bqueries, qbytes, hipMemcpyHostToDevice, s.stream));
+    GSIM_HIP(hipMemcpyAsync(s.d_bqpop, hp, static_cast<size_t>(nq) * 4, hipMemcpyHostToDevice, s.stream));
+    GSIM_HIP(hipMemsetAsync(s.d_bstate, 0, sizeof(gsim::BatchQueryState) * nq, s.stream));
+    GSIM_HIP(hipMemsetAsync(s.d_bflags, 0, 16, s.stream));
+    gsim::BatchRare& rr = *s.h_brare;
+    rr.qstate = s.d_bstate;
+    rr.cand = s.d_bcand;
+    rr.cand_cb = s.d_bcand_cb;
+    rr.cand_q = s.d_bcand_q;
+    rr.seg_count = s.d_bseg_count;
+    rr.fin_key = s.d_bfin_key;
+    rr.fin_cb = s.d_bfin_cb;
+    rr.flags = s.d_bflags;
+    rr.ticket = s.d_bflags + 1;
+    rr.seg_cap = s.bseg_cap;
+    rr.pad = 0;
+    GSIM_HIP(hipMemcpyAsync(s.d_brare, s.h_brare, sizeof(gsim::BatchRare), hipMemcpyHostToDevice, s.stream));
+    gsim::BatchArgs a{};
+    a.rows = s.d_rows;
+    a.nrows = s.nrows;
+    a.W = s.W;
+    a.queries = s.d_bqueries;
+    a.qpop = s.d_bqpop;
+    a.rare = s.d_brare;
+    a.k = k;
+    a.cutoff = cutoff;
+    a.metric = metric;
+    a.alpha = alpha;
+    a.beta = beta;
+    const uint32_t sample = static_cast<uint32_t>(env_int("GSIM_BATCH_SAMPLE_CHUNKS", 8));
+    for (uint32_t q0 = 0; q0 < nq; q0 += gsim::kBQ) {
+        a.q0 = q0;
+        a.nq = std::min<uint32_t>(gsim::kBQ, nq - q0);
+        GSIM_HIP(gsim::launch_batch_pass(a, rr, s.bgeo, sample, row_base, s.h_bresult, gsim_result_block_bytes(k),
+                                         s.stream));
+    }
+    GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 16, hipMemcpyDeviceToHost, s.stream));
+    return GSIM_OK;
+}
+
+// One query through the single-query pipeline on every shard, host merge across shards
+// (FingerprintDB::search, fingerprintdb_cuda.cu:341-381).
+int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha, float beta,
+               gsim_hit* hits, uint32_t* count, uint64_t* approx, std::vector<gsim_hit>& merged)
+{
+    const size_t nsh = db->shards.size();
+    for (auto& s : db->shards) {
+        int rc = ensure_result_capacity(s, k);
+        if (rc != GSIM_OK) return rc;
+        // the select kernel writes the block straight into pinned host memory
+        rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta,
+                           db->row_base + static_cast<uint32_t>(s.first_row), s.h_result, true);
+        if (rc != GSIM_OK) return rc;
+    }
+    uint64_t ap = 0;
+    merged.clear();
+    for (auto& s : db->shards) {
+        GSIM_HIP(hipSetDevice(s.device));
+        int rc = wait_stream(s.stream);
+        if (rc != GSIM_OK) return rc;
+        const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
+        const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+        ap += h->approx;
+        if (nsh == 1) {
+            std::memcpy(hits, hh, sizeof(gsim_hit) * h->count);
+            *count = h->count;
+        } else {
+            merged.insert(merged.end(), hh, hh + h->count);
+        }
+    }
+    if (nsh > 1) {
+        // std::sort + truncate (fingerprintdb_cuda.cu:363-380)
+        std::sort(merged.begin(), merged.end(), hit_before);
+        const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
+        std::memcpy(hits, merged.data(), sizeof(gsim_hit) * n);
+        *count = n;
+    }
+    if (approx) *approx = ap;
+    return GSIM_OK;
+}
 
 // Search of a folded table, fingerprintdb_cuda.cu:228-339 with m_fold_factor > 1, per storage:
 // folded query vs folded rows on the GPU for the k*F*(int)log2(2F) best FOLDED scores (:284-287),
@@ -800,40 +977,67 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         if (metric != GSIM_METRIC_TANIMOTO) return fail(GSIM_ERR_INVALID, "folded tables support Tanimoto only");
         return search_folded(db, queries, nq, k, cutoff, hits, counts, approx);
     }
-    for (uint32_t q = 0; q < nq; q++) {
-        const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
-        for (auto& s : db->shards) {
-            rc = ensure_result_capacity(s, k);
-            if (rc != GSIM_OK) return rc;
-            // the select kernel writes the block straight into pinned host memory
-            rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta,
-                               db->row_base + static_cast<uint32_t>(s.first_row), s.h_result, true);
-            if (rc != GSIM_OK) return rc;
-        }
-        uint64_t ap = 0;
-        merged.clear();
-        for (auto& s : db->shards) {
-            GSIM_HIP(hipSetDevice(s.device));
-            rc = wait_stream(s.stream);
-            if (rc != GSIM_OK) return rc;
-            const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
-            const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
-            ap += h->approx;
-            if (nsh == 1) {
-                std::memcpy(hits + static_cast<size_t>(q) * k, hh, sizeof(gsim_hit) * h->count);
-                counts[q] = h->count;
-            } else {
-                merged.insert(merged.end(), hh, hh + h->count);
+    const bool batched = nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 && gsim::batch_supported(db->W) &&
+                         env_int("GSIM_BATCH", 1) != 0;
+    if (batched) {
+        // Multi-query path: kBQ queries share each pass over the table (VALU-bound).
+        const size_t blk = gsim_result_block_bytes(k);
+        for (uint32_t base = 0; base < nq; base += kBatchMaxQ) {
+            const uint32_t nb = std::min<uint32_t>(kBatchMaxQ, nq - base);
+            const uint32_t* qb = queries + static_cast<size_t>(base) * db->W;
+            std::vector<char> redo(nb, 0);
+            for (auto& s : db->shards) {
+                if (s.nrows == 0) continue;
+                rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta,
+                                   db->row_base + static_cast<uint32_t>(s.first_row));
+                if (rc != GSIM_OK) return rc;
+            }
+            bool overflow = false;
+            for (auto& s : db->shards) {
+                if (s.nrows == 0) continue;
+                GSIM_HIP(hipSetDevice(s.device));
+                rc = wait_stream(s.stream);
+                if (rc != GSIM_OK) return rc;
+                if (s.h_bflags[0] & 1u) overflow = true;
+            }
+            for (uint32_t q = 0; q < nb; q++) {
+                uint64_t ap = 0;
+                merged.clear();
+                bool bad = overflow;
+                for (auto& s : db->shards) {
+                    if (s.nrows == 0) continue;
+                    const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_bresult + q * blk);
+                    if (h->flags & 2u) bad = true;
+                    ap += h->approx;
+                    const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+                    merged.insert(merged.end(), hh, hh + h->count);
+                }
+                if (bad) {
+                    redo[q] = 1;
+                    continue;
+                }
+                if (nsh > 1) std::sort(merged.begin(), merged.end(), hit_before);
+                const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
+                if (n) std::memcpy(hits + static_cast<size_t>(base + q) * k, merged.data(), sizeof(gsim_hit) * n);
+                counts[base + q] = n;
+                if (approx) approx[base + q] = ap;
+            }
+            // heavy ties / candidate overflow: those queries go through the single-query path
+            for (uint32_t q = 0; q < nb; q++) {
+                if (!redo[q]) continue;
+                rc = search_one(db, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta,
+                                hits + static_cast<size_t>(base + q) * k, &counts[base + q],
+                                approx ? &approx[base + q] : nullptr, merged);
+                if (rc != GSIM_OK) return rc;
             }
         }
-        if (nsh > 1) {
-            // FingerprintDB::search's host merge: std::sort + truncate (fingerprintdb_cuda.cu:363-380)
-            std::sort(merged.begin(), merged.end(), hit_before);
-            const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
-            std::memcpy(hits + static_cast<size_t>(q) * k, merged.data(), sizeof(gsim_hit) * n);
-            counts[q] = n;
-        }
-        if (approx) approx[q] = ap;
+        return GSIM_OK;
+    }
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
+        rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * k, &counts[q],
+                        approx ? &approx[q] : nullptr, merged);
+        if (rc != GSIM_OK) return rc;
     }
     return GSIM_OK;
 }

@@ -89,6 +89,54 @@ hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_
 hipError_t launch_merge(const void* d_blocks, uint32_t nblocks, size_t block_bytes, uint32_t k,
                         void* d_result, hipStream_t s);
 
+// ---- multi-query batches (gsim_batch.hip) ------------------------------------------
+constexpr int kBQ = 32;     // queries per pass over the table
+constexpr int kBBins = 512; // linear coarse bins of the batch filter
+
+struct BatchQueryState { // one per query of a batch, device memory, zeroed before the batch
+    uint32_t ghist[kBBins];
+    uint32_t gtau;
+    uint32_t nfinal;
+    uint32_t bstar;
+    uint32_t pad;
+    unsigned long long kept;
+};
+
+// Rarely used arguments (emission / compaction paths) live in device memory so that the
+// scan's inner loop has scalar registers left for double-buffered query loads.
+struct BatchRare {
+    BatchQueryState* qstate; // device, Q
+    unsigned long long* cand; // per-wave segments, seg_cap entries each
+    uint32_t* cand_cb;
+    uint32_t* cand_q;
+    uint32_t* seg_count;      // nwaves
+    unsigned long long* fin_key; // Q x kSelectCap
+    uint32_t* fin_cb;
+    uint32_t* flags;          // bit 0: a candidate segment overflowed
+    uint32_t* ticket;
+    uint32_t seg_cap;
+    uint32_t pad;
+};
+
+struct BatchArgs {
+    const void* rows;
+    uint64_t nrows;
+    const uint32_t* queries; // device, Q x W words
+    const uint32_t* qpop;    // device, Q
+    const BatchRare* rare;   // device copy of the rare arguments
+    uint32_t W;
+    uint32_t q0, nq;         // this pass: queries q0 .. q0+nq-1, nq <= kBQ
+    uint32_t k;
+    float cutoff;
+    int metric;
+    float alpha, beta;
+};
+
+bool batch_supported(uint32_t W);
+hipError_t launch_batch_pass(const BatchArgs& a, const BatchRare& rare_host, const ScanGeometry& g,
+                             uint32_t sample_chunks, uint32_t row_base, void* results, size_t block_bytes,
+                             hipStream_t s);
+
 hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows,
                            uint32_t W, hipStream_t s);
 

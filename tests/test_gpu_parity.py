@@ -479,3 +479,64 @@ def test_folded_search_matches_reference_semantics():
     assert ap == wap
     assert_hits_equal(h, want, "small.fsim folded")
     assert int(h["row"][0]) == 3 and h["score"][0] == 1.0
+
+
+def batch_check(t, db, qs, k, cutoff=0.0, ctx="", **kw):
+    hits, approx = t.search(qs, k, cutoff, **kw)
+    okw = {}
+    if "metric" in kw:
+        okw = dict(metric=kw["metric"], alpha=kw.get("alpha", 1.0), beta=kw.get("beta", 1.0))
+    for i in range(len(qs)):
+        want, wap = O.search(qs[i], db, k, cutoff, nthreads=8, **okw)
+        assert int(approx[i]) == wap, "%s q=%d" % (ctx, i)
+        assert_hits_equal(hits[i], want, "%s q=%d" % (ctx, i))
+
+
+@pytest.mark.parametrize("W,kind,n", [(64, 0, 150_000), (32, 0, 200_000), (32, 1, 120_000), (16, 0, 90_000),
+                                      (8, 1, 50_000), (4, 0, 40_000)])
+def test_multi_query_pass_matches_single_query_results(W, kind, n):
+    """The VALU-bound multi-query kernels (kBQ = 32 queries per table pass): identical
+    results to the oracle for every query, several passes (70 queries = 32 + 32 + 6)."""
+    db = O.synth_rows(0xBA7C0 + W, kind, 0, n, W)
+    t = make_table(db)
+    qs = np.stack([db[O.query_row(i, n)] for i in range(66)] +
+                  [O.synth_rows(0x5EED0002, kind, 100 + i, 1, W)[0] for i in range(4)])
+    batch_check(t, db, qs, 100, 0.0, ctx="batch W=%d" % W)
+    batch_check(t, db, qs[:37], 1000, 0.0, ctx="batch k=1000 W=%d" % W)
+    batch_check(t, db, qs[:9], 25, 0.11, ctx="batch cutoff W=%d" % W)
+    batch_check(t, db, qs[:33], 300, 0.0, ctx="batch tversky W=%d" % W, metric=capi.METRIC_TVERSKY,
+                alpha=np.float32(0.3), beta=np.float32(0.7))
+    t.close()
+
+
+def test_multi_query_pass_large_table_with_sampling():
+    """3 M rows x 2048 bit: the batch sample kernel sets the starting thresholds."""
+    n, W = 3_000_000, 64
+    t = capi.Table(W * 32)
+    t.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
+    db = O.synth_rows(0x5EED0001, 0, 0, n, W)
+    qs = np.stack([db[O.query_row(i, n)] for i in range(40)])
+    batch_check(t, db, qs, 1000, 0.0, ctx="3M x 2048-bit tversky", metric=capi.METRIC_TVERSKY,
+                alpha=np.float32(0.3), beta=np.float32(0.7))
+    t.close()
+
+
+def test_multi_query_pass_fallbacks():
+    """Heavy ties (> SELECT_CAP finalists for a query) and candidate-segment overflow: those
+    queries are re-run through the single-query path; results stay exact."""
+    base = O.synth_rows(0x71E5, 0, 0, 3, 32)
+    n = 40_000
+    db = np.ascontiguousarray(np.tile(base, (n // 3 + 1, 1))[:n])
+    t = make_table(db)
+    qs = np.stack([db[i % 3] for i in range(8)])
+    batch_check(t, db, qs, 50, 0.0, ctx="batch heavy ties")
+    t.close()
+    os.environ["GSIM_BATCH_SEG_CAP"] = "256"  # force candidate-segment overflow
+    try:
+        db2 = O.synth_rows(0x0F10, 0, 0, 300_000, 32)
+        t2 = make_table(db2)
+        qs2 = np.stack([db2[O.query_row(i, len(db2))] for i in range(12)])
+        batch_check(t2, db2, qs2, 200, 0.0, ctx="batch overflow fallback")
+        t2.close()
+    finally:
+        del os.environ["GSIM_BATCH_SEG_CAP"]
