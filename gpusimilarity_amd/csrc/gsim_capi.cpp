@@ -271,7 +271,6 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
     a.cand_cb = s.d_cand_cb;
     a.seg_count = s.d_seg_count;
     a.state = s.d_state;
-    a.debug = static_cast<uint32_t>(env_int("GSIM_DEBUG", 0));
     if (s.geo.lanes_per_row == 0 || s.nrows == 0) {
         // generic-width scan reads the query per word: give it a device copy
         GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(s.W) * 4, hipMemcpyHostToDevice, s.stream));

@@ -57,7 +57,6 @@ struct ScanArgs {
     uint32_t* cand_cb;        // device, nwaves*seg_cap (common << 16 | popc_db), parallel to cand
     uint32_t* seg_count;      // device, nwaves
     QueryState* state;        // device
-    uint32_t debug;           // GSIM_DEBUG bits (experiments only; 0 in production)
 };
 
 // Geometry of the scan grid for a table (host side, no device work).
