@@ -1026,8 +1026,11 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
 {
     if (g.lanes_per_row == 0 || a.k == 0 || chunks_per_wave == 0) return hipSuccess;
     const uint64_t nfull = a.nrows / g.chunk_rows;
+    // never sample more than 1/8 of the table; under one chunk per wave the scan's own warm-up is cheaper
+    const uint64_t fit = nfull / (8ull * g.nwaves);
+    if (fit < chunks_per_wave) chunks_per_wave = static_cast<uint32_t>(fit);
+    if (chunks_per_wave == 0) return hipSuccess;
     const uint64_t want = static_cast<uint64_t>(g.nwaves) * chunks_per_wave;
-    if (nfull < want * 16) return hipSuccess; // small table: the scan's own warm-up is cheaper
     const uint64_t stride = nfull / want;
     const uint32_t nsample = static_cast<uint32_t>(want);
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
