@@ -127,6 +127,9 @@ struct gsim_db {
     uint32_t row_base = 0;
     bool timing = false;
     gsim_timing acc{};
+    // One search at a time per handle (the reference serialises searches behind a function-static
+    // mutex, fingerprintdb_cuda.cu:236): concurrent callers queue here.
+    std::mutex search_mutex;
 };
 
 namespace
@@ -180,6 +183,8 @@ uint32_t next_pow2_u32(uint64_t x)
 // Allocate the per-shard search scratch once the rows are in place.
 int setup_shard(gsim_db* db, Shard& s)
 {
+    if (s.nrows > 0x7FFFFFFFull) // candidate / finalist slots are 32-bit indexed, capacity a power of two <= 2^31
+        return fail(GSIM_ERR_INVALID, "more than 2^31-1 rows on one device: shard the table over more devices");
     GSIM_HIP(hipSetDevice(s.device));
     hipDeviceProp_t prop;
     GSIM_HIP(hipGetDeviceProperties(&prop, s.device));
@@ -970,6 +975,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
     int rc = check_search_args(db, queries, metric);
     if (rc != GSIM_OK) return rc;
     if ((!hits && k && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
     const size_t nsh = db->shards.size();
     std::vector<gsim_hit> merged;
     if (db->fold > 1) {
@@ -1048,6 +1054,8 @@ int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float 
     if (rc != GSIM_OK) return rc;
     if (!d_result) return fail(GSIM_ERR_INVALID, "d_result is NULL");
     if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "search_device needs a single-shard handle");
+    if (db->fold > 1) return fail(GSIM_ERR_STATE, "search_device does not support folded tables");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
     Shard& s = db->shards[0];
     return enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base, d_result, false);
 }
