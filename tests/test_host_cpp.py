@@ -172,3 +172,39 @@ print(json.dumps({"n": n, "ids": [i.decode() for i in ids], "scores": scores}))
         srv.close()
     assert got["n"] == 20 and got["ids"][0] == "ZINC00000022" and got["scores"][0] == 1.0
     assert got["ids"][1] == "ZINC00000323"  # SURVEY Appendix C, query = row 3
+
+
+@pytest.mark.gpu
+def test_server_gpu_bitcount_folds_like_the_reference(fsim_pair):
+    """`gpusimserver --gpu_bitcount 512` (gpusim.cpp:144-163): tables are folded by 1024/512 = 2 and
+    searched the reference's approximate way; replies match the oracle's folded search."""
+    import struct
+    import numpy as np
+    import oracle_lib as O
+    from gpusimilarity_amd.fsim import read_fsim
+    fs = read_fsim(fsim_pair[0])
+    rows = fs.rows()
+
+    def cstr(b):
+        return struct.pack(">I", len(b) + 1) + b + b"\0"
+
+    srv = Server(["--gpu_bitcount", "512", fsim_pair[0]])
+    try:
+        for qrow, k, cutoff in ((3, 10, 0.0), (0, 5, 0.25)):
+            fp = rows[qrow].tobytes()
+            req = (struct.pack(">i", 1) + cstr(b"small") + cstr(b"pass") + struct.pack(">iid", 4242 + qrow, k, cutoff) +
+                   struct.pack(">I", len(fp)) + fp)
+            reply = srv.ask(req)
+            reqnum, n, approx = struct.unpack(">iiQ", reply[:16])
+            want, wap = O.search_folded(rows[qrow], rows, 2, k, cutoff)
+            assert reqnum == 4242 + qrow and n == len(want) and approx == wap
+            off, ids = 16, []
+            for _ in range(2 * n):
+                ln = struct.unpack(">I", reply[off:off + 4])[0]
+                ids.append(reply[off + 4:off + 4 + ln - 1])
+                off += 4 + ln
+            assert ids[n:] == [fs.ids[int(r)] for r in want["row"]]
+            scores = struct.unpack(">%dd" % n, reply[off:off + 8 * n])
+            assert [np.float32(s) for s in scores] == [s for s in want["score"]]
+    finally:
+        srv.close()
