@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,7 @@ struct Shard {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr; // the stream in use (own or caller's)
     gsim::ScanGeometry geo{};
+    bool state_dirty = false; // set when an enqueue failed: the device state is re-zeroed before the next one
     int sample_chunks = 4; // chunks per scan wave scored by the sample kernel (0 = off)
     uint32_t* d_query = nullptr;
     gsim::QueryState* d_state = nullptr;
@@ -248,10 +250,14 @@ uint32_t popcount_words(const uint32_t* q, uint32_t W)
 // straight from a pinned ring slot (no upload op) and the select kernel re-zeroes
 // the per-query state (no memset op).  Nothing here synchronises with the host
 // unless k > kSelectCap.
-int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                  float beta, uint32_t row_base, void* out, bool caller_syncs)
+int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                       float beta, uint32_t row_base, void* out, bool caller_syncs)
 {
     GSIM_HIP(hipSetDevice(s.device));
+    if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
+        GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, ncand_sum), s.stream));
+        s.state_dirty = false;
+    }
     const uint32_t slot = s.q_next++ % kQueryRing;
     uint32_t* hq = s.h_query + static_cast<size_t>(slot) * s.W;
     if (s.q_pending[slot]) { // only set by asynchronous searches
@@ -323,6 +329,14 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
         s.ev_used++;
     }
     return GSIM_OK;
+}
+
+int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                  float beta, uint32_t row_base, void* out, bool caller_syncs)
+{
+    const int rc = enqueue_query_impl(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, caller_syncs);
+    if (rc != GSIM_OK) s.state_dirty = true;
+    return rc;
 }
 
 // Fold the recorded events of a shard into the handle's accumulators.

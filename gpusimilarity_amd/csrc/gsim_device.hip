@@ -1085,10 +1085,17 @@ hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned lon
 hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, const uint32_t* finalists_cb,
                          uint32_t finalists_cap, uint32_t row_base, void* d_result, hipStream_t s)
 {
-    // per-device attribute: set on every launch (cheap, idempotent)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSelectLds));
+    // per-device function attribute, set once per device
+    static bool attr_done[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSelectLds));
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
     hipLaunchKernelGGL(select_kernel, dim3(kSelectBlocks), dim3(kSelectThreads), kSelectLds, s, a, finalists,
                        finalists_cb, finalists_cap, row_base, d_result);
     return hipGetLastError();
