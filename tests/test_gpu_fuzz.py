@@ -30,12 +30,14 @@ def random_table(rng, n, W, style):
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_against_oracle(seed):
     rng = np.random.default_rng(0xF022 + seed)
-    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537, 262144 + 7, 524288 - 1]
+    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537, 262144 + 7, 524288 - 1, 524288 + 65, 1_200_003]
     for case in range(22):
         W = int(rng.choice([1, 3, 4, 8, 16, 32, 32, 32, 64, 64, 128]))
         n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(1, 300_000))
         if W >= 64:
             n = min(n, 120_000)
+        elif W != 32:
+            n = min(n, 600_000)
         style = str(rng.choice(["sparse", "dense", "ties"]))
         db = random_table(rng, n, W, style)
         t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
