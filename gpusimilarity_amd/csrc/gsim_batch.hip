@@ -46,13 +46,6 @@ struct BatchFilter {
     uint32_t stage_q[kScanBlock / 64][kBStage];
 };
 
-__device__ __forceinline__ uint32_t batch_bin(float s)
-{
-    const float t = fminf(fmaxf(s, 0.0f), 1.0f) * static_cast<float>(kBBins);
-    const uint32_t b = static_cast<uint32_t>(t);
-    return b < static_cast<uint32_t>(kBBins) ? b : static_cast<uint32_t>(kBBins - 1);
-}
-
 // push the un-pushed counts of query slot qs into its table-wide histogram; optionally
 // derive the threshold from it (one wavefront)
 __device__ __forceinline__ void batch_push(BatchFilter* sh, BatchQueryState* gq, int qs, uint32_t k, int lane,
@@ -460,7 +453,8 @@ __global__ __launch_bounds__(256) void batch_select_kernel(BatchArgs a, uint32_t
 }
 
 template <int WORDS, int RPL>
-hipError_t launch_batch_t(const BatchArgs& a, const ScanGeometry& g, uint32_t sample_chunks, hipStream_t s)
+hipError_t launch_batch_t(const BatchArgs& a, const ScanGeometry& g, uint32_t sample_chunks, hipStream_t s,
+                          bool sample_only)
 {
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
     const u64 nchunks = (a.nrows + 64 * RPL - 1) / (64 * RPL);
@@ -473,7 +467,49 @@ hipError_t launch_batch_t(const BatchArgs& a, const ScanGeometry& g, uint32_t sa
         hipLaunchKernelGGL((batch_scan_kernel<WORDS, RPL, true>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g,
                            static_cast<uint32_t>(want), (nchunks - 1) / want);
     }
+    if (sample_only) return hipGetLastError();
     hipLaunchKernelGGL((batch_scan_kernel<WORDS, RPL, false>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g, 0u, u64(0));
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_scan(const BatchArgs& a, const ScanGeometry& g, uint32_t sample_chunks, hipStream_t s,
+                             bool sample_only)
+{
+    static const int rpl_env = std::getenv("GSIM_BATCH_RPL") ? std::atoi(std::getenv("GSIM_BATCH_RPL")) : 0;
+    const int rpl = rpl_env ? rpl_env : (a.W >= 64 ? 1 : (a.W >= 32 ? 2 : 4)); // rows per lane (scripts/bench_batch.py)
+    switch (a.W) {
+    case 4: return launch_batch_t<4, 4>(a, g, sample_chunks, s, sample_only);
+    case 8: return launch_batch_t<8, 4>(a, g, sample_chunks, s, sample_only);
+    case 16:
+        return rpl == 1 ? launch_batch_t<16, 1>(a, g, sample_chunks, s, sample_only)
+                        : rpl == 2 ? launch_batch_t<16, 2>(a, g, sample_chunks, s, sample_only)
+                                   : launch_batch_t<16, 4>(a, g, sample_chunks, s, sample_only);
+    case 32:
+        return rpl == 1 ? launch_batch_t<32, 1>(a, g, sample_chunks, s, sample_only)
+                        : rpl == 2 ? launch_batch_t<32, 2>(a, g, sample_chunks, s, sample_only)
+                                   : launch_batch_t<32, 4>(a, g, sample_chunks, s, sample_only);
+    case 64:
+        return rpl == 2 ? launch_batch_t<64, 2>(a, g, sample_chunks, s, sample_only)
+                        : launch_batch_t<64, 1>(a, g, sample_chunks, s, sample_only);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// B* -> compact -> select for the a.nq queries from a.q0 whose candidates sit in nwaves segments.
+hipError_t launch_batch_finish(const BatchArgs& a, uint32_t nwaves, uint32_t row_base, void* results,
+                               size_t block_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(batch_bstar_kernel, dim3(a.nq), dim3(64), 0, s, a);
+    const uint32_t nblocks = nwaves / (kScanBlock / 64);
+    ScanGeometry g{};
+    g.nwaves = nwaves;
+    hipLaunchKernelGGL(batch_compact_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    const size_t lds = static_cast<size_t>(kSelectCap) * sizeof(u64);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch_select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(batch_select_kernel, dim3(kSelectCap / 256, a.nq), dim3(256), lds, s, a, row_base,
+                       reinterpret_cast<unsigned char*>(results), block_bytes);
     return hipGetLastError();
 }
 
@@ -488,28 +524,27 @@ bool batch_supported(uint32_t W)
 hipError_t launch_batch_pass(const BatchArgs& a, const BatchRare& /*rare_host*/, const ScanGeometry& g,
                              uint32_t sample_chunks, uint32_t row_base, void* results, size_t block_bytes, hipStream_t s)
 {
-    hipError_t e = hipErrorInvalidValue;
-    static const int rpl_env = std::getenv("GSIM_BATCH_RPL") ? std::atoi(std::getenv("GSIM_BATCH_RPL")) : 0;
-    const int rpl = rpl_env ? rpl_env : (a.W >= 64 ? 1 : (a.W >= 32 ? 2 : 4)); // rows per lane (scripts/bench_batch.py)
-    switch (a.W) {
-    case 4: e = launch_batch_t<4, 4>(a, g, sample_chunks, s); break;
-    case 8: e = launch_batch_t<8, 4>(a, g, sample_chunks, s); break;
-    case 16: e = rpl == 1 ? launch_batch_t<16, 1>(a, g, sample_chunks, s) : rpl == 2 ? launch_batch_t<16, 2>(a, g, sample_chunks, s) : launch_batch_t<16, 4>(a, g, sample_chunks, s); break;
-    case 32: e = rpl == 1 ? launch_batch_t<32, 1>(a, g, sample_chunks, s) : rpl == 2 ? launch_batch_t<32, 2>(a, g, sample_chunks, s) : launch_batch_t<32, 4>(a, g, sample_chunks, s); break;
-    case 64: e = rpl == 2 ? launch_batch_t<64, 2>(a, g, sample_chunks, s) : launch_batch_t<64, 1>(a, g, sample_chunks, s); break;
-    default: return hipErrorInvalidValue;
+    const hipError_t e = launch_batch_scan(a, g, sample_chunks, s, false);
+    if (e != hipSuccess) return e;
+    return launch_batch_finish(a, g.nwaves, row_base, results, block_bytes, s);
+}
+
+// The same pipeline with the scan on the matrix cores (gsim_batch_mfma.hip): sample passes per
+// kBQ queries (they set the starting thresholds), ONE contraction pass for all a.nq
+// (<= kMfmaQueries) queries, then B* / compact / select for all of them.
+hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,
+                                  uint32_t row_base, void* results, size_t block_bytes, hipStream_t s)
+{
+    for (uint32_t q0 = 0; q0 < a.nq; q0 += kBQ) {
+        BatchArgs as = a;
+        as.q0 = a.q0 + q0;
+        as.nq = a.nq - q0 < static_cast<uint32_t>(kBQ) ? a.nq - q0 : static_cast<uint32_t>(kBQ);
+        const hipError_t e = launch_batch_scan(as, g, sample_chunks, s, true);
+        if (e != hipSuccess) return e;
     }
+    const hipError_t e = launch_batch_mfma_scan(a, num_cus, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(batch_bstar_kernel, dim3(a.nq), dim3(64), 0, s, a);
-    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    hipLaunchKernelGGL(batch_compact_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
-    const size_t lds = static_cast<size_t>(kSelectCap) * sizeof(u64);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch_select_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(batch_select_kernel, dim3(kSelectCap / 256, a.nq), dim3(256), lds, s, a, row_base,
-                       reinterpret_cast<unsigned char*>(results), block_bytes);
-    return hipGetLastError();
+    return launch_batch_finish(a, batch_mfma_waves(num_cus), row_base, results, block_bytes, s);
 }
 
 } // namespace gsim

@@ -1,0 +1,402 @@
+// gsim_batch_mfma.hip -- the multi-query pass as a binary contraction on the matrix cores.
+//
+// With Q queries per table pass the intersection counts form a (Q x K) . (K x N) product of 0/1
+// matrices (K = fingerprint bits).  On the vector ALU that costs two instructions per 32-bit
+// word and (query, row) pair (gsim_batch.hip: 8 cycles per word-pair per SIMD, which IS the
+// VALU issue ceiling for v_and + v_bcnt); gfx950's block-scaled MFMA
+// (v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP4/E2M1) does 32 x 32 pairs x 64 bits per
+// instruction -- one eighth of the VALU time per bit -- and accumulates exactly in f32 (the
+// counts are < 2^24).  Only this Q >= 64 batch path uses it; the single-query scan stays a
+// streaming HBM-bound kernel.
+//
+// Packed bits -> FP4 operands with ONE v_and per operand dword (scripts/mfma_fp4_probe.hip):
+//   x & 0x11111111 -> nibbles {0, 0.5}    block scale 2^1
+//   x & 0x22222222 -> nibbles {0, 1.0}    block scale 2^0
+//   x & 0x44444444 -> nibbles {0, 2.0}    block scale 2^-1
+//   (x >> 3) & 0x11111111                 (0x8 is the FP4 sign bit: -0, so that class is shifted)
+// i.e. each 256-bit group of a row (8 words: 4 per lane half) feeds four MFMAs, one per class.
+// Which bit lands in which k slot is irrelevant as long as queries and rows use the same map.
+//
+// Work split: one 512-thread workgroup per CU; wave w owns query tile w (32 queries, the A
+// operand), expanded ONCE into registers (2 W VGPRs); all eight waves stream the same table
+// rows, staged through LDS in 16 KB blocks by global_load_lds (double-buffered, XOR-swizzled
+// so the per-lane 16-byte fragment reads are conflict-free).  Per (32 queries x 32 rows) tile:
+// W/2 MFMAs; the epilogue is a division-free linear pre-filter (2 VALU per pair: the candidate
+// condition score >= tau/kBBins is c >= ka[q] + kb[q] * popc(row), conservative by 2^-12), and
+// only tiles with a passing pair run the exact score / bin / emit path.  The streaming top-k
+// filter is the table-wide one of the other scans (per-query histogram + threshold, monotone),
+// kept in global memory here because emissions are rare after the sample pass.
+#include "gsim_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gpusim_hip.h"
+#include "gsim_device_common.h"
+
+namespace gsim
+{
+namespace
+{
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMWaves = 8;             // waves per workgroup = query tiles per pass
+constexpr int kMBlock = kMWaves * 64;  // threads
+constexpr int kMChunks = 4096;         // 16-byte chunks per LDS row block (64 KB, two buffers)
+constexpr int kMStage = 128;           // raw candidates staged per wave (processed in bulk above 64)
+
+constexpr int kScale1 = 0x80808080;  // E8M0 2^1
+constexpr int kScale0 = 0x7F7F7F7F;  // 2^0
+constexpr int kScaleM = 0x7E7E7E7E;  // 2^-1
+
+struct MfmaShared {
+    u32x4 rows[2][kMChunks];
+    float kap_a[kMWaves][2][16]; // pre-filter constants in accumulator order: [lane half][acc register]
+    float kap_b[kMWaves][2][16];
+    uint32_t tau[kMWaves][32];
+    uint32_t qpop[kMWaves][32];
+    uint32_t stage_row[kMWaves][kMStage]; // pairs that passed the pre-filter: row, (common << 16) + popc(row),
+    uint32_t stage_cb[kMWaves][kMStage];  // query of the tile -- scored exactly in bulk (drain_stage)
+    uint32_t stage_q[kMWaves][kMStage];
+};
+
+// The class masks are passed in VGPRs: v_and_b32 with two vector operands issues in 2 cycles,
+// with a literal or scalar operand in 4 (scripts/valu_op_rate_probe.hip).
+struct ClassMasks {
+    uint32_t m1, m2, m4;
+};
+
+template <int CLS> __device__ __forceinline__ v4i fp4_class(u32x4 x, const ClassMasks& k)
+{
+    if (CLS == 0) x = x & k.m1;
+    if (CLS == 1) x = x & k.m2;
+    if (CLS == 2) x = x & k.m4;
+    if (CLS == 3) x = (x >> 3) & k.m1;
+    return v4i{static_cast<int>(x.x), static_cast<int>(x.y), static_cast<int>(x.z), static_cast<int>(x.w)};
+}
+
+template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, u32x4 row, v16f acc, const ClassMasks& k)
+{
+    const v4i rb = fp4_class<CLS>(row, k);
+    const v8i A = {qa.x, qa.y, qa.z, qa.w, 0, 0, 0, 0};
+    const v8i B = {rb.x, rb.y, rb.z, rb.w, 0, 0, 0, 0};
+    constexpr int sc = CLS == 1 ? kScale0 : (CLS == 2 ? kScaleM : kScale1);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, /*A fp4*/ 4, /*B fp4*/ 4, 0, sc, 0, sc);
+}
+
+// c >= ka + kb * popc(row) is implied by bin(score) >= tau (see the file header); tau == 0,
+// exotic weights or an ill-conditioned bound switch the pre-filter off (everything passes).
+__device__ __forceinline__ void prefilter_constants(int metric, float alpha, float beta, uint32_t qa, uint32_t tau,
+                                                    bool valid, float& ka, float& kb)
+{
+    ka = 0.0f;
+    kb = 0.0f;
+    if (!valid) { // padding query of the last tile: never a candidate
+        ka = 3.0e38f;
+        return;
+    }
+    const float al = metric == GSIM_METRIC_TVERSKY ? alpha : 1.0f;
+    const float be = metric == GSIM_METRIC_TVERSKY ? beta : 1.0f;
+    const float T = static_cast<float>(tau) * (1.0f / kBBins);
+    const float D = 1.0f - T * (1.0f - al - be);
+    if (tau == 0 || !(al >= 0.0f) || !(be >= 0.0f) || !(D > 0.05f)) return;
+    const float f = T / D * (1.0f - 0.000244140625f); // (1 - 2^-12)
+    ka = f * al * static_cast<float>(qa);
+    kb = f * be;
+}
+
+template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
+{
+    constexpr int KG = WORDS / 8;       // 256-bit groups per row
+    constexpr int CPR = WORDS / 4;      // 16-byte chunks per row
+    constexpr int RPLN = 16 / CPR;      // rows per 256-byte LDS line
+    constexpr int RB = kMChunks / CPR;  // rows per LDS block
+    constexpr int NTB = RB / 32;        // 32-row tiles per block
+    static_assert(WORDS % 8 == 0 && CPR <= 16 && NTB >= 2 && NTB % 2 == 0, "unsupported row width");
+    __shared__ MfmaShared sh;
+
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const uint32_t w = blockIdx.x * kMWaves + wq; // candidate segment of this wave
+    const int nq = static_cast<int>(a.nq);
+    const bool wave_has_queries = wq * 32 < nq;
+    // The rare arguments once, into scalar registers; device pointers carry the global address
+    // space so that stores and atomics are global_* instructions (a flat_* access may alias LDS and
+    // would have to wait for the row block in flight to LDS).
+    typedef __attribute__((address_space(1))) u64* g_u64p;
+    typedef __attribute__((address_space(1))) uint32_t* g_u32p;
+    const BatchRare rr = *a.rare;
+    BatchQueryState* qstate = rr.qstate + a.q0;
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+
+    // ---- A operand: this wave's 32 queries, expanded once ----------------------------------
+    ClassMasks km{0x11111111u, 0x22222222u, 0x44444444u};
+    asm volatile("" : "+v"(km.m1), "+v"(km.m2), "+v"(km.m4)); // keep them in VGPRs
+    v4i aexp[KG][4];
+    {
+        const int ql = wq * 32 + i;
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.queries + static_cast<size_t>(a.q0 + ql) * WORDS);
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const u32x4 x = ql < nq ? qp[2 * g + h] : u32x4{0, 0, 0, 0};
+            aexp[g][0] = fp4_class<0>(x, km);
+            aexp[g][1] = fp4_class<1>(x, km);
+            aexp[g][2] = fp4_class<2>(x, km);
+            aexp[g][3] = fp4_class<3>(x, km);
+        }
+    }
+    // per-query constants of this wave (wave-private LDS: no workgroup barrier needed)
+    auto set_query_constants = [&](uint32_t tau) { // lanes 0..31: query i of the tile
+        const bool valid = wq * 32 + i < nq;
+        float ka, kb;
+        prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][i], tau, valid, ka, kb);
+        const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i
+        sh.kap_a[wq][hh][r] = ka;
+        sh.kap_b[wq][hh][r] = kb;
+        sh.tau[wq][i] = tau;
+    };
+    if (lane < 32) {
+        const bool valid = wq * 32 + i < nq;
+        sh.qpop[wq][i] = valid ? a.qpop[a.q0 + wq * 32 + i] : 0u;
+        set_query_constants(valid ? *((g_u32p) &qstate[wq * 32 + i].gtau) : static_cast<uint32_t>(kBBins));
+    }
+
+    // ---- candidate staging (as in batch_scan_kernel) ---------------------------------------
+    const u64 seg_off = static_cast<u64>(w) * rr.seg_cap;
+    const g_u64p seg_key = (g_u64p) (rr.cand + seg_off);
+    const g_u32p seg_cb = (g_u32p) (rr.cand_cb + seg_off);
+    const g_u32p seg_q = (g_u32p) (rr.cand_q + seg_off);
+    uint32_t cursor = 0, staged = 0;
+    uint32_t* stg_row = sh.stage_row[wq];
+    uint32_t* stg_cb = sh.stage_cb[wq];
+    uint32_t* stg_q = sh.stage_q[wq];
+    // Exact scores of the staged pairs, 64 at a time: the survivors of the current thresholds go to
+    // this wave's candidate segment and into the table-wide histograms.  Done in bulk because every
+    // global access here is followed, at the end of the row block, by a wait of the whole workgroup.
+    auto drain_stage = [&]() {
+        for (uint32_t s0 = 0; s0 < staged; s0 += 64) {
+            const uint32_t e = s0 + lane;
+            const bool have = e < staged;
+            const uint32_t row = have ? stg_row[e] : 0u;
+            const uint32_t cb = have ? stg_cb[e] : 0u;
+            const uint32_t qi = have ? stg_q[e] : 0u;
+            float sc = score_of(a.metric, a.alpha, a.beta, sh.qpop[wq][qi], cb & 0xFFFFu, cb >> 16);
+            sc = apply_cutoff(sc, a.cutoff);
+            const uint32_t bin = batch_bin(sc);
+            const bool cand = have && bin >= sh.tau[wq][qi];
+            const u64 mc = __ballot(cand);
+            if (cand) {
+                const uint32_t pos = cursor + lane_rank(mc);
+                if (pos < rr.seg_cap) {
+                    seg_key[pos] = make_key(sc, row);
+                    seg_cb[pos] = cb;
+                    seg_q[pos] = static_cast<uint32_t>(wq * 32) + qi;
+                }
+                // no return value: fire and forget
+                __hip_atomic_fetch_add((g_u32p) &qstate[wq * 32 + qi].ghist[bin], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            cursor += static_cast<uint32_t>(__popcll(mc));
+        }
+        staged = 0;
+    };
+
+    // ---- row block staging: global -> LDS, swizzled ----------------------------------------
+    auto issue_block = [&](u64 blk, int buf) {
+#pragma unroll
+        for (int j = 0; j < kMChunks / kMBlock; j++) {
+            const int first = (j * kMWaves + wq) * 64; // LDS chunk of lane 0 (wave-uniform)
+            const int p = first + lane;
+            const int line = p >> 4, slot = p & 15;
+            const int rowl = line * RPLN + slot / CPR;
+            const int c = (slot % CPR) ^ (line % CPR);
+            u64 grow = blk * RB + rowl;
+            if (grow >= a.nrows) grow = a.nrows - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (db + grow * CPR + c),
+                                             (__attribute__((address_space(3))) void*) (&sh.rows[buf][first]), 16, 0, 0);
+        }
+    };
+
+    u64 blk = blockIdx.x;
+    int buf = 0;
+    if (blk < nblocks) issue_block(blk, 0);
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
+
+    constexpr int PER = kBBins / 64; // histogram bins per lane in a threshold update
+    uint32_t turn = blockIdx.x;      // rotates the query whose threshold this wave refreshes
+    for (; blk < nblocks; blk += gridDim.x, buf ^= 1, turn++) {
+        const u64 next = blk + gridDim.x;
+        if (next < nblocks) issue_block(next, buf ^ 1);
+        // Threshold upkeep, software-pipelined around the block (the loads are consumed after the
+        // tiles): (1) poll the table-wide thresholds of this wave's 32 queries; (2) one query per
+        // block, in rotation (staggered over the workgroups), gets its threshold recomputed from the
+        // table-wide histogram of emitted rows.  All updates are monotone (atomicMax).
+        uint32_t gt = 0;
+        uint32_t hh[PER];
+        const int qref = wq * 32 + static_cast<int>(turn & 31u);
+        const bool refresh = wave_has_queries && qref < nq;
+        if (wave_has_queries && lane < 32 && wq * 32 + lane < nq)
+            gt = __hip_atomic_load((g_u32p) &qstate[wq * 32 + lane].gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (refresh) {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(qstate[qref].ghist, 0, kBBins * 4, 0x00020000);
+#pragma unroll
+            for (int v = 0; v < PER / 4; v++) {
+                const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * PER * 4 + v * 16, 0, /*sc1*/ 16);
+                hh[4 * v + 0] = v4.x;
+                hh[4 * v + 1] = v4.y;
+                hh[4 * v + 2] = v4.z;
+                hh[4 * v + 3] = v4.w;
+            }
+        }
+
+        if (wave_has_queries) {
+#pragma unroll 1
+            for (int t2 = 0; t2 < NTB; t2 += 2) {
+                v16f acc0 = {}, acc1 = {};
+                uint32_t pb0 = 0, pb1 = 0;
+                const int row0 = t2 * 32 + i, row1 = row0 + 32;
+                const int line0 = row0 / RPLN, line1 = row1 / RPLN;
+                const u32x4* l0 = &sh.rows[buf][line0 * 16 + (row0 % RPLN) * CPR];
+                const u32x4* l1 = &sh.rows[buf][line1 * 16 + (row1 % RPLN) * CPR];
+                const int x0 = line0 % CPR, x1 = line1 % CPR;
+#pragma unroll
+                for (int g = 0; g < KG; g++) {
+                    const u32x4 b0 = l0[(2 * g + h) ^ x0];
+                    const u32x4 b1 = l1[(2 * g + h) ^ x1];
+                    pb0 = bcnt_acc(b0.x, pb0);
+                    pb0 = bcnt_acc(b0.y, pb0);
+                    pb0 = bcnt_acc(b0.z, pb0);
+                    pb0 = bcnt_acc(b0.w, pb0);
+                    pb1 = bcnt_acc(b1.x, pb1);
+                    pb1 = bcnt_acc(b1.y, pb1);
+                    pb1 = bcnt_acc(b1.z, pb1);
+                    pb1 = bcnt_acc(b1.w, pb1);
+                    acc0 = mfma_class<0>(aexp[g][0], b0, acc0, km);
+                    acc1 = mfma_class<0>(aexp[g][0], b1, acc1, km);
+                    acc0 = mfma_class<1>(aexp[g][1], b0, acc0, km);
+                    acc1 = mfma_class<1>(aexp[g][1], b1, acc1, km);
+                    acc0 = mfma_class<2>(aexp[g][2], b0, acc0, km);
+                    acc1 = mfma_class<2>(aexp[g][2], b1, acc1, km);
+                    acc0 = mfma_class<3>(aexp[g][3], b0, acc0, km);
+                    acc1 = mfma_class<3>(aexp[g][3], b1, acc1, km);
+                }
+                pb0 += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb0), 32, 64));
+                pb1 += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb1), 32, 64));
+
+                // ---- epilogue: linear pre-filter, exact path only for tiles with a passing pair ----
+                const f32x4* kap = reinterpret_cast<const f32x4*>(sh.kap_a[wq][h]);
+                const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][h]);
+                const float pbf0 = static_cast<float>(pb0), pbf1 = static_cast<float>(pb1);
+                const u64 rowi0 = blk * RB + t2 * 32 + i, rowi1 = rowi0 + 32;
+                // which accumulator registers hold a passing pair (bit r: tile 0, bit 16 + r: tile 1)
+                uint32_t rmask = 0;
+                {
+                    u64 m0 = 0, m1 = 0;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const f32x4 va = kap[r4], vb = kbp[r4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            m0 |= __ballot(acc0[4 * r4 + e] >= __builtin_fmaf(vb[e], pbf0, va[e]));
+                            m1 |= __ballot(acc1[4 * r4 + e] >= __builtin_fmaf(vb[e], pbf1, va[e]));
+                        }
+                    }
+                    m0 &= __ballot(rowi0 < a.nrows);
+                    m1 &= __ballot(rowi1 < a.nrows);
+                    if ((m0 | m1) != 0) {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const f32x4 va = kap[r4], vb = kbp[r4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int r = 4 * r4 + e;
+                                if (m0 & __ballot(acc0[r] >= __builtin_fmaf(vb[e], pbf0, va[e]))) rmask |= 1u << r;
+                                if (m1 & __ballot(acc1[r] >= __builtin_fmaf(vb[e], pbf1, va[e]))) rmask |= 1u << (16 + r);
+                            }
+                        }
+                    }
+                }
+                // rare: stage the pairs that passed
+                while (rmask) {
+                    const int bit = __builtin_ctz(rmask);
+                    rmask &= rmask - 1;
+                    const int r = bit & 15;
+                    const bool second = bit >= 16;
+                    const float cf = second ? acc1[r] : acc0[r];
+                    const uint32_t pb = second ? pb1 : pb0;
+                    const u64 rowi = second ? rowi1 : rowi0;
+                    const bool pass = rowi < a.nrows &&
+                                      cf >= __builtin_fmaf(sh.kap_b[wq][h][r], static_cast<float>(pb), sh.kap_a[wq][h][r]);
+                    const u64 mp = __ballot(pass);
+                    if (pass) {
+                        const uint32_t slot = staged + lane_rank(mp);
+                        stg_row[slot] = static_cast<uint32_t>(rowi);
+                        stg_cb[slot] = (static_cast<uint32_t>(cf) << 16) + pb;
+                        stg_q[slot] = static_cast<uint32_t>((r & 3) + 8 * (r >> 2) + 4 * h); // query of the tile
+                    }
+                    staged += static_cast<uint32_t>(__popcll(mp));
+                    if (staged > 64) drain_stage();
+                }
+            }
+            if (refresh) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int v = 0; v < PER; v++) sum += hh[v];
+                uint32_t bin_k, cnt;
+                threshold_from_counts<PER>(hh, sum, a.k, lane, bin_k, cnt);
+                bin_k = __builtin_amdgcn_readfirstlane(bin_k);
+                cnt = __builtin_amdgcn_readfirstlane(cnt);
+                if (cnt >= a.k) {
+                    if (lane == 0)
+                        __hip_atomic_fetch_max((g_u32p) &qstate[qref].gtau, bin_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == (qref & 31) && bin_k > gt) gt = bin_k;
+                }
+            }
+            if (lane < 32 && gt > sh.tau[wq][lane]) set_query_constants(gt);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+    }
+    if (staged) drain_stage();
+    if (lane == 0) {
+        rr.seg_count[w] = cursor < rr.seg_cap ? cursor : rr.seg_cap;
+        if (cursor > rr.seg_cap) atomicOr(rr.flags, 1u); // segment overflow: the host falls back
+    }
+}
+
+} // namespace
+
+bool batch_mfma_supported(uint32_t W)
+{
+    return W == 32 || W == 64;
+}
+
+uint32_t batch_mfma_waves(int num_cus)
+{
+    return static_cast<uint32_t>(num_cus) * kMWaves;
+}
+
+// The scan of one pass (a.nq <= kMfmaQueries queries from a.q0) for cutoff <= 0; thresholds come
+// from the sample passes launched before it, finish with launch_batch_finish.
+hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s)
+{
+    if (a.nq > static_cast<uint32_t>(kMfmaQueries) || a.cutoff > 0.0f || a.nrows == 0) return hipErrorInvalidValue;
+    if (a.W == 64) {
+        const u64 nblocks = (a.nrows + (kMChunks / 16) - 1) / (kMChunks / 16);
+        hipLaunchKernelGGL((batch_mfma_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+    } else if (a.W == 32) {
+        const u64 nblocks = (a.nrows + (kMChunks / 8) - 1) / (kMChunks / 8);
+        hipLaunchKernelGGL((batch_mfma_kernel<32>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace gsim

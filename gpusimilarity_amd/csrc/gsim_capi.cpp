@@ -438,6 +438,12 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         // else 64 Ki entries; a wave that needs more sets the overflow flag and the host falls back
         const uint64_t rows_per_wave = ((nchunks + nw - 1) / nw) * 64 + 256; // chunks are 64 x (1..4) rows
         uint64_t cap = rows_per_wave * gsim::kBQ;
+        // a wave of the matrix-core pass meets 32 queries and every row of its workgroup
+        const uint64_t mfma_waves = gsim::batch_mfma_waves(s.num_cus);
+        if (gsim::batch_mfma_supported(s.W)) {
+            cap = std::max<uint64_t>(cap, (s.nrows / static_cast<uint64_t>(s.num_cus) + 512) * 32);
+            nw = std::max<uint64_t>(nw, mfma_waves);
+        }
         const uint64_t lim = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP", 65536));
         if (cap > lim) cap = lim;
         if (cap < 256) cap = 256;
@@ -511,6 +517,18 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     a.alpha = alpha;
     a.beta = beta;
     const uint32_t sample = static_cast<uint32_t>(env_int("GSIM_BATCH_SAMPLE_CHUNKS", 8));
+    // enough queries to fill matrix-core tiles: one contraction pass for all of them
+    // (gsim_batch_mfma.hip); counts of rows above a cutoff are only kept by the VALU pass
+    static const int mfma_min_q = env_int("GSIM_BATCH_MFMA_MIN_Q", 64);
+    if (mfma_min_q > 0 && nq >= static_cast<uint32_t>(mfma_min_q) && nq <= static_cast<uint32_t>(gsim::kMfmaQueries) &&
+        !(cutoff > 0.0f) && gsim::batch_mfma_supported(s.W)) {
+        a.q0 = 0;
+        a.nq = nq;
+        GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, s.h_bresult,
+                                              gsim_result_block_bytes(k), s.stream));
+        GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 16, hipMemcpyDeviceToHost, s.stream));
+        return GSIM_OK;
+    }
     for (uint32_t q0 = 0; q0 < nq; q0 += gsim::kBQ) {
         a.q0 = q0;
         a.nq = std::min<uint32_t>(gsim::kBQ, nq - q0);
@@ -1018,6 +1036,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                 rc = wait_stream(s.stream);
                 if (rc != GSIM_OK) return rc;
                 if (s.h_bflags[0] & 1u) overflow = true;
+                if (std::getenv("GSIM_DEBUG_BATCH")) std::fprintf(stderr, "batch flags %u slow visits %u bits %u\n", s.h_bflags[0], s.h_bflags[2], s.h_bflags[3]);
             }
             for (uint32_t q = 0; q < nb; q++) {
                 uint64_t ap = 0;

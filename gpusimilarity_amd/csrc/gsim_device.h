@@ -97,7 +97,7 @@ struct BatchQueryState { // one per query of a batch, device memory, zeroed befo
     uint32_t gtau;
     uint32_t nfinal;
     uint32_t bstar;
-    uint32_t pad;
+    uint32_t pad;             // matrix-core pass: candidates emitted so far (threshold update trigger)
     unsigned long long kept;
 };
 
@@ -124,7 +124,7 @@ struct BatchArgs {
     const uint32_t* qpop;    // device, Q
     const BatchRare* rare;   // device copy of the rare arguments
     uint32_t W;
-    uint32_t q0, nq;         // this pass: queries q0 .. q0+nq-1, nq <= kBQ
+    uint32_t q0, nq;         // this pass: queries q0 .. q0+nq-1 (nq <= kBQ, matrix-core pass: kMfmaQueries)
     uint32_t k;
     float cutoff;
     int metric;
@@ -135,6 +135,14 @@ bool batch_supported(uint32_t W);
 hipError_t launch_batch_pass(const BatchArgs& a, const BatchRare& rare_host, const ScanGeometry& g,
                              uint32_t sample_chunks, uint32_t row_base, void* results, size_t block_bytes,
                              hipStream_t s);
+
+// Matrix-core variant of the scan (gsim_batch_mfma.hip): up to kMfmaQueries queries per table pass.
+constexpr int kMfmaQueries = 256;
+bool batch_mfma_supported(uint32_t W);
+uint32_t batch_mfma_waves(int num_cus);
+hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,
+                                  uint32_t row_base, void* results, size_t block_bytes, hipStream_t s);
 
 hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows,
                            uint32_t W, hipStream_t s);

@@ -54,6 +54,14 @@ __device__ __forceinline__ uint32_t coarse_bin(float s)
     return b < static_cast<uint32_t>(kScanBins) ? b : static_cast<uint32_t>(kScanBins - 1);
 }
 
+// Coarse bin of the multi-query passes (kBBins bins; gsim_batch.hip, gsim_batch_mfma.hip).
+__device__ __forceinline__ uint32_t batch_bin(float s)
+{
+    const float t = fminf(fmaxf(s, 0.0f), 1.0f) * static_cast<float>(kBBins);
+    const uint32_t b = static_cast<uint32_t>(t);
+    return b < static_cast<uint32_t>(kBBins) ? b : static_cast<uint32_t>(kBBins - 1);
+}
+
 // The reference's arithmetic, fingerprintdb_cuda.cu:89-101:
 //   score = (float)common / (float)(total - common), total = popc(q) + popc(d)
 // one correctly rounded IEEE f32 divide.  Tversky (build-defined; oracle
