@@ -265,10 +265,26 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 const u32x4* l0 = &sh.rows[buf][line0 * 16 + (row0 % RPLN) * CPR];
                 const u32x4* l1 = &sh.rows[buf][line1 * 16 + (row1 % RPLN) * CPR];
                 const int x0 = line0 % CPR, x1 = line1 % CPR;
+                // Row fragments are read from LDS one 256-bit group ahead of their use.  Hand-issued
+                // (hipcc sinks such reads next to their use and waits with lgkmcnt(0)): LDS returns in
+                // order, so lgkmcnt(2) leaves exactly the two prefetched reads in flight.
+                const uint32_t base0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+                    (__attribute__((address_space(3))) const u32x4*) l0));
+                const uint32_t base1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+                    (__attribute__((address_space(3))) const u32x4*) l1));
+                u32x4 nb0, nb1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(nb0) : "v"(base0 + ((h ^ x0) << 4)));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(nb1) : "v"(base1 + ((h ^ x1) << 4)));
 #pragma unroll
                 for (int g = 0; g < KG; g++) {
-                    const u32x4 b0 = l0[(2 * g + h) ^ x0];
-                    const u32x4 b1 = l1[(2 * g + h) ^ x1];
+                    u32x4 b0 = nb0, b1 = nb1;
+                    if (g + 1 < KG) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nb0) : "v"(base0 + (((2 * (g + 1) + h) ^ x0) << 4)));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nb1) : "v"(base1 + (((2 * (g + 1) + h) ^ x1) << 4)));
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0), "+v"(b1));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1));
+                    }
                     pb0 = bcnt_acc(b0.x, pb0);
                     pb0 = bcnt_acc(b0.y, pb0);
                     pb0 = bcnt_acc(b0.z, pb0);

@@ -58,3 +58,32 @@ def test_fuzz_against_oracle(seed):
                 assert int(approx[i]) == wap, ctx
                 assert hits_equal(hits[i], want), ctx
         t.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_large_batches_against_oracle(seed):
+    """Batches of 64..200 queries (the matrix-core pass for 1024/2048-bit rows and cutoff <= 0, the
+    VALU pass otherwise), random table shapes, metrics and k."""
+    rng = np.random.default_rng(0xBA7C4 + seed)
+    for case in range(8):
+        W = int(rng.choice([32, 64, 32, 64, 16]))
+        n = int(rng.choice([1, 33, 255, 256, 257, 511, 513, 4097, 50_000, 100_003]))
+        style = str(rng.choice(["sparse", "dense", "ties"]))
+        db = random_table(rng, n, W, style)
+        t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
+        k = int(rng.choice([1, 10, 100, 1000, n + 1]))
+        cutoff = float(rng.choice([0.0, 0.0, 0.0, -1.0, 0.1]))
+        metric = int(rng.choice([0, 1]))
+        al, be = (np.float32(rng.choice([0.0, 0.3, 1.0])), np.float32(rng.choice([0.7, 0.5, 1.0])))
+        nq = int(rng.integers(64, 201))
+        qs = np.stack([db[rng.integers(0, n)] if rng.random() < 0.7 else
+                       O.synth_rows(int(rng.integers(1, 2**31)), int(rng.integers(0, 2)), 0, 1, W)[0] for _ in range(nq)])
+        kw = dict(metric=metric, alpha=al, beta=be) if metric else {}
+        hits, approx = t.search(qs, k, np.float32(cutoff), **kw)
+        for i in range(nq):
+            want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=4, **kw)
+            ctx = "seed=%d case=%d W=%d n=%d style=%s k=%d cutoff=%g metric=%d (%g,%g) nq=%d q=%d" % (
+                seed, case, W, n, style, k, cutoff, metric, al, be, nq, i)
+            assert int(approx[i]) == wap, ctx
+            assert hits_equal(hits[i], want), ctx
+        t.close()

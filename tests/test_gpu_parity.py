@@ -540,3 +540,85 @@ def test_multi_query_pass_fallbacks():
         t2.close()
     finally:
         del os.environ["GSIM_BATCH_SEG_CAP"]
+
+
+# ---------------------------------------------------------------------------
+# multi-query pass on the matrix cores (gsim_batch_mfma.hip): >= 64 queries, cutoff <= 0,
+# 1024- and 2048-bit rows
+# ---------------------------------------------------------------------------
+
+def _mixed_queries(db, kind, nq, W):
+    n = len(db)
+    own = [db[O.query_row(i, n)] for i in range(nq - nq // 4)]
+    fresh = [O.synth_rows(0x5EED0002, kind, 500 + i, 1, W)[0] for i in range(nq // 4)]
+    return np.stack(own + fresh)
+
+
+@pytest.mark.parametrize("W,kind,n,nq", [(64, 0, 130_001, 256), (32, 0, 90_000, 97), (32, 1, 70_003, 64),
+                                         (64, 1, 40_000, 130), (32, 0, 31, 64), (64, 0, 257, 65)])
+def test_matrix_core_pass_matches_oracle(W, kind, n, nq):
+    """Every query of a 64..256-query batch: rows, score bits, popcounts and approx identical to the
+    oracle -- ragged table sizes (not a multiple of the 256/512-row LDS blocks, smaller than one
+    tile), query counts that leave padding slots in the last 32-query tile."""
+    db = O.synth_rows(0x3FA4 + W + n, kind, 0, n, W)
+    t = make_table(db)
+    qs = _mixed_queries(db, kind, nq, W)
+    batch_check(t, db, qs, 100, 0.0, ctx="mfma W=%d n=%d nq=%d" % (W, n, nq))
+    batch_check(t, db, qs[:64], 1000, -1.0, ctx="mfma k=1000 W=%d n=%d" % (W, n))
+    batch_check(t, db, qs, 7, 0.0, ctx="mfma tversky W=%d n=%d" % (W, n), metric=capi.METRIC_TVERSKY,
+                alpha=np.float32(0.3), beta=np.float32(0.7))
+    t.close()
+
+
+def test_matrix_core_pass_tversky_weight_corners():
+    """Weights for which the linear pre-filter is switched off or ill-conditioned (alpha = beta = 0,
+    alpha + beta << 1) and asymmetric ones: the exact path decides, results equal the oracle."""
+    n, W = 20_000, 32
+    db = O.synth_rows(0xC0A7, 0, 0, n, W)
+    t = make_table(db)
+    qs = _mixed_queries(db, 0, 64, W)
+    for al, be in [(0.0, 0.0), (0.01, 0.02), (1.0, 0.0), (0.0, 1.0), (2.0, 0.5), (1.0, 1.0)]:
+        batch_check(t, db, qs, 50, 0.0, ctx="mfma tversky(%g,%g)" % (al, be), metric=capi.METRIC_TVERSKY,
+                    alpha=np.float32(al), beta=np.float32(be))
+    t.close()
+
+
+def test_matrix_core_pass_ties_and_fallbacks():
+    """Heavy ties (> SELECT_CAP finalists) and candidate-segment overflow on the matrix-core pass:
+    flagged queries are re-run through the single-query path."""
+    base = O.synth_rows(0x71E6, 0, 0, 5, 64)
+    base[4] = 0
+    n = 60_000
+    rng = np.random.default_rng(5)
+    db = np.ascontiguousarray(base[rng.integers(0, 5, size=n)])
+    t = make_table(db)
+    qs = np.stack([base[i % 5] for i in range(64)])
+    batch_check(t, db, qs, 40, 0.0, ctx="mfma heavy ties")
+    t.close()
+    os.environ["GSIM_BATCH_SEG_CAP"] = "256"
+    try:
+        db2 = O.synth_rows(0x0F11, 0, 0, 200_000, 32)
+        t2 = make_table(db2)
+        qs2 = _mixed_queries(db2, 0, 64, 32)
+        batch_check(t2, db2, qs2, 200, 0.0, ctx="mfma overflow fallback")
+        t2.close()
+    finally:
+        del os.environ["GSIM_BATCH_SEG_CAP"]
+
+
+def test_matrix_core_pass_large_table_with_sampling():
+    """4 M rows x 1024 bit, 128 queries: sample passes set the starting thresholds, the contraction
+    pass raises them while it streams; spot-checked against the oracle, every self hit present."""
+    n, W, nq = 4_000_000, 32, 128
+    t = capi.Table(W * 32)
+    t.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
+    db = O.synth_rows(0x5EED0001, 0, 0, n, W)
+    qs = np.stack([db[O.query_row(i, n)] for i in range(nq)])
+    hits, approx = t.search(qs, 1000, 0.0)
+    for i in range(nq):
+        assert int(approx[i]) == n
+        assert int(hits[i]["row"][0]) == O.query_row(i, n) and hits[i]["score"][0] == 1.0
+    for i in (0, 31, 32, 77, 127):
+        want, _ = O.search(qs[i], db, 1000, 0.0, nthreads=8)
+        assert_hits_equal(hits[i], want, "4M x 1024-bit q=%d" % i)
+    t.close()
