@@ -48,6 +48,19 @@ constexpr int kMBlock = kMWaves * 64;  // threads
 constexpr int kMChunks = 4096;         // 16-byte chunks per LDS row block (64 KB, two buffers)
 constexpr int kMStage = 128;           // raw candidates staged per wave (processed in bulk above 64)
 
+// GSIM_MF_TIMING: per-phase cycle counters of wave 0 of every workgroup, summed into flags[2..]
+// (units of 64 cycles; printed by the host under GSIM_DEBUG_BATCH)
+#ifndef GSIM_MF_TIMING
+#define GSIM_MF_TIMING 0
+#endif
+#if GSIM_MF_TIMING
+#define MF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define MF_ACC(slot, t0, t1) tacc[slot] += (t1) - (t0)
+#else
+#define MF_T(var)
+#define MF_ACC(slot, t0, t1)
+#endif
+
 constexpr int kScale1 = 0x80808080;  // E8M0 2^1
 constexpr int kScale0 = 0x7F7F7F7F;  // 2^0
 constexpr int kScaleM = 0x7E7E7E7E;  // 2^-1
@@ -69,18 +82,20 @@ struct ClassMasks {
     uint32_t m1, m2, m4;
 };
 
-template <int CLS> __device__ __forceinline__ v4i fp4_class(u32x4 x, const ClassMasks& k)
+template <int CLS> __device__ __forceinline__ uint32_t fp4_word(uint32_t x, const ClassMasks& k)
 {
-    if (CLS == 0) x = x & k.m1;
-    if (CLS == 1) x = x & k.m2;
-    if (CLS == 2) x = x & k.m4;
-    if (CLS == 3) x = (x >> 3) & k.m1;
-    return v4i{static_cast<int>(x.x), static_cast<int>(x.y), static_cast<int>(x.z), static_cast<int>(x.w)};
+    return CLS == 0 ? (x & k.m1) : CLS == 1 ? (x & k.m2) : CLS == 2 ? (x & k.m4) : ((x >> 3) & k.m1);
 }
 
-template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, u32x4 row, v16f acc, const ClassMasks& k)
+// element by element: a vector AND with a splat mask makes hipcc keep four copies of every mask
+template <int CLS> __device__ __forceinline__ v4i fp4_class(u32x4 x, const ClassMasks& k)
 {
-    const v4i rb = fp4_class<CLS>(row, k);
+    return v4i{static_cast<int>(fp4_word<CLS>(x.x, k)), static_cast<int>(fp4_word<CLS>(x.y, k)),
+               static_cast<int>(fp4_word<CLS>(x.z, k)), static_cast<int>(fp4_word<CLS>(x.w, k))};
+}
+
+template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, v4i rb, v16f acc)
+{
     const v8i A = {qa.x, qa.y, qa.z, qa.w, 0, 0, 0, 0};
     const v8i B = {rb.x, rb.y, rb.z, rb.w, 0, 0, 0, 0};
     constexpr int sc = CLS == 1 ? kScale0 : (CLS == 2 ? kScaleM : kScale1);
@@ -206,18 +221,24 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     };
 
     // ---- row block staging: global -> LDS, swizzled ----------------------------------------
+    // LDS chunk p of a block (p = (j * 8 + wave) * 64 + lane for the wave's j-th load) holds chunk
+    // c = (p % CPR') ^ swizzle of row p / CPR'; both the row offset inside a load group and c are the
+    // same for every j, so a lane keeps two values and does 32-bit row arithmetic per load (rows per
+    // device < 2^31).
+    constexpr int RPJ = kMBlock / CPR; // rows covered by one load of the whole workgroup
+    const int line0 = wq * 4 + (lane >> 4);
+    const uint32_t rowl0 = static_cast<uint32_t>(line0 * RPLN + (lane & 15) / CPR);
+    const uint32_t chunk0 = static_cast<uint32_t>(((lane & 15) % CPR) ^ (line0 % CPR));
+    const u32x4* dbc = db + chunk0;
+    const uint32_t last_row = static_cast<uint32_t>(a.nrows - 1);
     auto issue_block = [&](u64 blk, int buf) {
+        const uint32_t first = static_cast<uint32_t>(blk) * RB + rowl0;
 #pragma unroll
         for (int j = 0; j < kMChunks / kMBlock; j++) {
-            const int first = (j * kMWaves + wq) * 64; // LDS chunk of lane 0 (wave-uniform)
-            const int p = first + lane;
-            const int line = p >> 4, slot = p & 15;
-            const int rowl = line * RPLN + slot / CPR;
-            const int c = (slot % CPR) ^ (line % CPR);
-            u64 grow = blk * RB + rowl;
-            if (grow >= a.nrows) grow = a.nrows - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (db + grow * CPR + c),
-                                             (__attribute__((address_space(3))) void*) (&sh.rows[buf][first]), 16, 0, 0);
+            uint32_t grow = first + j * RPJ;
+            grow = grow < last_row ? grow : last_row;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (dbc + static_cast<u64>(grow) * CPR),
+                                             (__attribute__((address_space(3))) void*) (&sh.rows[buf][(j * kMWaves + wq) * 64]), 16, 0, 0);
         }
     };
 
@@ -227,37 +248,30 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) lgkmcnt(0)
     __syncthreads();
 
+#if GSIM_MF_TIMING
+    unsigned long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     constexpr int PER = kBBins / 64; // histogram bins per lane in a threshold update
     uint32_t turn = blockIdx.x;      // rotates the query whose threshold this wave refreshes
     for (; blk < nblocks; blk += gridDim.x, buf ^= 1, turn++) {
+        MF_T(tb0);
         const u64 next = blk + gridDim.x;
         if (next < nblocks) issue_block(next, buf ^ 1);
-        // Threshold upkeep, software-pipelined around the block (the loads are consumed after the
-        // tiles): (1) poll the table-wide thresholds of this wave's 32 queries; (2) one query per
-        // block, in rotation (staggered over the workgroups), gets its threshold recomputed from the
-        // table-wide histogram of emitted rows.  All updates are monotone (atomicMax).
+        // Threshold upkeep: (1) poll the table-wide thresholds of this wave's 32 queries (loaded
+        // here, consumed after the tiles); (2) every fourth block one query, in rotation (staggered
+        // over the workgroups), gets its threshold recomputed from the table-wide histogram of
+        // emitted rows.  All updates are monotone (atomicMax).
         uint32_t gt = 0;
-        uint32_t hh[PER];
-        const int qref = wq * 32 + static_cast<int>(turn & 31u);
-        const bool refresh = wave_has_queries && qref < nq;
+        const int qref = wq * 32 + static_cast<int>((turn >> 2) & 31u);
+        const bool refresh = wave_has_queries && qref < nq && (turn & 3u) == 0;
         if (wave_has_queries && lane < 32 && wq * 32 + lane < nq)
             gt = __hip_atomic_load((g_u32p) &qstate[wq * 32 + lane].gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (refresh) {
-            const __amdgpu_buffer_rsrc_t rsrc =
-                __builtin_amdgcn_make_buffer_rsrc(qstate[qref].ghist, 0, kBBins * 4, 0x00020000);
-#pragma unroll
-            for (int v = 0; v < PER / 4; v++) {
-                const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * PER * 4 + v * 16, 0, /*sc1*/ 16);
-                hh[4 * v + 0] = v4.x;
-                hh[4 * v + 1] = v4.y;
-                hh[4 * v + 2] = v4.z;
-                hh[4 * v + 3] = v4.w;
-            }
-        }
-
+        MF_T(tb2);
+        MF_ACC(7, tb0, tb2);
         if (wave_has_queries) {
 #pragma unroll 1
             for (int t2 = 0; t2 < NTB; t2 += 2) {
+                MF_T(tk0);
                 v16f acc0 = {}, acc1 = {};
                 uint32_t pb0 = 0, pb1 = 0;
                 const int row0 = t2 * 32 + i, row1 = row0 + 32;
@@ -265,26 +279,10 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 const u32x4* l0 = &sh.rows[buf][line0 * 16 + (row0 % RPLN) * CPR];
                 const u32x4* l1 = &sh.rows[buf][line1 * 16 + (row1 % RPLN) * CPR];
                 const int x0 = line0 % CPR, x1 = line1 % CPR;
-                // Row fragments are read from LDS one 256-bit group ahead of their use.  Hand-issued
-                // (hipcc sinks such reads next to their use and waits with lgkmcnt(0)): LDS returns in
-                // order, so lgkmcnt(2) leaves exactly the two prefetched reads in flight.
-                const uint32_t base0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
-                    (__attribute__((address_space(3))) const u32x4*) l0));
-                const uint32_t base1 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
-                    (__attribute__((address_space(3))) const u32x4*) l1));
-                u32x4 nb0, nb1;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(nb0) : "v"(base0 + ((h ^ x0) << 4)));
-                asm volatile("ds_read_b128 %0, %1" : "=v"(nb1) : "v"(base1 + ((h ^ x1) << 4)));
 #pragma unroll
                 for (int g = 0; g < KG; g++) {
-                    u32x4 b0 = nb0, b1 = nb1;
-                    if (g + 1 < KG) {
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(nb0) : "v"(base0 + (((2 * (g + 1) + h) ^ x0) << 4)));
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(nb1) : "v"(base1 + (((2 * (g + 1) + h) ^ x1) << 4)));
-                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(b0), "+v"(b1));
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1));
-                    }
+                    const u32x4 b0 = l0[(2 * g + h) ^ x0];
+                    const u32x4 b1 = l1[(2 * g + h) ^ x1];
                     pb0 = bcnt_acc(b0.x, pb0);
                     pb0 = bcnt_acc(b0.y, pb0);
                     pb0 = bcnt_acc(b0.z, pb0);
@@ -293,15 +291,17 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                     pb1 = bcnt_acc(b1.y, pb1);
                     pb1 = bcnt_acc(b1.z, pb1);
                     pb1 = bcnt_acc(b1.w, pb1);
-                    acc0 = mfma_class<0>(aexp[g][0], b0, acc0, km);
-                    acc1 = mfma_class<0>(aexp[g][0], b1, acc1, km);
-                    acc0 = mfma_class<1>(aexp[g][1], b0, acc0, km);
-                    acc1 = mfma_class<1>(aexp[g][1], b1, acc1, km);
-                    acc0 = mfma_class<2>(aexp[g][2], b0, acc0, km);
-                    acc1 = mfma_class<2>(aexp[g][2], b1, acc1, km);
-                    acc0 = mfma_class<3>(aexp[g][3], b0, acc0, km);
-                    acc1 = mfma_class<3>(aexp[g][3], b1, acc1, km);
+                    acc0 = mfma_class<0>(aexp[g][0], fp4_class<0>(b0, km), acc0);
+                    acc1 = mfma_class<0>(aexp[g][0], fp4_class<0>(b1, km), acc1);
+                    acc0 = mfma_class<1>(aexp[g][1], fp4_class<1>(b0, km), acc0);
+                    acc1 = mfma_class<1>(aexp[g][1], fp4_class<1>(b1, km), acc1);
+                    acc0 = mfma_class<2>(aexp[g][2], fp4_class<2>(b0, km), acc0);
+                    acc1 = mfma_class<2>(aexp[g][2], fp4_class<2>(b1, km), acc1);
+                    acc0 = mfma_class<3>(aexp[g][3], fp4_class<3>(b0, km), acc0);
+                    acc1 = mfma_class<3>(aexp[g][3], fp4_class<3>(b1, km), acc1);
                 }
+                MF_T(tk1);
+                MF_ACC(0, tk0, tk1);
                 pb0 += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb0), 32, 64));
                 pb1 += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb1), 32, 64));
 
@@ -310,34 +310,46 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][h]);
                 const float pbf0 = static_cast<float>(pb0), pbf1 = static_cast<float>(pb1);
                 const u64 rowi0 = blk * RB + t2 * 32 + i, rowi1 = rowi0 + 32;
+                // Fast test, vector ALU only (a compare per pair into a scalar mask would stall on the
+                // VALU->SALU dependency 32 times): d = c - kb * popc(row) - ka, maximum over the 16 queries
+                // of the lane; a pair can only pass with d >= 0 up to rounding (|error| << 0.05).
+                float mx0 = -1.0f, mx1 = -1.0f;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const f32x4 va = kap[r4], vb = kbp[r4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        mx0 = fmaxf(mx0, __builtin_fmaf(-vb[e], pbf0, acc0[4 * r4 + e]) - va[e]);
+                        mx1 = fmaxf(mx1, __builtin_fmaf(-vb[e], pbf1, acc1[4 * r4 + e]) - va[e]);
+                    }
+                }
+                const bool active0 = rowi0 < a.nrows, active1 = rowi1 < a.nrows;
                 // which accumulator registers hold a passing pair (bit r: tile 0, bit 16 + r: tile 1)
-                uint32_t rmask = 0;
-                {
-                    u64 m0 = 0, m1 = 0;
+                uint32_t bits = 0, rmask = 0;
+                if (__ballot((active0 && mx0 >= -0.05f) || (active1 && mx1 >= -0.05f)) != 0) {
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {
                         const f32x4 va = kap[r4], vb = kbp[r4];
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            m0 |= __ballot(acc0[4 * r4 + e] >= __builtin_fmaf(vb[e], pbf0, va[e]));
-                            m1 |= __ballot(acc1[4 * r4 + e] >= __builtin_fmaf(vb[e], pbf1, va[e]));
+                            const int r = 4 * r4 + e;
+                            bits |= (acc0[r] >= __builtin_fmaf(vb[e], pbf0, va[e])) ? (1u << r) : 0u;
+                            bits |= (acc1[r] >= __builtin_fmaf(vb[e], pbf1, va[e])) ? (1u << (16 + r)) : 0u;
                         }
                     }
-                    m0 &= __ballot(rowi0 < a.nrows);
-                    m1 &= __ballot(rowi1 < a.nrows);
-                    if ((m0 | m1) != 0) {
-#pragma unroll
-                        for (int r4 = 0; r4 < 4; r4++) {
-                            const f32x4 va = kap[r4], vb = kbp[r4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const int r = 4 * r4 + e;
-                                if (m0 & __ballot(acc0[r] >= __builtin_fmaf(vb[e], pbf0, va[e]))) rmask |= 1u << r;
-                                if (m1 & __ballot(acc1[r] >= __builtin_fmaf(vb[e], pbf1, va[e]))) rmask |= 1u << (16 + r);
-                            }
-                        }
-                    }
+                    if (!active0) bits &= 0xFFFF0000u;
+                    if (!active1) bits &= 0x0000FFFFu;
+                    uint32_t o = bits; // OR over the wavefront
+                    o |= dpp<0xB1>(o);
+                    o |= dpp<0x4E>(o);
+                    o |= dpp<0x141>(o);
+                    o |= dpp<0x140>(o);
+                    o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 16, 64));
+                    o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 32, 64));
+                    rmask = __builtin_amdgcn_readfirstlane(o);
                 }
+                MF_T(tk2);
+                MF_ACC(1, tk1, tk2);
                 // rare: stage the pairs that passed
                 while (rmask) {
                     const int bit = __builtin_ctz(rmask);
@@ -347,8 +359,7 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                     const float cf = second ? acc1[r] : acc0[r];
                     const uint32_t pb = second ? pb1 : pb0;
                     const u64 rowi = second ? rowi1 : rowi0;
-                    const bool pass = rowi < a.nrows &&
-                                      cf >= __builtin_fmaf(sh.kap_b[wq][h][r], static_cast<float>(pb), sh.kap_a[wq][h][r]);
+                    const bool pass = (bits >> bit) & 1u;
                     const u64 mp = __ballot(pass);
                     if (pass) {
                         const uint32_t slot = staged + lane_rank(mp);
@@ -357,13 +368,32 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                         stg_q[slot] = static_cast<uint32_t>((r & 3) + 8 * (r >> 2) + 4 * h); // query of the tile
                     }
                     staged += static_cast<uint32_t>(__popcll(mp));
-                    if (staged > 64) drain_stage();
+                    if (staged > 64) {
+                        MF_T(td0);
+                        drain_stage();
+                        MF_T(td1);
+                        MF_ACC(8, td0, td1);
+                    }
                 }
+                MF_T(tk3);
+                MF_ACC(6, tk2, tk3);
             }
+            MF_T(tr0);
             if (refresh) {
+                // (not prefetched: eight more live registers across the tiles would spill)
+                uint32_t hh[PER];
+                const __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc(qstate[qref].ghist, 0, kBBins * 4, 0x00020000);
                 uint32_t sum = 0;
 #pragma unroll
-                for (int v = 0; v < PER; v++) sum += hh[v];
+                for (int v = 0; v < PER / 4; v++) {
+                    const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * PER * 4 + v * 16, 0, /*sc1*/ 16);
+                    hh[4 * v + 0] = v4.x;
+                    hh[4 * v + 1] = v4.y;
+                    hh[4 * v + 2] = v4.z;
+                    hh[4 * v + 3] = v4.w;
+                    sum += v4.x + v4.y + v4.z + v4.w;
+                }
                 uint32_t bin_k, cnt;
                 threshold_from_counts<PER>(hh, sum, a.k, lane, bin_k, cnt);
                 bin_k = __builtin_amdgcn_readfirstlane(bin_k);
@@ -375,10 +405,22 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 }
             }
             if (lane < 32 && gt > sh.tau[wq][lane]) set_query_constants(gt);
+            MF_T(tr9);
+            MF_ACC(3, tr0, tr9);
         }
+        MF_T(tr1);
         __builtin_amdgcn_s_waitcnt(0);
+        MF_T(tw);
+        MF_ACC(4, tr1, tw);
         __syncthreads();
+        MF_T(tb1);
+        MF_ACC(5, tw, tb1);
+        MF_ACC(2, tb0, tb1);
     }
+#if GSIM_MF_TIMING
+    if (wq == 0 && lane == 0)
+        for (int d = 0; d < 9; d++) atomicAdd(&rr.flags[2 + d], static_cast<uint32_t>(tacc[d] >> 6));
+#endif
     if (staged) drain_stage();
     if (lane == 0) {
         rr.seg_count[w] = cursor < rr.seg_cap ? cursor : rr.seg_cap;

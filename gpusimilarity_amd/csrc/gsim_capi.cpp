@@ -458,10 +458,10 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         GSIM_HIP(hipMalloc(&s.d_bseg_count, nw * 4));
         GSIM_HIP(hipMalloc(&s.d_bfin_key, static_cast<size_t>(kBatchMaxQ) * gsim::kSelectCap * 8));
         GSIM_HIP(hipMalloc(&s.d_bfin_cb, static_cast<size_t>(kBatchMaxQ) * gsim::kSelectCap * 4));
-        GSIM_HIP(hipMalloc(&s.d_bflags, 16));
+        GSIM_HIP(hipMalloc(&s.d_bflags, 64));
         GSIM_HIP(hipMalloc(&s.d_brare, sizeof(gsim::BatchRare)));
         GSIM_HIP(hipHostMalloc(&s.h_brare, sizeof(gsim::BatchRare), hipHostMallocDefault));
-        GSIM_HIP(hipHostMalloc(&s.h_bflags, 16, hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(&s.h_bflags, 64, hipHostMallocDefault));
         GSIM_HIP(hipHostMalloc(&s.h_bqueries, static_cast<size_t>(kBatchMaxQ) * (s.W + 1) * 4, hipHostMallocDefault));
         s.bq_cap = kBatchMaxQ;
     }
@@ -490,7 +490,7 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     GSIM_HIP(hipMemcpyAsync(s.d_bqueries, s.h_bqueries, qbytes, hipMemcpyHostToDevice, s.stream));
     GSIM_HIP(hipMemcpyAsync(s.d_bqpop, hp, static_cast<size_t>(nq) * 4, hipMemcpyHostToDevice, s.stream));
     GSIM_HIP(hipMemsetAsync(s.d_bstate, 0, sizeof(gsim::BatchQueryState) * nq, s.stream));
-    GSIM_HIP(hipMemsetAsync(s.d_bflags, 0, 16, s.stream));
+    GSIM_HIP(hipMemsetAsync(s.d_bflags, 0, 64, s.stream));
     gsim::BatchRare& rr = *s.h_brare;
     rr.qstate = s.d_bstate;
     rr.cand = s.d_bcand;
@@ -526,7 +526,7 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         a.nq = nq;
         GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, s.h_bresult,
                                               gsim_result_block_bytes(k), s.stream));
-        GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 16, hipMemcpyDeviceToHost, s.stream));
+        GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
         return GSIM_OK;
     }
     for (uint32_t q0 = 0; q0 < nq; q0 += gsim::kBQ) {
@@ -535,7 +535,7 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         GSIM_HIP(gsim::launch_batch_pass(a, rr, s.bgeo, sample, row_base, s.h_bresult, gsim_result_block_bytes(k),
                                          s.stream));
     }
-    GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 16, hipMemcpyDeviceToHost, s.stream));
+    GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
     return GSIM_OK;
 }
 
@@ -1036,7 +1036,11 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                 rc = wait_stream(s.stream);
                 if (rc != GSIM_OK) return rc;
                 if (s.h_bflags[0] & 1u) overflow = true;
-                if (std::getenv("GSIM_DEBUG_BATCH")) std::fprintf(stderr, "batch flags %u slow visits %u bits %u\n", s.h_bflags[0], s.h_bflags[2], s.h_bflags[3]);
+                if (std::getenv("GSIM_DEBUG_BATCH")) { // counters of instrumented builds (GSIM_MF_TIMING)
+                    std::fprintf(stderr, "batch flags %u dbg", s.h_bflags[0]);
+                    for (int d = 2; d < 16; d++) std::fprintf(stderr, " %u", s.h_bflags[d]);
+                    std::fprintf(stderr, "\n");
+                }
             }
             for (uint32_t q = 0; q < nb; q++) {
                 uint64_t ap = 0;

@@ -62,6 +62,52 @@ template <int NACC, int VALU_PER> __global__ __launch_bounds__(256) void rate_ke
     for (int j = 0; j < 8; j++) ju ^= junk[j];
     out[blockIdx.x * 256 + threadIdx.x] = t + ju;
 }
+// burst pattern: BURST MFMAs back to back on ONE accumulator, then BURST * VALU_PER v_and_b32; the two
+// accumulators alternate.  (An issue slot between dependent MFMAs costs far more than one between
+// independent ones, so VALU work is better batched between bursts than interleaved.)
+template <int BURST, int VALU_PER> __global__ __launch_bounds__(256) void burst_kernel(const u32x4* A, float* out, int iters)
+{
+    u32x4 a = A[threadIdx.x & 63], b = A[(threadIdx.x + 7) & 63];
+    v16f acc[2];
+    acc[0] = v16f{}; acc[1] = v16f{};
+    unsigned junk[8];
+    for (int j = 0; j < 8; j++) junk[j] = threadIdx.x + j;
+    unsigned y = threadIdx.x * 2654435761u;
+    const int s0 = 0x7F7F7F7F;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+#pragma unroll
+            for (int m = 0; m < BURST; m++)
+                acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cls(a, 0x22222222u), cls(b, 0x22222222u), acc[n], 4, 4, 0, s0, 0, s0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < VALU_PER * BURST; v++) asm volatile("v_and_b32 %0, %1, %0" : "+v"(junk[v & 7]) : "v"(y));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float t = 0;
+    for (int n = 0; n < 2; n++) for (int r = 0; r < 16; r++) t += acc[n][r];
+    unsigned ju = 0;
+    for (int j = 0; j < 8; j++) ju ^= junk[j];
+    out[blockIdx.x * 256 + threadIdx.x] = t + ju;
+}
+template <int BURST, int VALU_PER> void burst(const u32x4* A, float* out, int wpc)
+{
+    const int iters = 1000, blocks = 256 * wpc / 4;
+    hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int t = 0; t < 4; t++) {
+        (void) hipEventRecord(e0);
+        hipLaunchKernelGGL((burst_kernel<BURST, VALU_PER>), dim3(blocks), dim3(256), 0, 0, A, out, iters);
+        (void) hipEventRecord(e1); (void) hipEventSynchronize(e1);
+        float ms; (void) hipEventElapsedTime(&ms, e0, e1);
+        if (t && ms < best) best = ms;
+    }
+    const double mf = double(blocks) * 4 * iters * 2 * BURST;
+    printf("burst %d v_and/mfma %2d waves/SIMD %d: %.1f cycles per MFMA per SIMD at 2.4 GHz\n", BURST, VALU_PER, wpc / 4,
+           best * 1e-3 * 2.4e9 / (mf / 1024.0));
+}
 template <int NACC, int VALU_PER> void rate(const u32x4* A, float* out, int wpc)
 {
     const int iters = 2000, blocks = 256 * wpc / 4;
@@ -100,7 +146,9 @@ int main()
     printf("check: C[a_row][b_row] mismatches %d (transposed reading: %d) of 1024; sample %.1f\n", bad, badT, hC[33]);
     for (int wpc : {4, 8}) {
         rate<2, 0>(dA, out, wpc); rate<2, 4>(dA, out, wpc); rate<2, 8>(dA, out, wpc); rate<2, 12>(dA, out, wpc);
-        rate<2, 16>(dA, out, wpc); rate<2, 24>(dA, out, wpc); rate<1, 8>(dA, out, wpc); rate<4, 8>(dA, out, wpc);
+        rate<1, 8>(dA, out, wpc); rate<4, 8>(dA, out, wpc);
+        burst<4, 4>(dA, out, wpc); burst<4, 6>(dA, out, wpc); burst<4, 8>(dA, out, wpc); burst<4, 12>(dA, out, wpc);
+        burst<8, 6>(dA, out, wpc); burst<8, 8>(dA, out, wpc); burst<2, 8>(dA, out, wpc); burst<16, 8>(dA, out, wpc);
     }
     return 0;
 }
