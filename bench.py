@@ -30,7 +30,7 @@ import torch  # noqa: E402  (first: one HIP runtime in the process, see capi.loa
 import torch.distributed as dist  # noqa: E402
 
 from gpusimilarity_amd import capi  # noqa: E402
-from gpusimilarity_amd.sharded import ShardedSearch  # noqa: E402
+from gpusimilarity_amd.sharded import ShardedBatchSearch, ShardedSearch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 DB_SEED = 0x5EED0001
@@ -95,6 +95,83 @@ def cpu_baseline(fp_bits, k, kind, budget_s=12.0):
                       (reps, n, fp_bits, cores, el, what)}
 
 
+MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-FP4, MI355X_MICROARCH.md (measured 9099)
+
+
+def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k, sharded_path, json_fd):
+    """BASELINE configs[4]: Tversky(0.3, 0.7), Q-query batches, top-k per query; a step = one batch.
+    Rows shard over the ranks, every rank scores all Q queries against its shard (the matrix-core
+    pass for Q >= 64), ONE all-gather of Q result blocks per step, one merge launch."""
+    Q = args.batch_queries
+    kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    nb = args.warmup + args.steps
+    batches = [np.stack([synth_row(DB_SEED, kind, query_row(b * Q + i, total_rows), W) for i in range(Q)])
+               for b in range(min(nb, 4))]  # a few distinct batches, cycled
+    sb = None
+    if sharded_path:
+        def local_batch(qs, kk, blocks):
+            table.search_batch_device(qs, kk, blocks.data_ptr(), 0.0, **kw)
+
+        with torch.cuda.stream(stream):
+            sb = ShardedBatchSearch(local_batch, k, Q, dev, stream_ptr=stream.cuda_stream)
+    last = {}
+
+    def one_batch(qs):
+        if not sharded_path:
+            last["hits"], last["approx"] = table.search(qs, k, 0.0, **kw)
+            return
+        with torch.cuda.stream(stream):
+            sb.enqueue(qs)
+        stream.synchronize()
+
+    for b in range(args.warmup):
+        one_batch(batches[b % len(batches)])
+    if args.warmup:
+        b = (args.warmup - 1) % len(batches)
+        first = sb.results()[0][0] if sharded_path else last["hits"][0]
+        assert int(first["row"][0]) == query_row(b * Q, total_rows) and first["score"][0] == 1.0, "self hit missing"
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for b in range(args.warmup, nb):
+        one_batch(batches[b % len(batches)])
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        steps = args.steps
+        per = elapsed / steps
+        pairs = Q * total_rows / per
+        tflops = 2.0 * Q * R * args.fp_bits / per / 1e12  # one GPU: 0/1 multiply-adds of the contraction
+        out = {
+            "metric": "(query, fingerprint) pairs scored/sec (%d-bit Tversky(0.3,0.7), %d-query batches, top-%d)" % (
+                args.fp_bits, Q, k),
+            "value": pairs, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * per, "queries_per_s": Q / per, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 bits as MX-FP4 {0,1} operands, f32 accumulate (exact)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] shape: %d x %d-bit rows per GPU x %d GPU(s), Tversky a=0.3 b=0.7, "
+                                   "%d-query batch, top-%d" % (R, args.fp_bits, world, Q, k),
+                       "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "batch": Q,
+                       "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of Q result blocks" if world > 1 else "")},
+            "roofline": {"kernel": "batch_mfma_kernel", "bound": "mfma",
+                         "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
+                         "traffic": None,
+                         "note": "whole step (sample passes, contraction, compaction, select, host) per GPU; "
+                                 "table bytes read once per batch: %.1f GB/s effective" % (R * args.fp_bits / 8 / per / 1e9)},
+        }
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     # stdout carries exactly ONE JSON line: route everything else that may write to fd 1
     # (RCCL prints a version banner from C) to stderr
@@ -110,6 +187,9 @@ def main():
     ap.add_argument("--fp-bits", type=int, default=1024)
     ap.add_argument("--kind", choices=["sparse", "dense"], default="sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-queries", type=int, default=0,
+                    help="BASELINE configs[4] instead of the headline run: Tversky(0.3, 0.7) batches of this many "
+                         "queries per step (use with --fp-bits 2048); a step is one batch")
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="run the N>1 code path (device result blocks, all-gather, device merge) even at N=1")
     args = ap.parse_args()
@@ -142,9 +222,12 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     table.set_stream(stream.cuda_stream)
 
+    sharded_path = world > 1 or args.force_sharded_path
+    if args.batch_queries:
+        run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k, sharded_path, json_fd)
+        return
     nq = args.warmup + args.steps
     queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(nq)]
-    sharded_path = world > 1 or args.force_sharded_path
     bufs = table.make_search_buffers(1, k)
     ss = None
     if sharded_path:

@@ -46,7 +46,8 @@ EXPORTS = [
     "gsim_fold_fingerprint", "gsim_db_generate", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
     "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
-    "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_merge_host",
+    "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
+    "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_db_enable_timing",
     "gsim_db_get_timing", "gsim_debug_score_table", "gsim_last_error", "gsim_version",
 ]
@@ -96,6 +97,9 @@ def load():
         "gsim_result_block_bytes": (C.c_size_t, [C.c_uint32]),
         "gsim_db_search_device": (C.c_int, [vp, u32p, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float, vp]),
         "gsim_merge_device": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
+        "gsim_db_search_batch_device": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_float,
+                                                  C.c_float, vp]),
+        "gsim_merge_device_batch": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
         "gsim_merge_host": (C.c_int, [vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
         "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
@@ -256,6 +260,12 @@ class Table:
         check(self._L.gsim_db_search_device(self._h, _u32(q), k, cutoff, metric, alpha, beta,
                                             C.c_void_p(d_result_ptr)))
 
+    def search_batch_device(self, queries, k, d_results_ptr, cutoff=0.0, metric=METRIC_TANIMOTO, alpha=1.0, beta=1.0):
+        """nq queries; result block q lands at d_results_ptr + q * result_block_bytes(k) (device)."""
+        q = np.ascontiguousarray(queries, dtype=np.uint32).reshape(-1, self.W)
+        check(self._L.gsim_db_search_batch_device(self._h, _u32(q), len(q), k, cutoff, metric, alpha, beta,
+                                                  C.c_void_p(d_results_ptr)))
+
     def enable_timing(self, enable=True):
         check(self._L.gsim_db_enable_timing(self._h, 1 if enable else 0))
 
@@ -275,6 +285,11 @@ def fold_fingerprint(fp, fold_factor: int) -> np.ndarray:
 def merge_device(device, stream_ptr, d_blocks_ptr, nblocks, block_bytes, k, d_result_ptr):
     check(load().gsim_merge_device(device, C.c_void_p(stream_ptr), C.c_void_p(d_blocks_ptr), nblocks, block_bytes, k,
                                    C.c_void_p(d_result_ptr)))
+
+
+def merge_device_batch(device, stream_ptr, d_blocks_ptr, nranks, nq, block_bytes, k, d_results_ptr):
+    check(load().gsim_merge_device_batch(device, C.c_void_p(stream_ptr), C.c_void_p(d_blocks_ptr), nranks, nq,
+                                         block_bytes, k, C.c_void_p(d_results_ptr)))
 
 
 def merge_host(blocks: bytes, nblocks: int, block_bytes: int, k: int) -> bytes:

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void batch_select_kernel(BatchArgs a, uint32_t
             hdr->count = 0;
             hdr->flags = 2;
             hdr->approx = approx;
+            atomicOr(a.rare->flags, 4u); // one word tells the host that some query needs the fallback
         }
         return;
     }

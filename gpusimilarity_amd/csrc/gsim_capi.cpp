@@ -475,10 +475,11 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
     return GSIM_OK;
 }
 
-// Enqueue nq (<= kBatchMaxQ) queries on one shard: ceil(nq / kBQ) passes over the table, the
-// result blocks land in s.h_bresult (pinned).  No host synchronisation.
+// Enqueue nq (<= kBatchMaxQ) queries on one shard: ceil(nq / kBQ) passes over the table (one on the
+// matrix cores), the result blocks land in `results` (pinned host or device memory).  No host
+// synchronisation.
 int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
-                  float alpha, float beta, uint32_t row_base)
+                  float alpha, float beta, uint32_t row_base, void* results)
 {
     int rc = ensure_batch_buffers(db, s, k);
     if (rc != GSIM_OK) return rc;
@@ -524,7 +525,7 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         !(cutoff > 0.0f) && gsim::batch_mfma_supported(s.W)) {
         a.q0 = 0;
         a.nq = nq;
-        GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, s.h_bresult,
+        GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, results,
                                               gsim_result_block_bytes(k), s.stream));
         GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
         return GSIM_OK;
@@ -532,7 +533,7 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     for (uint32_t q0 = 0; q0 < nq; q0 += gsim::kBQ) {
         a.q0 = q0;
         a.nq = std::min<uint32_t>(gsim::kBQ, nq - q0);
-        GSIM_HIP(gsim::launch_batch_pass(a, rr, s.bgeo, sample, row_base, s.h_bresult, gsim_result_block_bytes(k),
+        GSIM_HIP(gsim::launch_batch_pass(a, rr, s.bgeo, sample, row_base, results, gsim_result_block_bytes(k),
                                          s.stream));
     }
     GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
@@ -1026,7 +1027,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             for (auto& s : db->shards) {
                 if (s.nrows == 0) continue;
                 rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta,
-                                   db->row_base + static_cast<uint32_t>(s.first_row));
+                                   db->row_base + static_cast<uint32_t>(s.first_row), s.h_bresult);
                 if (rc != GSIM_OK) return rc;
             }
             bool overflow = false;
@@ -1097,13 +1098,65 @@ int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float 
     return enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base, d_result, false);
 }
 
+int gsim_db_search_batch_device(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+                                float alpha, float beta, void* d_results)
+{
+    int rc = check_search_args(db, queries, metric);
+    if (rc != GSIM_OK) return rc;
+    if (!d_results) return fail(GSIM_ERR_INVALID, "d_results is NULL");
+    if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "search_batch_device needs a single-shard handle");
+    if (db->fold > 1) return fail(GSIM_ERR_STATE, "search_batch_device does not support folded tables");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    Shard& s = db->shards[0];
+    const size_t blk = gsim_result_block_bytes(k);
+    unsigned char* out = static_cast<unsigned char*>(d_results);
+    const bool batched = nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 && gsim::batch_supported(db->W) &&
+                         s.nrows > 0 && env_int("GSIM_BATCH", 1) != 0;
+    for (uint32_t base = 0; base < nq; base += kBatchMaxQ) {
+        const uint32_t nb = std::min<uint32_t>(kBatchMaxQ, nq - base);
+        const uint32_t* qb = queries + static_cast<size_t>(base) * db->W;
+        bool redo = !batched;
+        if (batched) {
+            rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, db->row_base, out + base * blk);
+            if (rc != GSIM_OK) return rc;
+            // the one host synchronisation of a batch: did a query overflow its candidate segment or
+            // collect too many ties for the multi-query select (bit 2, set by batch_select_kernel)?
+            GSIM_HIP(hipSetDevice(s.device));
+            rc = wait_stream(s.stream);
+            if (rc != GSIM_OK) return rc;
+            redo = (s.h_bflags[0] & 5u) != 0;
+        }
+        if (redo) { // those cases are rare: the whole chunk goes through the single-query pipeline
+            for (uint32_t q = 0; q < nb; q++) {
+                rc = enqueue_query(db, s, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta,
+                                   db->row_base, out + (base + q) * blk, false);
+                if (rc != GSIM_OK) return rc;
+            }
+        }
+    }
+    return GSIM_OK;
+}
+
 int gsim_merge_device(int device, void* hip_stream, const void* d_blocks, uint32_t nblocks, size_t block_bytes,
                       uint32_t k, void* d_result)
 {
     if (!d_blocks || !d_result || nblocks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
     if (block_bytes < gsim_result_block_bytes(k)) return fail(GSIM_ERR_INVALID, "block_bytes too small for k");
     GSIM_HIP(hipSetDevice(device));
-    GSIM_HIP(gsim::launch_merge(d_blocks, nblocks, block_bytes, k, d_result, static_cast<hipStream_t>(hip_stream)));
+    GSIM_HIP(gsim::launch_merge_batch(d_blocks, nblocks, 1, block_bytes, k, d_result,
+                                      static_cast<hipStream_t>(hip_stream)));
+    return GSIM_OK;
+}
+
+int gsim_merge_device_batch(int device, void* hip_stream, const void* d_blocks, uint32_t nranks, uint32_t nq,
+                            size_t block_bytes, uint32_t k, void* d_results)
+{
+    if (!d_blocks || !d_results || nranks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
+    if (block_bytes < gsim_result_block_bytes(k)) return fail(GSIM_ERR_INVALID, "block_bytes too small for k");
+    if (nq == 0) return GSIM_OK;
+    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(gsim::launch_merge_batch(d_blocks, nranks, nq, block_bytes, k, d_results,
+                                      static_cast<hipStream_t>(hip_stream)));
     return GSIM_OK;
 }
 

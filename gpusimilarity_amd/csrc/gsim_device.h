@@ -84,9 +84,10 @@ hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_
                             uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags,
                             void* d_result, hipStream_t s);
 
-// Merge of result blocks (multi-GPU gather).
-hipError_t launch_merge(const void* d_blocks, uint32_t nblocks, size_t block_bytes, uint32_t k,
-                        void* d_result, hipStream_t s);
+// Merge of result blocks (multi-GPU gather) for nq queries: the lists of query q are the blocks
+// q, q + nq, ... (nblocks of them); merged block q goes to d_results + q * block_bytes.
+hipError_t launch_merge_batch(const void* d_blocks, uint32_t nblocks, uint32_t nq, size_t block_bytes, uint32_t k,
+                              void* d_results, hipStream_t s);
 
 // ---- multi-query batches (gsim_batch.hip) ------------------------------------------
 constexpr int kBQ = 32;     // queries per pass over the table

@@ -884,17 +884,23 @@ __device__ __forceinline__ const gsim_result_header* block_hdr(const void* block
 // Every list is in canonical order and keys are unique across lists, so the
 // output position of an element is the number of elements that precede it:
 // its own index plus, for every other list, a binary search.
-__global__ __launch_bounds__(256) void merge_kernel(const void* blocks, uint32_t nblocks, size_t block_bytes,
-                                                    uint32_t k, void* d_result)
+// blockIdx.y = query: its lists are the blocks q, q + nq, q + 2 nq, ... of the gathered buffer
+// (rank-major, as an all-gather of per-rank [nq] block arrays leaves them).
+__global__ __launch_bounds__(256) void merge_kernel(const void* all_blocks, uint32_t nblocks, uint32_t nq,
+                                                    size_t block_bytes, uint32_t k, void* d_results)
 {
-    gsim_result_header* ohdr = reinterpret_cast<gsim_result_header*>(d_result);
+    const uint32_t q = blockIdx.y;
+    const void* blocks = static_cast<const unsigned char*>(all_blocks) + static_cast<size_t>(q) * block_bytes;
+    const size_t list_stride = static_cast<size_t>(nq) * block_bytes;
+    gsim_result_header* ohdr =
+        reinterpret_cast<gsim_result_header*>(static_cast<unsigned char*>(d_results) + static_cast<size_t>(q) * block_bytes);
     gsim_hit* out = reinterpret_cast<gsim_hit*>(ohdr + 1);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {
         u64 approx = 0, total = 0;
         uint32_t flags = 0;
         for (uint32_t i = 0; i < nblocks; i++) {
-            const gsim_result_header* h = block_hdr(blocks, block_bytes, i);
+            const gsim_result_header* h = block_hdr(blocks, list_stride, i);
             approx += h->approx;
             total += h->count;
             flags |= h->flags;
@@ -905,7 +911,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const void* blocks, uint32_t
     }
     const uint32_t li = t / k, e = t % k;
     if (li >= nblocks) return;
-    const gsim_result_header* mh = block_hdr(blocks, block_bytes, li);
+    const gsim_result_header* mh = block_hdr(blocks, list_stride, li);
     if (e >= mh->count) return;
     const gsim_hit* mine = reinterpret_cast<const gsim_hit*>(mh + 1);
     const gsim_hit me = mine[e];
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const void* blocks, uint32_t
     uint32_t rank = e;
     for (uint32_t j = 0; j < nblocks; j++) {
         if (j == li) continue;
-        const gsim_result_header* h = block_hdr(blocks, block_bytes, j);
+        const gsim_result_header* h = block_hdr(blocks, list_stride, j);
         const gsim_hit* lst = reinterpret_cast<const gsim_hit*>(h + 1);
         uint32_t lo = 0, hi = h->count; // first index whose key < mykey
         while (lo < hi) {
@@ -1137,13 +1143,13 @@ hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_
     return hipGetLastError();
 }
 
-hipError_t launch_merge(const void* d_blocks, uint32_t nblocks, size_t block_bytes, uint32_t k, void* d_result,
-                        hipStream_t s)
+hipError_t launch_merge_batch(const void* d_blocks, uint32_t nblocks, uint32_t nq, size_t block_bytes, uint32_t k,
+                              void* d_results, hipStream_t s)
 {
     const uint64_t nthreads = static_cast<uint64_t>(nblocks) * (k ? k : 1);
     const uint32_t nb = static_cast<uint32_t>((nthreads + 255) / 256);
-    hipLaunchKernelGGL(merge_kernel, dim3(nb ? nb : 1), dim3(256), 0, s, d_blocks, nblocks, block_bytes,
-                       k ? k : 1, d_result);
+    hipLaunchKernelGGL(merge_kernel, dim3(nb ? nb : 1, nq), dim3(256), 0, s, d_blocks, nblocks, nq, block_bytes,
+                       k ? k : 1, d_results);
     return hipGetLastError();
 }
 

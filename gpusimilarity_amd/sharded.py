@@ -77,3 +77,66 @@ class ShardedSearch:
     def result(self):
         """(hits, approx, flags) of the last enqueued query (after the stream is synchronised)."""
         return capi.parse_result_block(self.host_out.numpy().tobytes(), self.k)
+
+
+class ShardedBatchSearch:
+    """The same gather + merge for batches of nq queries (BASELINE config 5: 256 queries per call).
+
+    ``local_search(queries, k, blocks)`` leaves this rank's nq result blocks (query-major) in the
+    uint8 tensor ``blocks`` -- on a GPU ``Table.search_batch_device``.  ONE all-gather of
+    nq * (16 + 12 k) bytes per rank, then one merge launch for all queries.
+    """
+
+    def __init__(self, local_search: Callable, k: int, max_queries: int, device, group=None,
+                 stream_ptr: Optional[int] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.k = k
+        self.max_queries = max_queries
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.blk = capi.result_block_bytes(k)
+        self.local_search = local_search
+        self.stream_ptr = stream_ptr
+        n = self.blk * max_queries
+        self.local = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.gathered = torch.zeros(n * self.world, dtype=torch.uint8, device=self.device)
+        self.merged = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        self.on_gpu = self.device.type == "cuda"
+        self.host_out = torch.zeros(n, dtype=torch.uint8)
+        if self.on_gpu:
+            self.host_out = self.host_out.pin_memory()
+        self.nq = 0
+
+    def enqueue(self, queries) -> None:
+        nq = len(queries)
+        if nq > self.max_queries:
+            raise ValueError("batch larger than max_queries")
+        self.nq = nq
+        n = self.blk * nq
+        local = self.local[:n]
+        self.local_search(queries, self.k, local)
+        gathered = self.gathered[:n * self.world]
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(gathered, local, group=self.group)
+        else:
+            gathered.copy_(local)
+        if self.on_gpu:
+            capi.merge_device_batch(self.device.index or 0, self.stream_ptr or 0, gathered.data_ptr(), self.world, nq,
+                                    self.blk, self.k, self.merged.data_ptr())
+            self.host_out[:n].copy_(self.merged[:n], non_blocking=True)
+        else:
+            raw = gathered.numpy().tobytes()
+            out = bytearray()
+            for q in range(nq):  # the lists of query q: block q of every rank
+                lists = b"".join(raw[(r * nq + q) * self.blk:(r * nq + q + 1) * self.blk] for r in range(self.world))
+                out += capi.merge_host(lists, self.world, self.blk, self.k)
+            self.host_out[:n].copy_(self.torch.frombuffer(out, dtype=self.torch.uint8))
+
+    def results(self):
+        """[(hits, approx, flags)] of the last enqueued batch (after the stream is synchronised)."""
+        raw = self.host_out.numpy().tobytes()
+        return [capi.parse_result_block(raw[q * self.blk:(q + 1) * self.blk], self.k) for q in range(self.nq)]

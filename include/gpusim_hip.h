@@ -187,6 +187,25 @@ int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float 
 int gsim_merge_device(int device, void* hip_stream, const void* d_blocks,
                       uint32_t nblocks, size_t block_bytes, uint32_t k, void* d_result);
 
+/* nq queries (host memory, nq x fp_bits/32 words), single-shard handle: result
+ * block q = {header; hits[k]} at d_results + q * gsim_result_block_bytes(k) in
+ * device memory, enqueued on the handle's stream.  Batches share table passes
+ * (the multi-query / matrix-core pass) exactly as in gsim_db_search; the call
+ * waits for the handle's stream once per 256 queries (queries that need the
+ * single-query pipeline -- heavy ties, candidate overflow -- are re-enqueued
+ * before it returns).  Reference: the per-storage half of FingerprintDB::search,
+ * fingerprintdb_cuda.cu:228-339, for a batch (build-defined). */
+int gsim_db_search_batch_device(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
+                                float cutoff, int metric, float alpha, float beta,
+                                void* d_results);
+/* gsim_merge_device for nq queries at once: d_blocks holds nranks arrays of nq
+ * result blocks (rank-major, the layout an all-gather of each rank's
+ * gsim_db_search_batch_device output produces); merged block q goes to
+ * d_results + q * block_bytes. */
+int gsim_merge_device_batch(int device, void* hip_stream, const void* d_blocks,
+                            uint32_t nranks, uint32_t nq, size_t block_bytes, uint32_t k,
+                            void* d_results);
+
 /* Host twin of gsim_merge_device for result blocks that are in host memory (the
  * in-process multi-device path, and the gloo/CPU tests of the gather+merge
  * logic): std::sort + truncate exactly as fingerprintdb_cuda.cu:363-380. */

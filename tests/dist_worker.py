@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as O  # noqa: E402
 from gpusimilarity_amd import capi  # noqa: E402
-from gpusimilarity_amd.sharded import ShardedSearch, shard_range  # noqa: E402
+from gpusimilarity_amd.sharded import ShardedBatchSearch, ShardedSearch, shard_range  # noqa: E402
 
 
 def main():
@@ -52,6 +52,27 @@ def main():
                             and (hits["score"].view(np.uint32) == want["score"].view(np.uint32)).all()
                             and (hits["common"] == want["common"]).all())
                     ok = ok and bool(same)
+    # batches (BASELINE config 5 shape, small): nq result blocks per rank, one all-gather, per-query merge
+    def local_batch(queries, k, blocks):
+        raw = bytearray()
+        for q in queries:
+            hits, approx = O.search(q, shard, k, 0.0, row_base=first, metric=1, alpha=np.float32(0.3), beta=np.float32(0.7))
+            raw += capi.make_result_block(hits, approx, k)
+        blocks.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+
+    sb = ShardedBatchSearch(local_batch, 50, 16, "cpu")
+    for nq in (1, 7, 16):
+        qs = np.stack([O.synth_rows(seed, 0, O.query_row(100 + i, total), 1, W)[0] for i in range(nq)])
+        sb.enqueue(qs)
+        res = sb.results()
+        ok = ok and len(res) == nq
+        if rank == 0:
+            for i in range(nq):
+                want, wap = O.search(qs[i], whole, 50, 0.0, nthreads=4, metric=1, alpha=np.float32(0.3), beta=np.float32(0.7))
+                hits, approx, _ = res[i]
+                same = (len(hits) == len(want) and approx == wap and (hits["row"] == want["row"]).all()
+                        and (hits["score"].view(np.uint32) == want["score"].view(np.uint32)).all())
+                ok = ok and bool(same)
     # every rank ends with the same merged block
     digest = torch.tensor([int(np.frombuffer(ss.host_out.numpy().tobytes(), dtype=np.uint8).sum())])
     gathered = [torch.zeros_like(digest) for _ in range(world)]

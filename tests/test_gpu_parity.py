@@ -622,3 +622,67 @@ def test_matrix_core_pass_large_table_with_sampling():
         want, _ = O.search(qs[i], db, 1000, 0.0, nthreads=8)
         assert_hits_equal(hits[i], want, "4M x 1024-bit q=%d" % i)
     t.close()
+
+
+def test_batch_device_blocks_and_batched_merge():
+    """The multi-rank data path of a query batch on one GPU: shards as separate handles,
+    gsim_db_search_batch_device per shard, rank-major gathered buffer, ONE
+    gsim_merge_device_batch launch -- equal to the oracle on the whole table for every
+    query; also the ShardedBatchSearch wrapper at world size 1, and the fallback of a
+    chunk (heavy ties) to the single-query pipeline."""
+    import torch
+    from gpusimilarity_amd.sharded import ShardedBatchSearch
+    n, W, k, G, nq = 90_000, 64, 100, 3, 70
+    db = O.synth_rows(0x6A7E5, 0, 0, n, W)
+    qs = _mixed_queries(db, 0, nq, W)
+    blk = capi.result_block_bytes(k)
+    st = torch.cuda.Stream(device=0)
+    torch.cuda.set_stream(st)
+    stream = st.cuda_stream
+    per = n // G
+    shards = []
+    for g in range(G):
+        t = make_table(db[g * per:(g + 1) * per])
+        t.set_stream(stream)
+        t.set_row_base(g * per)
+        shards.append(t)
+    kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    gathered = torch.zeros(G * nq * blk, dtype=torch.uint8, device="cuda:0")
+    for g, t in enumerate(shards):
+        t.search_batch_device(qs, k, gathered.data_ptr() + g * nq * blk, 0.0, **kw)
+    out = torch.zeros(nq * blk, dtype=torch.uint8, device="cuda:0")
+    capi.merge_device_batch(0, stream, gathered.data_ptr(), G, nq, blk, k, out.data_ptr())
+    torch.cuda.synchronize()
+    raw = out.cpu().numpy().tobytes()
+    for i in range(nq):
+        hits, approx, _ = capi.parse_result_block(raw[i * blk:(i + 1) * blk], k)
+        want, wap = O.search(qs[i], db, k, 0.0, nthreads=8, **kw)
+        assert approx == wap
+        assert_hits_equal(hits, want, "batched merge q=%d" % i)
+    # wrapper, world size 1 (no process group): local blocks -> merge -> pinned host
+    whole = make_table(db)
+    whole.set_stream(stream)
+    sb = ShardedBatchSearch(lambda q, kk, blocks: whole.search_batch_device(q, kk, blocks.data_ptr(), 0.0, **kw),
+                            k, 128, "cuda:0", stream_ptr=stream)
+    sb.enqueue(qs[:65])
+    torch.cuda.synchronize()
+    for i, (hits, approx, _) in enumerate(sb.results()):
+        want, wap = O.search(qs[i], db, k, 0.0, nthreads=8, **kw)
+        assert approx == wap
+        assert_hits_equal(hits, want, "ShardedBatchSearch q=%d" % i)
+    # heavy ties: the chunk is re-enqueued on the single-query pipeline, blocks stay exact
+    base = O.synth_rows(0x71E7, 0, 0, 4, W)
+    tied = np.ascontiguousarray(base[np.random.default_rng(9).integers(0, 4, size=50_000)])
+    tt = make_table(tied)
+    tt.set_stream(stream)
+    q2 = np.stack([base[i % 4] for i in range(64)])
+    buf = torch.zeros(64 * blk, dtype=torch.uint8, device="cuda:0")
+    tt.search_batch_device(q2, k, buf.data_ptr(), 0.0)
+    torch.cuda.synchronize()
+    raw = buf.cpu().numpy().tobytes()
+    for i in (0, 1, 2, 3, 63):
+        hits, approx, _ = capi.parse_result_block(raw[i * blk:(i + 1) * blk], k)
+        want, wap = O.search(q2[i], tied, k, 0.0, nthreads=8)
+        assert approx == wap
+        assert_hits_equal(hits, want, "batch device fallback q=%d" % i)
+    torch.cuda.set_stream(torch.cuda.default_stream(0))
