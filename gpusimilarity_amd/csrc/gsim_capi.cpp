@@ -476,13 +476,14 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
 }
 
 // Enqueue nq (<= kBatchMaxQ) queries on one shard: ceil(nq / kBQ) passes over the table (one on the
-// matrix cores), the result blocks land in `results` (pinned host or device memory).  No host
-// synchronisation.
+// matrix cores), the result blocks land in `results` (device memory; NULL = the shard's pinned host
+// block array s.h_bresult).  No host synchronisation.
 int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
                   float alpha, float beta, uint32_t row_base, void* results)
 {
     int rc = ensure_batch_buffers(db, s, k);
     if (rc != GSIM_OK) return rc;
+    if (!results) results = s.h_bresult; // (allocated or grown just above)
     GSIM_HIP(hipSetDevice(s.device));
     const size_t qbytes = static_cast<size_t>(nq) * s.W * 4;
     std::memcpy(s.h_bqueries, queries, qbytes);
@@ -1027,7 +1028,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             for (auto& s : db->shards) {
                 if (s.nrows == 0) continue;
                 rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta,
-                                   db->row_base + static_cast<uint32_t>(s.first_row), s.h_bresult);
+                                   db->row_base + static_cast<uint32_t>(s.first_row), nullptr);
                 if (rc != GSIM_OK) return rc;
             }
             bool overflow = false;
