@@ -110,6 +110,7 @@ struct Shard {
     uint32_t* h_bflags = nullptr;
     uint32_t* h_bqueries = nullptr; // pinned staging: queries + popcounts
     unsigned char* h_bresult = nullptr;
+    unsigned char* d_bresult = nullptr; // the select kernel writes here; one bulk copy to h_bresult
     size_t h_bresult_bytes = 0;
 };
 
@@ -168,6 +169,7 @@ int free_shard(Shard& s)
     if (s.h_bflags) (void) hipHostFree(s.h_bflags);
     if (s.h_bqueries) (void) hipHostFree(s.h_bqueries);
     if (s.h_bresult) (void) hipHostFree(s.h_bresult);
+    if (s.d_bresult) (void) hipFree(s.d_bresult);
     for (auto e : s.ev) (void) hipEventDestroy(e);
     for (auto e : s.q_ev) (void) hipEventDestroy(e);
     if (s.own_stream) (void) hipStreamDestroy(s.own_stream);
@@ -468,8 +470,11 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
     const size_t need = gsim_result_block_bytes(k) * kBatchMaxQ;
     if (need > s.h_bresult_bytes) {
         if (s.h_bresult) GSIM_HIP(hipHostFree(s.h_bresult));
+        if (s.d_bresult) GSIM_HIP(hipFree(s.d_bresult));
         s.h_bresult = nullptr;
+        s.d_bresult = nullptr;
         GSIM_HIP(hipHostMalloc(&s.h_bresult, need, hipHostMallocDefault));
+        GSIM_HIP(hipMalloc(&s.d_bresult, need));
         s.h_bresult_bytes = need;
     }
     return GSIM_OK;
@@ -477,13 +482,16 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
 
 // Enqueue nq (<= kBatchMaxQ) queries on one shard: ceil(nq / kBQ) passes over the table (one on the
 // matrix cores), the result blocks land in `results` (device memory; NULL = the shard's pinned host
-// block array s.h_bresult).  No host synchronisation.
+// block array s.h_bresult, through s.d_bresult).  No host synchronisation.
 int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
                   float alpha, float beta, uint32_t row_base, void* results)
 {
     int rc = ensure_batch_buffers(db, s, k);
     if (rc != GSIM_OK) return rc;
-    if (!results) results = s.h_bresult; // (allocated or grown just above)
+    // NULL: blocks go to device memory and then, in one copy, to the pinned array (256 blocks of
+    // 12 KB written by the select kernel straight over PCIe cost ~5 ms per batch)
+    const bool to_host = results == nullptr;
+    if (to_host) results = s.d_bresult; // (allocated or grown just above)
     GSIM_HIP(hipSetDevice(s.device));
     const size_t qbytes = static_cast<size_t>(nq) * s.W * 4;
     std::memcpy(s.h_bqueries, queries, qbytes);
@@ -528,6 +536,8 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         a.nq = nq;
         GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, results,
                                               gsim_result_block_bytes(k), s.stream));
+        if (to_host)
+            GSIM_HIP(hipMemcpyAsync(s.h_bresult, s.d_bresult, gsim_result_block_bytes(k) * nq, hipMemcpyDeviceToHost, s.stream));
         GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
         return GSIM_OK;
     }
@@ -537,6 +547,8 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         GSIM_HIP(gsim::launch_batch_pass(a, rr, s.bgeo, sample, row_base, results, gsim_result_block_bytes(k),
                                          s.stream));
     }
+    if (to_host)
+        GSIM_HIP(hipMemcpyAsync(s.h_bresult, s.d_bresult, gsim_result_block_bytes(k) * nq, hipMemcpyDeviceToHost, s.stream));
     GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
     return GSIM_OK;
 }

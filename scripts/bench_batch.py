@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE config 5 on one GPU: Tversky(0.3, 0.7), 2048-bit fingerprints, 256-query batches,
-top-1000.  This configuration is VALU-bound (2 VALU ops per 32-bit word per (query, row)
-pair), so it is reported as pairs/s, as a fraction of the v_and/v_bcnt issue rate, and as
-"effective" bytes (Q x table bytes / time) next to the real HBM traffic (passes x table)."""
+top-1000.  With Q >= 64 the pass runs on the matrix cores (gsim_batch_mfma.hip): reported as
+pairs/s, as 0/1 multiply-adds per second against the dense MX-FP4 MFMA peak, and as "effective"
+bytes (Q x table bytes / time) next to the real HBM traffic (the table is read once per batch).
+GSIM_BATCH_MFMA_MIN_Q=0 in the environment selects the VALU pass (32 queries per table pass)."""
 import json
 import os
 import sys
@@ -37,12 +38,21 @@ t1 = time.perf_counter()
 t.search(qs[:4], K, 0.0, **kw)
 single = (time.perf_counter() - t1) / 4
 pairs = Q * N / el
-valu_ops = pairs * (2 * W)               # v_and + v_bcnt per word
-peak_lane_ops = 256 * 4 * 32 * 2.4e9     # CUs x SIMDs x 32 lanes/clk x 2.4 GHz (MI355X_MICROARCH.md: 2 cyc per wave64 VALU op)
-print(json.dumps({
+mfma = int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "64")) > 0 and Q >= int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "64")) and W in (32, 64)
+passes = 1 if mfma else (Q + 31) // 32
+out = {
     "config": "Tversky(0.3,0.7) %d-bit, %d-query batch, top-%d, %d rows, 1 GPU" % (BITS, Q, K, N),
+    "pass": "matrix cores (MX-FP4 MFMA)" if mfma else "VALU (v_and + v_bcnt)",
     "batch_s": el, "pairs_per_s": pairs, "queries_per_s": Q / el,
-    "valu_lane_ops_per_s": valu_ops, "frac_of_valu_issue_peak": valu_ops / peak_lane_ops,
     "effective_GBs": Q * N * (BITS // 8) / el / 1e9,
-    "hbm_GBs": ((Q + 31) // 32) * N * (BITS // 8) / el / 1e9,
-    "single_query_path_s_per_query": single, "speedup_vs_single_query_path": single * Q / el}))
+    "hbm_GBs": passes * N * (BITS // 8) / el / 1e9,
+    "single_query_path_s_per_query": single, "speedup_vs_single_query_path": single * Q / el}
+if mfma:
+    out["mfma_TFLOPs_equivalent"] = 2.0 * pairs * BITS / 1e12
+    out["frac_of_fp4_mfma_peak_10PF"] = out["mfma_TFLOPs_equivalent"] / 10000.0
+else:
+    valu_ops = pairs * (2 * W)            # v_and + v_bcnt per word
+    peak_lane_ops = 256 * 4 * 16 * 2.4e9  # CUs x SIMDs x (64 lanes / 4 cycles: both ops issue in 4 cycles,
+    out["valu_lane_ops_per_s"] = valu_ops  # scripts/valu_op_rate_probe.hip) x 2.4 GHz
+    out["frac_of_valu_issue_peak"] = valu_ops / peak_lane_ops
+print(json.dumps(out))
