@@ -1,9 +1,11 @@
 // gsim_batch.hip -- multi-query scan: Q queries against the table in ceil(Q / kBQ) passes.
 //
-// BASELINE config 5 (Tversky, 2048-bit, 256-query batches) is not HBM-bound: with Q
-// queries per table pass the work per fingerprint is Q * (2 * W) VALU operations
-// (v_and + v_bcnt_u32_b32 per 32-bit word), i.e. the bound is the VALU issue rate,
-// not memory.  So the layout is turned around relative to the
+// A batch of queries is not HBM-bound: with Q queries per table pass the work per
+// fingerprint is Q * (2 * W) VALU operations (v_and + v_bcnt_u32_b32 per 32-bit word),
+// i.e. the bound is the VALU issue rate, not memory.  This is the
+// pass for 4 <= Q < 64 queries, any cutoff and any supported width (larger batches of
+// 1024/2048-bit rows without a cutoff: gsim_batch_mfma.hip), and its SAMPLE variant sets
+// the starting thresholds of both.  The layout is turned around relative to the
 // single-query scan:
 //   * every lane holds ONE whole fingerprint in registers (W VGPRs) -- no cross-lane
 //     reduction at all;
@@ -186,11 +188,12 @@ __global__ __launch_bounds__(kScanBlock) void batch_scan_kernel(BatchArgs a, Sca
         // block) is in flight while the current one is reduced.  Scalar loads return out of
         // order, hence the full lgkmcnt(0) before a buffer is used; sched_barrier keeps the
         // compiler from regrouping the phases.
-        // Measured limits of this form (scripts/valu_pattern_probe.hip): a v_and with a
-        // scalar operand issues at 4 cycles per wave64 instruction instead of 2.1, so the loop is
-        // VALU-bound at roughly half the vector-operand rate; broadcasting the query words into
-        // VGPRs through LDS (ds_read_b128) removes that limit but was LDS-latency-bound at the
-        // same speed in this structure (round-2 work).
+        // Measured limit of this form (scripts/valu_op_rate_probe.hip, scripts/qbcast_probe.hip,
+        // DESIGN.md): v_bcnt_u32_b32 (VOP3) and a v_and with a scalar operand both issue in 4 cycles
+        // per wave64, so the loop runs at the 8 cycles per word-pair ceiling of the instruction
+        // pair; bringing the query words into VGPRs (LDS broadcast, v_mov) only trades the 4-cycle
+        // v_and for a 2-cycle one plus the delivery cost.  Batches of 64+ queries therefore use the
+        // matrix-core pass (gsim_batch_mfma.hip).
         constexpr bool MANUAL = (WORDS % 32 == 0);
         constexpr int NB = WORDS / 16;
         s16 qA, qB;
