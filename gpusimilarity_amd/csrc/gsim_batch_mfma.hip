@@ -69,6 +69,8 @@ struct MfmaShared {
     u32x4 rows[2][kMChunks];
     float kap_a[kMWaves][2][16]; // pre-filter constants in accumulator order: [lane half][acc register]
     float kap_b[kMWaves][2][16];
+    float kap_u[kMWaves][2][16]; // the same bound solved for popc(row): c * u + v >= popc(row)
+    float kap_v[kMWaves][2][16];
     uint32_t tau[kMWaves][32];
     uint32_t qpop[kMWaves][32];
     uint32_t stage_row[kMWaves][kMStage]; // pairs that passed the pre-filter: row, (common << 16) + popc(row),
@@ -172,6 +174,15 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
         const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i
         sh.kap_a[wq][hh][r] = ka;
         sh.kap_b[wq][hh][r] = kb;
+        // c >= ka + kb p - 0.05  <=>  c u + v >= p  with u = 1 / kb, v = (0.05 - ka) u; a vanishing kb
+        // (filter off, beta = 0) passes everything to the exact test, a padding query nothing
+        float u = 0.0f, v = ka > 1.0e38f ? -3.0e38f : 3.0e38f;
+        if (kb > 1.0e-6f && ka < 1.0e4f) { // (beyond: the rounding of c u + v could exceed the 0.05 slack)
+            u = 1.0f / kb;
+            v = (0.05f - ka) * u;
+        }
+        sh.kap_u[wq][hh][r] = u;
+        sh.kap_v[wq][hh][r] = v;
         sh.tau[wq][i] = tau;
     };
     if (lane < 32) {
@@ -311,22 +322,24 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 const float pbf0 = static_cast<float>(pb0), pbf1 = static_cast<float>(pb1);
                 const u64 rowi0 = blk * RB + t2 * 32 + i, rowi1 = rowi0 + 32;
                 // Fast test, vector ALU only (a compare per pair into a scalar mask would stall on the
-                // VALU->SALU dependency 32 times): d = c - kb * popc(row) - ka, maximum over the 16 queries
-                // of the lane; a pair can only pass with d >= 0 up to rounding (|error| << 0.05).
-                float mx0 = -1.0f, mx1 = -1.0f;
+                // VALU->SALU dependency 32 times), two instructions per pair: the bound solved for
+                // popc(row), maximum over the 16 queries of the lane, one compare per tile.
+                const f32x4* kup = reinterpret_cast<const f32x4*>(sh.kap_u[wq][h]);
+                const f32x4* kvp = reinterpret_cast<const f32x4*>(sh.kap_v[wq][h]);
+                float mx0 = -3.0e38f, mx1 = -3.0e38f;
 #pragma unroll
                 for (int r4 = 0; r4 < 4; r4++) {
-                    const f32x4 va = kap[r4], vb = kbp[r4];
+                    const f32x4 vu = kup[r4], vv = kvp[r4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        mx0 = fmaxf(mx0, __builtin_fmaf(-vb[e], pbf0, acc0[4 * r4 + e]) - va[e]);
-                        mx1 = fmaxf(mx1, __builtin_fmaf(-vb[e], pbf1, acc1[4 * r4 + e]) - va[e]);
+                        mx0 = fmaxf(mx0, __builtin_fmaf(acc0[4 * r4 + e], vu[e], vv[e]));
+                        mx1 = fmaxf(mx1, __builtin_fmaf(acc1[4 * r4 + e], vu[e], vv[e]));
                     }
                 }
                 const bool active0 = rowi0 < a.nrows, active1 = rowi1 < a.nrows;
                 // which accumulator registers hold a passing pair (bit r: tile 0, bit 16 + r: tile 1)
                 uint32_t bits = 0, rmask = 0;
-                if (__ballot((active0 && mx0 >= -0.05f) || (active1 && mx1 >= -0.05f)) != 0) {
+                if (__ballot((active0 && mx0 >= pbf0 - 0.01f) || (active1 && mx1 >= pbf1 - 0.01f)) != 0) {
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {
                         const f32x4 va = kap[r4], vb = kbp[r4];
