@@ -101,7 +101,7 @@ MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-FP4, MI355X_MICROARCH.md (measured 90
 def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k, sharded_path, json_fd):
     """BASELINE configs[4]: Tversky(0.3, 0.7), Q-query batches, top-k per query; a step = one batch.
     Rows shard over the ranks, every rank scores all Q queries against its shard (the matrix-core
-    pass for Q >= 64), ONE all-gather of Q result blocks per step, one merge launch."""
+    pass), ONE all-gather of Q result blocks per step, one merge launch."""
     Q = args.batch_queries
     kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
     nb = args.warmup + args.steps

@@ -6,7 +6,7 @@
 // VALU issue ceiling for v_and + v_bcnt); gfx950's block-scaled MFMA
 // (v_mfma_scale_f32_32x32x64_f8f6f4, both operands FP4/E2M1) does 32 x 32 pairs x 64 bits per
 // instruction -- one eighth of the VALU time per bit -- and accumulates exactly in f32 (the
-// counts are < 2^24).  Only this Q >= 64 batch path uses it; the single-query scan stays a
+// counts are < 2^24).  Only the batch path uses it; the single-query scan stays a
 // streaming HBM-bound kernel.
 //
 // Packed bits -> FP4 operands with ONE v_and per operand dword (scripts/mfma_fp4_probe.hip):
@@ -146,7 +146,13 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     const int i = lane & 31, h = lane >> 5;
     const uint32_t w = blockIdx.x * kMWaves + wq; // candidate segment of this wave
     const int nq = static_cast<int>(a.nq);
-    const bool wave_has_queries = wq * 32 < nq;
+    // Fewer than eight query tiles: several waves share a tile and split the row tiles of a block
+    // between them (tile = wave % p2, row group = wave / p2, p2 = query tiles rounded up to 2^n).
+    const int ntiles = (nq + 31) / 32;
+    const int p2 = ntiles <= 1 ? 1 : (ntiles <= 2 ? 2 : (ntiles <= 4 ? 4 : 8));
+    const int tile = wq % p2, rgroup = wq / p2, ngroups = kMWaves / p2;
+    const int q0t = tile * 32; // first query of this wave's tile
+    const bool wave_has_queries = q0t < nq && rgroup * 2 < NTB;
     // The rare arguments once, into scalar registers; device pointers carry the global address
     // space so that stores and atomics are global_* instructions (a flat_* access may alias LDS and
     // would have to wait for the row block in flight to LDS).
@@ -161,7 +167,7 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     asm volatile("" : "+v"(km.m1), "+v"(km.m2), "+v"(km.m4)); // keep them in VGPRs
     v4i aexp[KG][4];
     {
-        const int ql = wq * 32 + i;
+        const int ql = q0t + i;
         const u32x4* qp = reinterpret_cast<const u32x4*>(a.queries + static_cast<size_t>(a.q0 + ql) * WORDS);
 #pragma unroll
         for (int g = 0; g < KG; g++) {
@@ -174,7 +180,7 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     }
     // per-query constants of this wave (wave-private LDS: no workgroup barrier needed)
     auto set_query_constants = [&](uint32_t tau) { // lanes 0..31: query i of the tile
-        const bool valid = wq * 32 + i < nq;
+        const bool valid = q0t + i < nq;
         float ka, kb;
         prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][i], tau, valid, ka, kb);
         const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i
@@ -192,9 +198,9 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
         sh.tau[wq][i] = tau;
     };
     if (lane < 32) {
-        const bool valid = wq * 32 + i < nq;
-        sh.qpop[wq][i] = valid ? a.qpop[a.q0 + wq * 32 + i] : 0u;
-        set_query_constants(valid ? *((g_u32p) &qstate[wq * 32 + i].gtau) : static_cast<uint32_t>(kBBins));
+        const bool valid = q0t + i < nq;
+        sh.qpop[wq][i] = valid ? a.qpop[a.q0 + q0t + i] : 0u;
+        set_query_constants(valid ? *((g_u32p) &qstate[q0t + i].gtau) : static_cast<uint32_t>(kBBins));
     }
 
     // ---- candidate staging (as in batch_scan_kernel) ---------------------------------------
@@ -226,10 +232,10 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 if (pos < rr.seg_cap) {
                     seg_key[pos] = make_key(sc, row);
                     seg_cb[pos] = cb;
-                    seg_q[pos] = static_cast<uint32_t>(wq * 32) + qi;
+                    seg_q[pos] = static_cast<uint32_t>(q0t) + qi;
                 }
                 // no return value: fire and forget
-                __hip_atomic_fetch_add((g_u32p) &qstate[wq * 32 + qi].ghist[bin], 1u, __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add((g_u32p) &qstate[q0t + qi].ghist[bin], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
             cursor += static_cast<uint32_t>(__popcll(mc));
@@ -279,15 +285,15 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
         // over the workgroups), gets its threshold recomputed from the table-wide histogram of
         // emitted rows.  All updates are monotone (atomicMax).
         uint32_t gt = 0;
-        const int qref = wq * 32 + static_cast<int>((turn >> 2) & 31u);
+        const int qref = q0t + static_cast<int>(((turn >> 2) + rgroup * (32 / ngroups)) & 31u);
         const bool refresh = wave_has_queries && qref < nq && (turn & 3u) == 0;
-        if (wave_has_queries && lane < 32 && wq * 32 + lane < nq)
-            gt = __hip_atomic_load((g_u32p) &qstate[wq * 32 + lane].gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave_has_queries && lane < 32 && q0t + lane < nq)
+            gt = __hip_atomic_load((g_u32p) &qstate[q0t + lane].gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MF_T(tb2);
         MF_ACC(7, tb0, tb2);
         if (wave_has_queries) {
 #pragma unroll 1
-            for (int t2 = 0; t2 < NTB; t2 += 2) {
+            for (int t2 = 2 * rgroup; t2 < NTB; t2 += 2 * ngroups) {
                 MF_T(tk0);
                 v16f acc0 = {}, acc1 = {};
                 uint32_t pb0 = 0, pb1 = 0;

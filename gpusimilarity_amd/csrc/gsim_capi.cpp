@@ -527,9 +527,10 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     a.alpha = alpha;
     a.beta = beta;
     const uint32_t sample = static_cast<uint32_t>(env_int("GSIM_BATCH_SAMPLE_CHUNKS", 8));
-    // enough queries to fill matrix-core tiles: one contraction pass for all of them
-    // (gsim_batch_mfma.hip); counts of rows above a cutoff are only kept by the VALU pass
-    static const int mfma_min_q = env_int("GSIM_BATCH_MFMA_MIN_Q", 64);
+    // one contraction pass on the matrix cores for all of them (gsim_batch_mfma.hip: with fewer
+    // than 8 x 32 queries the waves of a workgroup share query tiles and split the rows); counts of
+    // rows above a cutoff are only kept by the VALU pass
+    static const int mfma_min_q = env_int("GSIM_BATCH_MFMA_MIN_Q", 4);
     if (mfma_min_q > 0 && nq >= static_cast<uint32_t>(mfma_min_q) && nq <= static_cast<uint32_t>(gsim::kMfmaQueries) &&
         !(cutoff > 0.0f) && gsim::batch_mfma_supported(s.W)) {
         a.q0 = 0;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 5 on one GPU: Tversky(0.3, 0.7), 2048-bit fingerprints, 256-query batches,
-top-1000.  With Q >= 64 the pass runs on the matrix cores (gsim_batch_mfma.hip): reported as
+top-1000.  The pass runs on the matrix cores (gsim_batch_mfma.hip): reported as
 pairs/s, as 0/1 multiply-adds per second against the dense MX-FP4 MFMA peak, and as "effective"
 bytes (Q x table bytes / time) next to the real HBM traffic (the table is read once per batch).
 GSIM_BATCH_MFMA_MIN_Q=0 in the environment selects the VALU pass (32 queries per table pass)."""
@@ -38,7 +38,7 @@ t1 = time.perf_counter()
 t.search(qs[:4], K, 0.0, **kw)
 single = (time.perf_counter() - t1) / 4
 pairs = Q * N / el
-mfma = int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "64")) > 0 and Q >= int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "64")) and W in (32, 64)
+mfma = int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "4")) > 0 and Q >= int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "4")) and W in (32, 64)
 passes = 1 if mfma else (Q + 31) // 32
 out = {
     "config": "Tversky(0.3,0.7) %d-bit, %d-query batch, top-%d, %d rows, 1 GPU" % (BITS, Q, K, N),

@@ -495,8 +495,10 @@ def batch_check(t, db, qs, k, cutoff=0.0, ctx="", **kw):
 @pytest.mark.parametrize("W,kind,n", [(64, 0, 150_000), (32, 0, 200_000), (32, 1, 120_000), (16, 0, 90_000),
                                       (8, 1, 50_000), (4, 0, 40_000)])
 def test_multi_query_pass_matches_single_query_results(W, kind, n):
-    """The VALU-bound multi-query kernels (kBQ = 32 queries per table pass): identical
-    results to the oracle for every query, several passes (70 queries = 32 + 32 + 6)."""
+    """Multi-query passes, 70 queries: identical results to the oracle for every query.  128..512-bit
+    rows and the cutoff case take the VALU pass (kBQ = 32 queries per table pass: 32 + 32 + 6), 1024
+    and 2048-bit rows without a cutoff the matrix-core pass (the VALU pass on those:
+    test_valu_pass_on_wide_rows_without_cutoff)."""
     db = O.synth_rows(0xBA7C0 + W, kind, 0, n, W)
     t = make_table(db)
     qs = np.stack([db[O.query_row(i, n)] for i in range(66)] +
@@ -543,7 +545,7 @@ def test_multi_query_pass_fallbacks():
 
 
 # ---------------------------------------------------------------------------
-# multi-query pass on the matrix cores (gsim_batch_mfma.hip): >= 64 queries, cutoff <= 0,
+# multi-query pass on the matrix cores (gsim_batch_mfma.hip): cutoff <= 0,
 # 1024- and 2048-bit rows
 # ---------------------------------------------------------------------------
 
@@ -686,3 +688,17 @@ def test_batch_device_blocks_and_batched_merge():
         assert approx == wap
         assert_hits_equal(hits, want, "batch device fallback q=%d" % i)
     torch.cuda.set_stream(torch.cuda.default_stream(0))
+
+
+def test_valu_pass_on_wide_rows_without_cutoff():
+    """GSIM_BATCH_MFMA_MIN_Q=0 (read once per process, hence the child process) routes 1024/2048-bit
+    batches without a cutoff through the VALU pass: it must stay exact too."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSIM_BATCH_MFMA_MIN_Q="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "test_multi_query_pass_matches_single_query_results and (64-0 or 32-1) or "
+                        "test_multi_query_pass_large_table_with_sampling"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout, r.stdout[-500:]
