@@ -36,6 +36,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
 
@@ -52,6 +54,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMWaves = 8;             // waves per workgroup = query tiles per pass
 constexpr int kMBlock = kMWaves * 64;  // threads
 constexpr int kMChunks = 4096;         // 16-byte chunks per LDS row block (64 KB, two buffers)
+constexpr int kMaxMT = 2;              // query tiles per wave (2 for 1024-bit rows: halves the operand work)
 constexpr int kMStage = 128;           // raw candidates staged per wave (processed in bulk above 64)
 
 // GSIM_MF_TIMING: per-phase cycle counters of wave 0 of every workgroup, summed into flags[2..]
@@ -73,12 +76,13 @@ constexpr int kScaleM = 0x7E7E7E7E;  // 2^-1
 
 struct MfmaShared {
     u32x4 rows[2][kMChunks];
-    float kap_a[kMWaves][2][16]; // pre-filter constants in accumulator order: [lane half][acc register]
-    float kap_b[kMWaves][2][16];
-    float kap_u[kMWaves][2][16]; // the same bound solved for popc(row): c * u + v >= popc(row)
-    float kap_v[kMWaves][2][16];
-    uint32_t tau[kMWaves][32];
-    uint32_t qpop[kMWaves][32];
+    // pre-filter constants in accumulator order: [query tile of the wave][lane half][acc register]
+    float kap_a[kMWaves][kMaxMT][2][16];
+    float kap_b[kMWaves][kMaxMT][2][16];
+    float kap_u[kMWaves][kMaxMT][2][16]; // the same bound solved for popc(row): c * u + v >= popc(row)
+    float kap_v[kMWaves][kMaxMT][2][16];
+    uint32_t tau[kMWaves][32 * kMaxMT];
+    uint32_t qpop[kMWaves][32 * kMaxMT];
     uint32_t stage_row[kMWaves][kMStage]; // pairs that passed the pre-filter: row, (common << 16) + popc(row),
     uint32_t stage_cb[kMWaves][kMStage];  // query of the tile -- scored exactly in bulk (drain_stage)
     uint32_t stage_q[kMWaves][kMStage];
@@ -131,14 +135,19 @@ __device__ __forceinline__ void prefilter_constants(int metric, float alpha, flo
     kb = f * be;
 }
 
-template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
+// MT = query tiles per wave: the expanded row operand of a tile is used by MT MFMAs per class, so
+// the operand work per MFMA is 5 / MT instructions; 2 W MT registers hold the queries.
+template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
 {
+    constexpr int QW = 32 * MT;         // queries per wave
+    constexpr int NT = MT == 1 ? 2 : 1; // row tiles in flight per wave (accumulators: 16 MT NT registers)
     constexpr int KG = WORDS / 8;       // 256-bit groups per row
     constexpr int CPR = WORDS / 4;      // 16-byte chunks per row
     constexpr int RPLN = 16 / CPR;      // rows per 256-byte LDS line
     constexpr int RB = kMChunks / CPR;  // rows per LDS block
     constexpr int NTB = RB / 32;        // 32-row tiles per block
     static_assert(WORDS % 8 == 0 && CPR <= 16 && NTB >= 2 && NTB % 2 == 0, "unsupported row width");
+    static_assert(MT >= 1 && MT <= kMaxMT && 2 * WORDS * MT <= 128, "query operands must fit in registers");
     __shared__ MfmaShared sh;
 
     const int lane = threadIdx.x & 63;
@@ -148,11 +157,11 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     const int nq = static_cast<int>(a.nq);
     // Fewer than eight query tiles: several waves share a tile and split the row tiles of a block
     // between them (tile = wave % p2, row group = wave / p2, p2 = query tiles rounded up to 2^n).
-    const int ntiles = (nq + 31) / 32;
+    const int ntiles = (nq + QW - 1) / QW;
     const int p2 = ntiles <= 1 ? 1 : (ntiles <= 2 ? 2 : (ntiles <= 4 ? 4 : 8));
     const int tile = wq % p2, rgroup = wq / p2, ngroups = kMWaves / p2;
-    const int q0t = tile * 32; // first query of this wave's tile
-    const bool wave_has_queries = q0t < nq && rgroup * 2 < NTB;
+    const int q0t = tile * QW; // first query of this wave's tile(s)
+    const bool wave_has_queries = q0t < nq && rgroup * NT < NTB;
     // The rare arguments once, into scalar registers; device pointers carry the global address
     // space so that stores and atomics are global_* instructions (a flat_* access may alias LDS and
     // would have to wait for the row block in flight to LDS).
@@ -165,27 +174,29 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
     // ---- A operand: this wave's 32 queries, expanded once ----------------------------------
     ClassMasks km{0x11111111u, 0x22222222u, 0x44444444u};
     asm volatile("" : "+v"(km.m1), "+v"(km.m2), "+v"(km.m4)); // keep them in VGPRs
-    v4i aexp[KG][4];
-    {
-        const int ql = q0t + i;
+    v4i aexp[MT][KG][4];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const int ql = q0t + m * 32 + i;
         const u32x4* qp = reinterpret_cast<const u32x4*>(a.queries + static_cast<size_t>(a.q0 + ql) * WORDS);
 #pragma unroll
         for (int g = 0; g < KG; g++) {
             const u32x4 x = ql < nq ? qp[2 * g + h] : u32x4{0, 0, 0, 0};
-            aexp[g][0] = fp4_class<0>(x, km);
-            aexp[g][1] = fp4_class<1>(x, km);
-            aexp[g][2] = fp4_class<2>(x, km);
-            aexp[g][3] = fp4_class<3>(x, km);
+            aexp[m][g][0] = fp4_class<0>(x, km);
+            aexp[m][g][1] = fp4_class<1>(x, km);
+            aexp[m][g][2] = fp4_class<2>(x, km);
+            aexp[m][g][3] = fp4_class<3>(x, km);
         }
     }
     // per-query constants of this wave (wave-private LDS: no workgroup barrier needed)
-    auto set_query_constants = [&](uint32_t tau) { // lanes 0..31: query i of the tile
-        const bool valid = q0t + i < nq;
+    auto set_query_constants = [&](uint32_t tau) { // lanes 0..QW-1: query `lane` of the wave
+        const int m = lane >> 5;
+        const bool valid = q0t + lane < nq;
         float ka, kb;
-        prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][i], tau, valid, ka, kb);
-        const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i
-        sh.kap_a[wq][hh][r] = ka;
-        sh.kap_b[wq][hh][r] = kb;
+        prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][lane], tau, valid, ka, kb);
+        const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i of a tile
+        sh.kap_a[wq][m][hh][r] = ka;
+        sh.kap_b[wq][m][hh][r] = kb;
         // c >= ka + kb p - 0.05  <=>  c u + v >= p  with u = 1 / kb, v = (0.05 - ka) u; a vanishing kb
         // (filter off, beta = 0) passes everything to the exact test, a padding query nothing
         float u = 0.0f, v = ka > 1.0e38f ? -3.0e38f : 3.0e38f;
@@ -193,14 +204,14 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
             u = 1.0f / kb;
             v = (0.05f - ka) * u;
         }
-        sh.kap_u[wq][hh][r] = u;
-        sh.kap_v[wq][hh][r] = v;
-        sh.tau[wq][i] = tau;
+        sh.kap_u[wq][m][hh][r] = u;
+        sh.kap_v[wq][m][hh][r] = v;
+        sh.tau[wq][lane] = tau;
     };
-    if (lane < 32) {
-        const bool valid = q0t + i < nq;
-        sh.qpop[wq][i] = valid ? a.qpop[a.q0 + q0t + i] : 0u;
-        set_query_constants(valid ? *((g_u32p) &qstate[q0t + i].gtau) : static_cast<uint32_t>(kBBins));
+    if (lane < QW) {
+        const bool valid = q0t + lane < nq;
+        sh.qpop[wq][lane] = valid ? a.qpop[a.q0 + q0t + lane] : 0u;
+        set_query_constants(valid ? *((g_u32p) &qstate[q0t + lane].gtau) : static_cast<uint32_t>(kBBins));
     }
 
     // ---- candidate staging (as in batch_scan_kernel) ---------------------------------------
@@ -285,123 +296,163 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
         // over the workgroups), gets its threshold recomputed from the table-wide histogram of
         // emitted rows.  All updates are monotone (atomicMax).
         uint32_t gt = 0;
-        const int qref = q0t + static_cast<int>(((turn >> 2) + rgroup * (32 / ngroups)) & 31u);
+        const int qref = q0t + static_cast<int>(((turn >> 2) + rgroup * (QW / ngroups)) & (QW - 1));
         const bool refresh = wave_has_queries && qref < nq && (turn & 3u) == 0;
-        if (wave_has_queries && lane < 32 && q0t + lane < nq)
+        if (wave_has_queries && lane < QW && q0t + lane < nq)
             gt = __hip_atomic_load((g_u32p) &qstate[q0t + lane].gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MF_T(tb2);
         MF_ACC(7, tb0, tb2);
         if (wave_has_queries) {
 #pragma unroll 1
-            for (int t2 = 2 * rgroup; t2 < NTB; t2 += 2 * ngroups) {
+            for (int t2 = NT * rgroup; t2 < NTB; t2 += NT * ngroups) {
                 MF_T(tk0);
-                v16f acc0 = {}, acc1 = {};
-                uint32_t pb0 = 0, pb1 = 0;
-                const int row0 = t2 * 32 + i, row1 = row0 + 32;
-                const int line0 = row0 / RPLN, line1 = row1 / RPLN;
-                const u32x4* l0 = &sh.rows[buf][line0 * 16 + (row0 % RPLN) * CPR];
-                const u32x4* l1 = &sh.rows[buf][line1 * 16 + (row1 % RPLN) * CPR];
-                const int x0 = line0 % CPR, x1 = line1 % CPR;
+                v16f acc[MT][NT];
+                uint32_t pb[NT];
+                const u32x4* lrow[NT];
+                int xr[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; tt++) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++) acc[m][tt] = v16f{};
+                    pb[tt] = 0;
+                    const int row = (t2 + tt) * 32 + i;
+                    const int line = row / RPLN;
+                    lrow[tt] = &sh.rows[buf][line * 16 + (row % RPLN) * CPR];
+                    xr[tt] = line % CPR;
+                }
 #pragma unroll
                 for (int g = 0; g < KG; g++) {
-                    const u32x4 b0 = l0[(2 * g + h) ^ x0];
-                    const u32x4 b1 = l1[(2 * g + h) ^ x1];
-                    pb0 = bcnt_acc(b0.x, pb0);
-                    pb0 = bcnt_acc(b0.y, pb0);
-                    pb0 = bcnt_acc(b0.z, pb0);
-                    pb0 = bcnt_acc(b0.w, pb0);
-                    pb1 = bcnt_acc(b1.x, pb1);
-                    pb1 = bcnt_acc(b1.y, pb1);
-                    pb1 = bcnt_acc(b1.z, pb1);
-                    pb1 = bcnt_acc(b1.w, pb1);
-                    acc0 = mfma_class<0>(aexp[g][0], fp4_class<0>(b0, km), acc0);
-                    acc1 = mfma_class<0>(aexp[g][0], fp4_class<0>(b1, km), acc1);
-                    acc0 = mfma_class<1>(aexp[g][1], fp4_class<1>(b0, km), acc0);
-                    acc1 = mfma_class<1>(aexp[g][1], fp4_class<1>(b1, km), acc1);
-                    acc0 = mfma_class<2>(aexp[g][2], fp4_class<2>(b0, km), acc0);
-                    acc1 = mfma_class<2>(aexp[g][2], fp4_class<2>(b1, km), acc1);
-                    acc0 = mfma_class<3>(aexp[g][3], fp4_class<3>(b0, km), acc0);
-                    acc1 = mfma_class<3>(aexp[g][3], fp4_class<3>(b1, km), acc1);
+                    u32x4 b[NT];
+#pragma unroll
+                    for (int tt = 0; tt < NT; tt++) {
+                        b[tt] = lrow[tt][(2 * g + h) ^ xr[tt]];
+                        pb[tt] = bcnt_acc(b[tt].x, pb[tt]);
+                        pb[tt] = bcnt_acc(b[tt].y, pb[tt]);
+                        pb[tt] = bcnt_acc(b[tt].z, pb[tt]);
+                        pb[tt] = bcnt_acc(b[tt].w, pb[tt]);
+                    }
+                    // the expanded row operand of a class is used by all MT query tiles
+#define GSIM_MFMA_CLASS(C)                                                                         \
+    {                                                                                              \
+        v4i e[NT];                                                                                 \
+        _Pragma("unroll") for (int tt = 0; tt < NT; tt++) e[tt] = fp4_class<C>(b[tt], km);         \
+        _Pragma("unroll") for (int m = 0; m < MT; m++)                                             \
+            _Pragma("unroll") for (int tt = 0; tt < NT; tt++)                                      \
+                acc[m][tt] = mfma_class<C>(aexp[m][g][C], e[tt], acc[m][tt]);                       \
+    }
+                    GSIM_MFMA_CLASS(0)
+                    GSIM_MFMA_CLASS(1)
+                    GSIM_MFMA_CLASS(2)
+                    GSIM_MFMA_CLASS(3)
+#undef GSIM_MFMA_CLASS
+                    // keep the 256-bit groups apart: with MT = 2 hipcc otherwise expands the row operands
+                    // of all groups first (64 more live registers, spills inside the tile loop)
+                    if (MT > 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (MT > 1) {
+                    // all accumulators are complete HERE: without this hipcc sinks the MFMA chain of the
+                    // second query tile below the epilogue of the first and keeps every expanded row
+                    // operand alive for it
+#pragma unroll
+                    for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]));
                 }
                 MF_T(tk1);
                 MF_ACC(0, tk0, tk1);
-                pb0 += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb0), 32, 64));
-                pb1 += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb1), 32, 64));
+                float pbf[NT];
+                bool active[NT];
+                u64 rowi[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; tt++) {
+                    pb[tt] += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb[tt]), 32, 64));
+                    pbf[tt] = static_cast<float>(pb[tt]);
+                    rowi[tt] = blk * RB + (t2 + tt) * 32 + i;
+                    active[tt] = rowi[tt] < a.nrows;
+                }
 
                 // ---- epilogue: linear pre-filter, exact path only for tiles with a passing pair ----
-                const f32x4* kap = reinterpret_cast<const f32x4*>(sh.kap_a[wq][h]);
-                const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][h]);
-                const float pbf0 = static_cast<float>(pb0), pbf1 = static_cast<float>(pb1);
-                const u64 rowi0 = blk * RB + t2 * 32 + i, rowi1 = rowi0 + 32;
-                // Fast test, vector ALU only (a compare per pair into a scalar mask would stall on the
-                // VALU->SALU dependency 32 times), two instructions per pair: the bound solved for
-                // popc(row), maximum over the 16 queries of the lane, one compare per tile.
-                const f32x4* kup = reinterpret_cast<const f32x4*>(sh.kap_u[wq][h]);
-                const f32x4* kvp = reinterpret_cast<const f32x4*>(sh.kap_v[wq][h]);
-                float mx0 = -3.0e38f, mx1 = -3.0e38f;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const f32x4 vu = kup[r4], vv = kvp[r4];
+                for (int m = 0; m < MT; m++) {
+                    // Fast test, vector ALU only (a compare per pair into a scalar mask would stall on
+                    // the VALU->SALU dependency 32 times), two instructions per pair: the bound solved
+                    // for popc(row), maximum over the 16 queries of the lane, one compare per tile.
+                    const f32x4* kup = reinterpret_cast<const f32x4*>(sh.kap_u[wq][m][h]);
+                    const f32x4* kvp = reinterpret_cast<const f32x4*>(sh.kap_v[wq][m][h]);
+                    float mx[NT];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        mx0 = fmaxf(mx0, __builtin_fmaf(acc0[4 * r4 + e], vu[e], vv[e]));
-                        mx1 = fmaxf(mx1, __builtin_fmaf(acc1[4 * r4 + e], vu[e], vv[e]));
-                    }
-                }
-                const bool active0 = rowi0 < a.nrows, active1 = rowi1 < a.nrows;
-                // which accumulator registers hold a passing pair (bit r: tile 0, bit 16 + r: tile 1)
-                uint32_t bits = 0, rmask = 0;
-                if (__ballot((active0 && mx0 >= pbf0 - 0.01f) || (active1 && mx1 >= pbf1 - 0.01f)) != 0) {
+                    for (int tt = 0; tt < NT; tt++) mx[tt] = -3.0e38f;
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {
-                        const f32x4 va = kap[r4], vb = kbp[r4];
+                        const f32x4 vu = kup[r4], vv = kvp[r4];
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const int r = 4 * r4 + e;
-                            bits |= (acc0[r] >= __builtin_fmaf(vb[e], pbf0, va[e])) ? (1u << r) : 0u;
-                            bits |= (acc1[r] >= __builtin_fmaf(vb[e], pbf1, va[e])) ? (1u << (16 + r)) : 0u;
+#pragma unroll
+                            for (int tt = 0; tt < NT; tt++)
+                                mx[tt] = fmaxf(mx[tt], __builtin_fmaf(acc[m][tt][4 * r4 + e], vu[e], vv[e]));
                         }
                     }
-                    if (!active0) bits &= 0xFFFF0000u;
-                    if (!active1) bits &= 0x0000FFFFu;
-                    uint32_t o = bits; // OR over the wavefront
-                    o |= dpp<0xB1>(o);
-                    o |= dpp<0x4E>(o);
-                    o |= dpp<0x141>(o);
-                    o |= dpp<0x140>(o);
-                    o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 16, 64));
-                    o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 32, 64));
-                    rmask = __builtin_amdgcn_readfirstlane(o);
+                    bool any = false;
+#pragma unroll
+                    for (int tt = 0; tt < NT; tt++) any = any || (active[tt] && mx[tt] >= pbf[tt] - 0.01f);
+                    // which accumulator registers hold a passing pair (bit 16 tt + r: row tile tt)
+                    uint32_t bits = 0, rmask = 0;
+                    if (__ballot(any) != 0) {
+                        const f32x4* kap = reinterpret_cast<const f32x4*>(sh.kap_a[wq][m][h]);
+                        const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][m][h]);
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const f32x4 va = kap[r4], vb = kbp[r4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const int r = 4 * r4 + e;
+#pragma unroll
+                                for (int tt = 0; tt < NT; tt++)
+                                    bits |= (active[tt] && acc[m][tt][r] >= __builtin_fmaf(vb[e], pbf[tt], va[e]))
+                                                ? (1u << (16 * tt + r))
+                                                : 0u;
+                            }
+                        }
+                        uint32_t o = bits; // OR over the wavefront
+                        o |= dpp<0xB1>(o);
+                        o |= dpp<0x4E>(o);
+                        o |= dpp<0x141>(o);
+                        o |= dpp<0x140>(o);
+                        o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 16, 64));
+                        o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 32, 64));
+                        rmask = __builtin_amdgcn_readfirstlane(o);
+                    }
+                    // rare: stage the pairs that passed
+                    while (rmask) {
+                        const int bit = __builtin_ctz(rmask);
+                        rmask &= rmask - 1;
+                        const int r = bit & 15;
+                        const int tt = NT > 1 ? bit >> 4 : 0;
+                        float cf = acc[m][0][r];
+                        uint32_t pbs = pb[0];
+                        u64 rws = rowi[0];
+                        if (NT > 1 && tt == 1) {
+                            cf = acc[m][NT - 1][r];
+                            pbs = pb[NT - 1];
+                            rws = rowi[NT - 1];
+                        }
+                        const bool pass = (bits >> bit) & 1u;
+                        const u64 mp = __ballot(pass);
+                        if (pass) {
+                            const uint32_t slot = staged + lane_rank(mp);
+                            stg_row[slot] = static_cast<uint32_t>(rws);
+                            stg_cb[slot] = (static_cast<uint32_t>(cf) << 16) + pbs;
+                            stg_q[slot] = static_cast<uint32_t>(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h); // query of the wave
+                        }
+                        staged += static_cast<uint32_t>(__popcll(mp));
+                        if (staged > 64) {
+                            MF_T(td0);
+                            drain_stage();
+                            MF_T(td1);
+                            MF_ACC(8, td0, td1);
+                        }
+                    }
                 }
                 MF_T(tk2);
                 MF_ACC(1, tk1, tk2);
-                // rare: stage the pairs that passed
-                while (rmask) {
-                    const int bit = __builtin_ctz(rmask);
-                    rmask &= rmask - 1;
-                    const int r = bit & 15;
-                    const bool second = bit >= 16;
-                    const float cf = second ? acc1[r] : acc0[r];
-                    const uint32_t pb = second ? pb1 : pb0;
-                    const u64 rowi = second ? rowi1 : rowi0;
-                    const bool pass = (bits >> bit) & 1u;
-                    const u64 mp = __ballot(pass);
-                    if (pass) {
-                        const uint32_t slot = staged + lane_rank(mp);
-                        stg_row[slot] = static_cast<uint32_t>(rowi);
-                        stg_cb[slot] = (static_cast<uint32_t>(cf) << 16) + pb;
-                        stg_q[slot] = static_cast<uint32_t>((r & 3) + 8 * (r >> 2) + 4 * h); // query of the tile
-                    }
-                    staged += static_cast<uint32_t>(__popcll(mp));
-                    if (staged > 64) {
-                        MF_T(td0);
-                        drain_stage();
-                        MF_T(td1);
-                        MF_ACC(8, td0, td1);
-                    }
-                }
-                MF_T(tk3);
-                MF_ACC(6, tk2, tk3);
             }
             MF_T(tr0);
             if (refresh) {
@@ -426,10 +477,10 @@ template <int WORDS> __global__ __launch_bounds__(kMBlock) void batch_mfma_kerne
                 if (cnt >= a.k) {
                     if (lane == 0)
                         __hip_atomic_fetch_max((g_u32p) &qstate[qref].gtau, bin_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == (qref & 31) && bin_k > gt) gt = bin_k;
+                    if (lane == (qref & (QW - 1)) && bin_k > gt) gt = bin_k;
                 }
             }
-            if (lane < 32 && gt > sh.tau[wq][lane]) set_query_constants(gt);
+            if (lane < QW && gt > sh.tau[wq][lane]) set_query_constants(gt);
             MF_T(tr9);
             MF_ACC(3, tr0, tr9);
         }
@@ -472,10 +523,16 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
     if (a.nq > static_cast<uint32_t>(kMfmaQueries) || a.cutoff > 0.0f || a.nrows == 0) return hipErrorInvalidValue;
     if (a.W == 64) {
         const u64 nblocks = (a.nrows + (kMChunks / 16) - 1) / (kMChunks / 16);
-        hipLaunchKernelGGL((batch_mfma_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        hipLaunchKernelGGL((batch_mfma_kernel<64, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
     } else if (a.W == 32) {
         const u64 nblocks = (a.nrows + (kMChunks / 8) - 1) / (kMChunks / 8);
-        hipLaunchKernelGGL((batch_mfma_kernel<32>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        static const int mt_env = std::getenv("GSIM_BATCH_MFMA_MT") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_MT")) : 0;
+        // two query tiles per wave halve the operand work: 8 % faster at 256 queries, even at 128,
+        // slower below (fewer row groups per query tile)
+        if (mt_env ? mt_env == 2 : a.nq > 128)
+            hipLaunchKernelGGL((batch_mfma_kernel<32, 2>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        else
+            hipLaunchKernelGGL((batch_mfma_kernel<32, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
     } else {
         return hipErrorInvalidValue;
     }

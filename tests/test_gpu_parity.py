@@ -557,11 +557,13 @@ def _mixed_queries(db, kind, nq, W):
 
 
 @pytest.mark.parametrize("W,kind,n,nq", [(64, 0, 130_001, 256), (32, 0, 90_000, 97), (32, 1, 70_003, 64),
-                                         (64, 1, 40_000, 130), (32, 0, 31, 64), (64, 0, 257, 65)])
+                                         (64, 1, 40_000, 130), (32, 0, 31, 64), (64, 0, 257, 65),
+                                         (32, 0, 50_001, 200), (32, 1, 1_025, 256)])
 def test_matrix_core_pass_matches_oracle(W, kind, n, nq):
     """Every query of a 64..256-query batch: rows, score bits, popcounts and approx identical to the
     oracle -- ragged table sizes (not a multiple of the 256/512-row LDS blocks, smaller than one
-    tile), query counts that leave padding slots in the last 32-query tile."""
+    tile), query counts that leave padding slots in the last 32-query tile; 1024-bit rows with more
+    than 128 queries take the two-query-tiles-per-wave variant."""
     db = O.synth_rows(0x3FA4 + W + n, kind, 0, n, W)
     t = make_table(db)
     qs = _mixed_queries(db, kind, nq, W)
