@@ -539,7 +539,10 @@ hipError_t launch_batch_pass(const BatchArgs& a, const BatchRare& /*rare_host*/,
 hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,
                                   uint32_t row_base, void* results, size_t block_bytes, hipStream_t s)
 {
-    for (uint32_t q0 = 0; q0 < a.nq; q0 += kBQ) {
+    hipError_t es = hipSuccess;
+    const bool sampled = launch_batch_mfma_sample(a, num_cus, s, &es); // large tables: one launch for all queries
+    if (es != hipSuccess) return es;
+    for (uint32_t q0 = 0; !sampled && q0 < a.nq; q0 += kBQ) {
         BatchArgs as = a;
         as.q0 = a.q0 + q0;
         as.nq = a.nq - q0 < static_cast<uint32_t>(kBQ) ? a.nq - q0 : static_cast<uint32_t>(kBQ);

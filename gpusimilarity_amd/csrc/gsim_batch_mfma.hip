@@ -504,6 +504,152 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
     }
 }
 
+// ---- sample pass on the matrix cores ------------------------------------------------------
+// Starting thresholds for all a.nq queries from a strided sample of row blocks: the contraction
+// of the main kernel (one query tile per wave), then EVERY pair of the sampled tiles is scored
+// exactly and counted in a coarse (64-bin) per-query histogram in LDS; the workgroups add their
+// histograms into the table-wide ones (at the lower edge of each coarse bin, so the threshold
+// derived from them is conservative) and the last workgroup turns them into gtau and clears
+// them.  Replaces ceil(nq / 32) launches of the VALU sample kernel (3.3 ms for 256 queries on
+// 2048-bit rows) with one launch of a few hundred microseconds.
+template <int WORDS>
+__global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a, uint32_t nsb, u64 stride_blocks)
+{
+    constexpr int KG = WORDS / 8, CPR = WORDS / 4, RPLN = 16 / CPR, RB = kMChunks / CPR, NTB = RB / 32;
+    constexpr int kCoarseWords = 32; // 64 coarse bins, two 16-bit counters per word
+    __shared__ MfmaShared sh;        // rows[0]: the sampled block, rows[1]: the histograms
+    __shared__ uint32_t s_last;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sh.rows[1]);
+    const int lane = threadIdx.x & 63;
+    const int wq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int nq = static_cast<int>(a.nq);
+    const int ntiles = (nq + 31) / 32;
+    const int p2 = ntiles <= 1 ? 1 : (ntiles <= 2 ? 2 : (ntiles <= 4 ? 4 : 8));
+    const int tile = wq % p2, rgroup = wq / p2, ngroups = kMWaves / p2;
+    const int q0t = tile * 32;
+    const bool wave_has_queries = q0t < nq && rgroup * 2 < NTB;
+    const BatchRare rr = *a.rare;
+    BatchQueryState* qstate = rr.qstate + a.q0;
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    for (int x = threadIdx.x; x < kMfmaQueries * kCoarseWords; x += kMBlock) hist[x] = 0;
+    if (lane < 32) sh.qpop[wq][lane] = q0t + lane < nq ? a.qpop[a.q0 + q0t + lane] : 0u;
+
+    ClassMasks km{0x11111111u, 0x22222222u, 0x44444444u};
+    asm volatile("" : "+v"(km.m1), "+v"(km.m2), "+v"(km.m4));
+    v4i aexp[KG][4];
+    {
+        const int ql = q0t + i;
+        const u32x4* qp = reinterpret_cast<const u32x4*>(a.queries + static_cast<size_t>(a.q0 + ql) * WORDS);
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const u32x4 x = ql < nq ? qp[2 * g + h] : u32x4{0, 0, 0, 0};
+            aexp[g][0] = fp4_class<0>(x, km);
+            aexp[g][1] = fp4_class<1>(x, km);
+            aexp[g][2] = fp4_class<2>(x, km);
+            aexp[g][3] = fp4_class<3>(x, km);
+        }
+    }
+    // row block staging exactly as in batch_mfma_kernel (one buffer)
+    constexpr int RPJ = kMBlock / CPR;
+    const int line0 = wq * 4 + (lane >> 4);
+    const uint32_t rowl0 = static_cast<uint32_t>(line0 * RPLN + (lane & 15) / CPR);
+    const uint32_t chunk0 = static_cast<uint32_t>(((lane & 15) % CPR) ^ (line0 % CPR));
+    const u32x4* dbc = db + chunk0;
+    const uint32_t last_row = static_cast<uint32_t>(a.nrows - 1);
+    __syncthreads();
+
+    for (uint32_t sb = blockIdx.x; sb < nsb; sb += gridDim.x) {
+        const u64 blk = static_cast<u64>(sb) * stride_blocks;
+        const uint32_t first = static_cast<uint32_t>(blk) * RB + rowl0;
+#pragma unroll
+        for (int j = 0; j < kMChunks / kMBlock; j++) {
+            uint32_t grow = first + j * RPJ;
+            grow = grow < last_row ? grow : last_row;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (dbc + static_cast<u64>(grow) * CPR),
+                                             (__attribute__((address_space(3))) void*) (&sh.rows[0][(j * kMWaves + wq) * 64]), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (wave_has_queries) {
+#pragma unroll 1
+            for (int t2 = 2 * rgroup; t2 < NTB; t2 += 2 * ngroups) {
+                v16f acc[2] = {v16f{}, v16f{}};
+                uint32_t pb[2] = {0, 0};
+#pragma unroll
+                for (int g = 0; g < KG; g++) {
+                    u32x4 b[2];
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++) {
+                        const int row = (t2 + tt) * 32 + i;
+                        const int line = row / RPLN;
+                        b[tt] = sh.rows[0][line * 16 + (row % RPLN) * CPR + ((2 * g + h) ^ (line % CPR))];
+                        pb[tt] = bcnt_acc(b[tt].x, pb[tt]);
+                        pb[tt] = bcnt_acc(b[tt].y, pb[tt]);
+                        pb[tt] = bcnt_acc(b[tt].z, pb[tt]);
+                        pb[tt] = bcnt_acc(b[tt].w, pb[tt]);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 2; tt++) {
+                        acc[tt] = mfma_class<0>(aexp[g][0], fp4_class<0>(b[tt], km), acc[tt]);
+                        acc[tt] = mfma_class<1>(aexp[g][1], fp4_class<1>(b[tt], km), acc[tt]);
+                        acc[tt] = mfma_class<2>(aexp[g][2], fp4_class<2>(b[tt], km), acc[tt]);
+                        acc[tt] = mfma_class<3>(aexp[g][3], fp4_class<3>(b[tt], km), acc[tt]);
+                    }
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; tt++) {
+                    pb[tt] += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb[tt]), 32, 64));
+                    const bool active = blk * RB + (t2 + tt) * 32 + i < a.nrows;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        float sc = score_of(a.metric, a.alpha, a.beta, sh.qpop[wq][qi], pb[tt], static_cast<uint32_t>(acc[tt][r]));
+                        sc = apply_cutoff(sc, a.cutoff);
+                        const uint32_t coarse = batch_bin(sc) >> 3;
+                        if (active && q0t + qi < nq)
+                            atomicAdd(&hist[(q0t + qi) * kCoarseWords + (coarse >> 1)], (coarse & 1u) ? 65536u : 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // the next block overwrites rows[0]
+    }
+    // this workgroup's counts into the table-wide histograms
+    for (int x = threadIdx.x; x < nq * kCoarseWords; x += kMBlock) {
+        const uint32_t v = hist[x];
+        if (v == 0) continue;
+        BatchQueryState* gq = &qstate[x / kCoarseWords];
+        const int c0 = 2 * (x % kCoarseWords);
+        if (v & 0xFFFFu) atomicAdd(&gq->ghist[c0 * 8], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&gq->ghist[(c0 + 1) * 8], v >> 16);
+    }
+    // the last workgroup turns every histogram into a starting threshold (as batch_scan_kernel<.., SAMPLE>)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(rr.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int q = wq; q < nq; q += kMWaves) {
+        BatchQueryState* gq = &qstate[q];
+        constexpr int PER = kBBins / 64;
+        uint32_t hh[PER];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int v = 0; v < PER; v++) {
+            hh[v] = __hip_atomic_load(&gq->ghist[lane * PER + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sum += hh[v];
+        }
+        uint32_t bin_k, cnt;
+        threshold_from_counts<PER>(hh, sum, a.k, lane, bin_k, cnt);
+        if (lane == 0) gq->gtau = (a.k && cnt >= a.k) ? bin_k : 0u;
+#pragma unroll
+        for (int v = 0; v < PER; v++) gq->ghist[lane * PER + v] = 0;
+    }
+    if (threadIdx.x == 0) *rr.ticket = 0;
+}
+
 } // namespace
 
 bool batch_mfma_supported(uint32_t W)
@@ -514,6 +660,26 @@ bool batch_mfma_supported(uint32_t W)
 uint32_t batch_mfma_waves(int num_cus)
 {
     return static_cast<uint32_t>(num_cus) * kMWaves;
+}
+
+// Sample pass for all a.nq queries in one launch; false when the table is too small for it (the
+// caller then uses the VALU sample passes, which have their own size rules).
+bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err)
+{
+    static const int enabled = std::getenv("GSIM_BATCH_MFMA_SAMPLE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_SAMPLE")) : 1;
+    *err = hipSuccess;
+    if (!enabled || a.k == 0 || a.nq > static_cast<uint32_t>(kMfmaQueries) || !(a.W == 32 || a.W == 64)) return false;
+    const uint32_t rb = kMChunks / (a.W / 4);
+    const u64 nblocks = (a.nrows + rb - 1) / rb;
+    const uint32_t nsb = (1u << 20) / rb; // about a million sampled rows
+    if (nblocks < 16ull * nsb) return false; // never more than 1/16 of the table
+    const u64 stride = nblocks / nsb;
+    if (a.W == 64)
+        hipLaunchKernelGGL((batch_mfma_sample_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
+    else
+        hipLaunchKernelGGL((batch_mfma_sample_kernel<32>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
+    *err = hipGetLastError();
+    return true;
 }
 
 // The scan of one pass (a.nq <= kMfmaQueries queries from a.q0) for cutoff <= 0; thresholds come

@@ -704,3 +704,25 @@ def test_valu_pass_on_wide_rows_without_cutoff():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "3 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("W,n", [(32, 20_000_000), (64, 17_000_000)])
+def test_matrix_core_sample_pass_thresholds_are_safe(W, n):
+    """Tables large enough for the matrix-core sample kernel (one launch sets the starting thresholds
+    of all queries from ~1 M sampled rows): every query of the batch must return exactly what the
+    single-query pipeline (itself pinned to the oracle) returns -- a threshold that is too high
+    would lose hits."""
+    t = capi.Table(W * 32)
+    t.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
+    own = [O.synth_rows(0x5EED0001, 0, O.query_row(i, n), 1, W)[0] for i in range(70)]
+    fresh = [O.synth_rows(0x5EED0002, 0, 900 + i, 1, W)[0] for i in range(10)]
+    qs = np.stack(own + fresh)
+    for kw in ({}, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))):
+        hits, approx = t.search(qs, 1000, 0.0, **kw)
+        for i in range(len(qs)):
+            one, ap1 = t.search(qs[i], 1000, 0.0, **kw)
+            assert int(approx[i]) == int(ap1[0]) == n
+            assert_hits_equal(hits[i], one[0], "W=%d q=%d %r" % (W, i, sorted(kw)))
+        for i in range(70):
+            assert int(hits[i]["row"][0]) == O.query_row(i, n) and hits[i]["score"][0] == 1.0
+    t.close()
