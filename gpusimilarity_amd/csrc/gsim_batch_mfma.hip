@@ -507,7 +507,7 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
 // ---- sample pass on the matrix cores ------------------------------------------------------
 // Starting thresholds for all a.nq queries from a strided sample of row blocks: the contraction
 // of the main kernel (one query tile per wave), then EVERY pair of the sampled tiles is scored
-// exactly and counted in a coarse (64-bin) per-query histogram in LDS; the workgroups add their
+// exactly and counted in a coarse (128-bin) per-query histogram in LDS; the workgroups add their
 // histograms into the table-wide ones (at the lower edge of each coarse bin, so the threshold
 // derived from them is conservative) and the last workgroup turns them into gtau and clears
 // them.  Replaces ceil(nq / 32) launches of the VALU sample kernel (3.3 ms for 256 queries on
@@ -516,7 +516,9 @@ template <int WORDS>
 __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a, uint32_t nsb, u64 stride_blocks)
 {
     constexpr int KG = WORDS / 8, CPR = WORDS / 4, RPLN = 16 / CPR, RB = kMChunks / CPR, NTB = RB / 32;
-    constexpr int kCoarseWords = 32; // 64 coarse bins, two 16-bit counters per word
+    constexpr int kCoarseWords = 64; // 128 coarse bins, two 16-bit counters per word: 64 KB for 256 queries
+    constexpr int kFinePerCoarse = kBBins / (2 * kCoarseWords);
+    static_assert(kMfmaQueries * kCoarseWords * 4 <= kMChunks * 16, "histograms live in the second row buffer");
     __shared__ MfmaShared sh;        // rows[0]: the sampled block, rows[1]: the histograms
     __shared__ uint32_t s_last;
     uint32_t* hist = reinterpret_cast<uint32_t*>(sh.rows[1]);
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a,
                         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
                         float sc = score_of(a.metric, a.alpha, a.beta, sh.qpop[wq][qi], pb[tt], static_cast<uint32_t>(acc[tt][r]));
                         sc = apply_cutoff(sc, a.cutoff);
-                        const uint32_t coarse = batch_bin(sc) >> 3;
+                        const uint32_t coarse = batch_bin(sc) / kFinePerCoarse;
                         if (active && q0t + qi < nq)
                             atomicAdd(&hist[(q0t + qi) * kCoarseWords + (coarse >> 1)], (coarse & 1u) ? 65536u : 1u);
                     }
@@ -621,8 +623,8 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a,
         if (v == 0) continue;
         BatchQueryState* gq = &qstate[x / kCoarseWords];
         const int c0 = 2 * (x % kCoarseWords);
-        if (v & 0xFFFFu) atomicAdd(&gq->ghist[c0 * 8], v & 0xFFFFu);
-        if (v >> 16) atomicAdd(&gq->ghist[(c0 + 1) * 8], v >> 16);
+        if (v & 0xFFFFu) atomicAdd(&gq->ghist[c0 * kFinePerCoarse], v & 0xFFFFu);
+        if (v >> 16) atomicAdd(&gq->ghist[(c0 + 1) * kFinePerCoarse], v >> 16);
     }
     // the last workgroup turns every histogram into a starting threshold (as batch_scan_kernel<.., SAMPLE>)
     __threadfence();
