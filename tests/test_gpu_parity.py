@@ -726,3 +726,16 @@ def test_matrix_core_sample_pass_thresholds_are_safe(W, n):
         for i in range(70):
             assert int(hits[i]["row"][0]) == O.query_row(i, n) and hits[i]["score"][0] == 1.0
     t.close()
+
+
+@pytest.mark.parametrize("W,n,nq,k", [(32, 50_000, 70, 8192), (64, 30_000, 130, 8192), (64, 300, 256, 300),
+                                      (32, 5, 64, 10)])
+def test_matrix_core_pass_large_k_and_tiny_tables(W, n, nq, k):
+    """k at the multi-query select capacity (8192 finalists per query: queries with more ties fall
+    back) and tables smaller than one row tile."""
+    db = O.synth_rows(0xAD0C + W + n, 0, 0, n, W)
+    t = make_table(db)
+    qs = _mixed_queries(db, 0, nq, W)
+    batch_check(t, db, qs, k, 0.0, ctx="mfma W=%d n=%d nq=%d k=%d" % (W, n, nq, k))
+    batch_check(t, db, qs[:5], k, 0.0, ctx="mfma small batch W=%d n=%d k=%d" % (W, n, k))
+    t.close()
