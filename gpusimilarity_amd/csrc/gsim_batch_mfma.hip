@@ -675,6 +675,7 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
     const u64 nblocks = (a.nrows + rb - 1) / rb;
     const uint32_t nsb = (1u << 20) / rb; // about a million sampled rows
     if (nblocks < 16ull * nsb) return false; // never more than 1/16 of the table
+    if ((static_cast<u64>(nsb) + num_cus - 1) / num_cus * rb > 60000u) return false; // 16-bit LDS counters per workgroup
     const u64 stride = nblocks / nsb;
     if (a.W == 64)
         hipLaunchKernelGGL((batch_mfma_sample_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
