@@ -3,7 +3,7 @@
 // A batch of queries is not HBM-bound: with Q queries per table pass the work per
 // fingerprint is Q * (2 * W) VALU operations (v_and + v_bcnt_u32_b32 per 32-bit word),
 // i.e. the bound is the VALU issue rate, not memory.  This is the
-// pass for batches with a cutoff > 0 and for 128..512-bit rows (1024/2048-bit rows without
+// pass for batches with a cutoff > 0 and for 128-bit rows (256..2048-bit rows without
 // a cutoff: gsim_batch_mfma.hip), and its SAMPLE variant sets the starting thresholds of
 // both.  The layout is turned around relative to the
 // single-query scan:
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kScanBlock) void batch_scan_kernel(BatchArgs a, Sca
         // DESIGN.md): v_bcnt_u32_b32 (VOP3) and a v_and with a scalar operand both issue in 4 cycles
         // per wave64, so the loop runs at the 8 cycles per word-pair ceiling of the instruction
         // pair; bringing the query words into VGPRs (LDS broadcast, v_mov) only trades the 4-cycle
-        // v_and for a 2-cycle one plus the delivery cost.  Batches of 1024/2048-bit rows therefore use the
+        // v_and for a 2-cycle one plus the delivery cost.  Batches of 256..2048-bit rows therefore use the
         // matrix-core pass (gsim_batch_mfma.hip).
         constexpr bool MANUAL = (WORDS % 32 == 0);
         constexpr int NB = WORDS / 16;

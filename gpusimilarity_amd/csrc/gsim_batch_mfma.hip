@@ -656,7 +656,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a,
 
 bool batch_mfma_supported(uint32_t W)
 {
-    return W == 32 || W == 64;
+    return W == 8 || W == 16 || W == 32 || W == 64; // 256 ... 2048-bit rows (multiples of the 256-bit MFMA group)
 }
 
 uint32_t batch_mfma_waves(int num_cus)
@@ -670,7 +670,7 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
 {
     static const int enabled = std::getenv("GSIM_BATCH_MFMA_SAMPLE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_SAMPLE")) : 1;
     *err = hipSuccess;
-    if (!enabled || a.k == 0 || a.nq > static_cast<uint32_t>(kMfmaQueries) || !(a.W == 32 || a.W == 64)) return false;
+    if (!enabled || a.k == 0 || a.nq > static_cast<uint32_t>(kMfmaQueries) || !batch_mfma_supported(a.W)) return false;
     const uint32_t rb = kMChunks / (a.W / 4);
     const u64 nblocks = (a.nrows + rb - 1) / rb;
     const uint32_t nsb = (1u << 20) / rb; // about a million sampled rows
@@ -679,8 +679,12 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
     const u64 stride = nblocks / nsb;
     if (a.W == 64)
         hipLaunchKernelGGL((batch_mfma_sample_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
-    else
+    else if (a.W == 32)
         hipLaunchKernelGGL((batch_mfma_sample_kernel<32>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
+    else if (a.W == 16)
+        hipLaunchKernelGGL((batch_mfma_sample_kernel<16>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
+    else
+        hipLaunchKernelGGL((batch_mfma_sample_kernel<8>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
     *err = hipGetLastError();
     return true;
 }
@@ -702,6 +706,20 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
             hipLaunchKernelGGL((batch_mfma_kernel<32, 2>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
         else
             hipLaunchKernelGGL((batch_mfma_kernel<32, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+    } else if (a.W == 16 || a.W == 8) {
+        // narrow rows: the epilogue outweighs the MFMAs, two query tiles per wave from 65 queries on
+        const u64 nblocks = (a.nrows + (kMChunks / (a.W / 4)) - 1) / (kMChunks / (a.W / 4));
+        if (a.W == 16) {
+            if (a.nq > 64)
+                hipLaunchKernelGGL((batch_mfma_kernel<16, 2>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+            else
+                hipLaunchKernelGGL((batch_mfma_kernel<16, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        } else {
+            if (a.nq > 64)
+                hipLaunchKernelGGL((batch_mfma_kernel<8, 2>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+            else
+                hipLaunchKernelGGL((batch_mfma_kernel<8, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        }
     } else {
         return hipErrorInvalidValue;
     }

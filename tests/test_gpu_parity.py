@@ -495,9 +495,9 @@ def batch_check(t, db, qs, k, cutoff=0.0, ctx="", **kw):
 @pytest.mark.parametrize("W,kind,n", [(64, 0, 150_000), (32, 0, 200_000), (32, 1, 120_000), (16, 0, 90_000),
                                       (8, 1, 50_000), (4, 0, 40_000)])
 def test_multi_query_pass_matches_single_query_results(W, kind, n):
-    """Multi-query passes, 70 queries: identical results to the oracle for every query.  128..512-bit
-    rows and the cutoff case take the VALU pass (kBQ = 32 queries per table pass: 32 + 32 + 6), 1024
-    and 2048-bit rows without a cutoff the matrix-core pass (the VALU pass on those:
+    """Multi-query passes, 70 queries: identical results to the oracle for every query.  128-bit rows
+    and the cutoff case take the VALU pass (kBQ = 32 queries per table pass: 32 + 32 + 6), 256..2048-bit
+    rows without a cutoff the matrix-core pass (the VALU pass on those:
     test_valu_pass_on_wide_rows_without_cutoff)."""
     db = O.synth_rows(0xBA7C0 + W, kind, 0, n, W)
     t = make_table(db)
