@@ -3,8 +3,8 @@
 // A batch of queries is not HBM-bound: with Q queries per table pass the work per
 // fingerprint is Q * (2 * W) VALU operations (v_and + v_bcnt_u32_b32 per 32-bit word),
 // i.e. the bound is the VALU issue rate, not memory.  This is the
-// pass for batches with a cutoff > 0 and for 128-bit rows (256..2048-bit rows without
-// a cutoff: gsim_batch_mfma.hip), and its SAMPLE variant sets the starting thresholds of
+// pass for 128-bit rows and for batches whose cutoff keeps many rows (or any cutoff on small
+// tables); 256..2048-bit rows otherwise: gsim_batch_mfma.hip, and its SAMPLE variant sets the starting thresholds of
 // both.  The layout is turned around relative to the
 // single-query scan:
 //   * every lane holds ONE whole fingerprint in registers (W VGPRs) -- no cross-lane

@@ -114,9 +114,9 @@ template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, v4i rb, v1
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, /*A fp4*/ 4, /*B fp4*/ 4, 0, sc, 0, sc);
 }
 
-// c >= ka + kb * popc(row) is implied by bin(score) >= tau (see the file header); tau == 0,
-// exotic weights or an ill-conditioned bound switch the pre-filter off (everything passes).
-__device__ __forceinline__ void prefilter_constants(int metric, float alpha, float beta, uint32_t qa, uint32_t tau,
+// c >= ka + kb * popc(row) is implied by score >= T (see the file header); T <= 0, exotic weights
+// or an ill-conditioned bound switch the pre-filter off (everything passes).
+__device__ __forceinline__ void prefilter_constants(int metric, float alpha, float beta, uint32_t qa, float T,
                                                     bool valid, float& ka, float& kb)
 {
     ka = 0.0f;
@@ -127,9 +127,13 @@ __device__ __forceinline__ void prefilter_constants(int metric, float alpha, flo
     }
     const float al = metric == GSIM_METRIC_TVERSKY ? alpha : 1.0f;
     const float be = metric == GSIM_METRIC_TVERSKY ? beta : 1.0f;
-    const float T = static_cast<float>(tau) * (1.0f / kBBins);
     const float D = 1.0f - T * (1.0f - al - be);
-    if (tau == 0 || !(al >= 0.0f) || !(be >= 0.0f) || !(D > 0.05f)) return;
+    if (!(T > 0.0f) || !(al >= 0.0f) || !(be >= 0.0f)) return;
+    if (T > 1.0f) { // scores never exceed 1 with non-negative weights
+        ka = 3.0e38f;
+        return;
+    }
+    if (!(D > 0.05f)) return;
     const float f = T / D * (1.0f - 0.000244140625f); // (1 - 2^-12)
     ka = f * al * static_cast<float>(qa);
     kb = f * be;
@@ -170,6 +174,14 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
     const BatchRare rr = *a.rare;
     BatchQueryState* qstate = rr.qstate + a.q0;
     const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    const bool has_cutoff = a.cutoff > 0.0f;
+    // A cutoff that keeps a sizeable fraction of the table (estimated by the sample pass, bit 3 of
+    // the flags) would send that fraction of all pairs through the exact path: leave such batches
+    // to the VALU pass (the host re-runs them when it sees the flag).
+    if (has_cutoff && (*((g_u32p) rr.flags) & 8u)) {
+        if (lane == 0) rr.seg_count[w] = 0;
+        return;
+    }
 
     // ---- A operand: this wave's 32 queries, expanded once ----------------------------------
     ClassMasks km{0x11111111u, 0x22222222u, 0x44444444u};
@@ -193,7 +205,12 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
         const int m = lane >> 5;
         const bool valid = q0t + lane < nq;
         float ka, kb;
-        prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][lane], tau, valid, ka, kb);
+        // With a cutoff every pair at or above it has to reach the exact path (it is counted), so the
+        // level of the pre-filter is the cutoff, whatever the top-k threshold; without one it is the
+        // threshold.
+        const float level = has_cutoff ? __fmul_rn(a.cutoff, 1.0f - 4.76837158203125e-7f) // cutoff (1 - 2^-21)
+                                       : static_cast<float>(tau) * (1.0f / kBBins);
+        prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][lane], level, valid, ka, kb);
         const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i of a tile
         sh.kap_a[wq][m][hh][r] = ka;
         sh.kap_b[wq][m][hh][r] = kb;
@@ -236,7 +253,11 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
             float sc = score_of(a.metric, a.alpha, a.beta, sh.qpop[wq][qi], cb & 0xFFFFu, cb >> 16);
             sc = apply_cutoff(sc, a.cutoff);
             const uint32_t bin = batch_bin(sc);
-            const bool cand = have && bin >= sh.tau[wq][qi];
+            const bool keep = have && (!has_cutoff || sc != 0.0f); // fingerprintdb_cuda.cu:265-271
+            if (has_cutoff && keep)
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) u64*) &qstate[q0t + qi].kept, 1ull, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            const bool cand = keep && bin >= sh.tau[wq][qi];
             const u64 mc = __ballot(cand);
             if (cand) {
                 const uint32_t pos = cursor + lane_rank(mc);
@@ -646,6 +667,14 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a,
         uint32_t bin_k, cnt;
         threshold_from_counts<PER>(hh, sum, a.k, lane, bin_k, cnt);
         if (lane == 0) gq->gtau = (a.k && cnt >= a.k) ? bin_k : 0u;
+        if (a.cutoff > 0.0f) {
+            // rows below the cutoff were counted with score 0 (coarse bin 0): more than 1/512 of the
+            // sample above it means millions of pairs for the exact path -> flag the batch for the
+            // VALU pass (bit 3)
+            const uint32_t total = wave_sum(sum);
+            const uint32_t below = static_cast<uint32_t>(__shfl(static_cast<int>(hh[0]), 0, 64));
+            if (lane == 0 && static_cast<u64>(total - below) * 512ull > total) atomicOr(rr.flags, 8u);
+        }
 #pragma unroll
         for (int v = 0; v < PER; v++) gq->ghist[lane * PER + v] = 0;
     }
@@ -664,18 +693,28 @@ uint32_t batch_mfma_waves(int num_cus)
     return static_cast<uint32_t>(num_cus) * kMWaves;
 }
 
+// Does the matrix-core sample pass apply to this table?  (Large tables only; batches with a cutoff
+// need it: it also estimates how many rows the cutoff keeps.)
+bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus)
+{
+    static const int enabled = std::getenv("GSIM_BATCH_MFMA_SAMPLE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_SAMPLE")) : 1;
+    if (!enabled || k == 0 || nq > static_cast<uint32_t>(kMfmaQueries) || !batch_mfma_supported(W)) return false;
+    const uint32_t rb = kMChunks / (W / 4);
+    const u64 nblocks = (nrows + rb - 1) / rb;
+    const uint32_t nsb = (1u << 20) / rb; // about a million sampled rows
+    if (nblocks < 16ull * nsb) return false; // never more than 1/16 of the table
+    return (static_cast<u64>(nsb) + num_cus - 1) / num_cus * rb <= 60000u; // 16-bit LDS counters per workgroup
+}
+
 // Sample pass for all a.nq queries in one launch; false when the table is too small for it (the
 // caller then uses the VALU sample passes, which have their own size rules).
 bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err)
 {
-    static const int enabled = std::getenv("GSIM_BATCH_MFMA_SAMPLE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_SAMPLE")) : 1;
     *err = hipSuccess;
-    if (!enabled || a.k == 0 || a.nq > static_cast<uint32_t>(kMfmaQueries) || !batch_mfma_supported(a.W)) return false;
+    if (!batch_mfma_sample_applies(a.W, a.nrows, a.nq, a.k, num_cus)) return false;
     const uint32_t rb = kMChunks / (a.W / 4);
     const u64 nblocks = (a.nrows + rb - 1) / rb;
-    const uint32_t nsb = (1u << 20) / rb; // about a million sampled rows
-    if (nblocks < 16ull * nsb) return false; // never more than 1/16 of the table
-    if ((static_cast<u64>(nsb) + num_cus - 1) / num_cus * rb > 60000u) return false; // 16-bit LDS counters per workgroup
+    const uint32_t nsb = (1u << 20) / rb;
     const u64 stride = nblocks / nsb;
     if (a.W == 64)
         hipLaunchKernelGGL((batch_mfma_sample_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
@@ -693,7 +732,7 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
 // from the sample passes launched before it, finish with launch_batch_finish.
 hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s)
 {
-    if (a.nq > static_cast<uint32_t>(kMfmaQueries) || a.cutoff > 0.0f || a.nrows == 0) return hipErrorInvalidValue;
+    if (a.nq > static_cast<uint32_t>(kMfmaQueries) || a.nrows == 0) return hipErrorInvalidValue;
     if (a.W == 64) {
         const u64 nblocks = (a.nrows + (kMChunks / 16) - 1) / (kMChunks / 16);
         hipLaunchKernelGGL((batch_mfma_kernel<64, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);

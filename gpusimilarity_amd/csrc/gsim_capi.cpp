@@ -484,7 +484,7 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
 // matrix cores), the result blocks land in `results` (device memory; NULL = the shard's pinned host
 // block array s.h_bresult, through s.d_bresult).  No host synchronisation.
 int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
-                  float alpha, float beta, uint32_t row_base, void* results)
+                  float alpha, float beta, uint32_t row_base, void* results, bool allow_mfma = true)
 {
     int rc = ensure_batch_buffers(db, s, k);
     if (rc != GSIM_OK) return rc;
@@ -527,12 +527,15 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     a.alpha = alpha;
     a.beta = beta;
     const uint32_t sample = static_cast<uint32_t>(env_int("GSIM_BATCH_SAMPLE_CHUNKS", 8));
-    // one contraction pass on the matrix cores for all of them (gsim_batch_mfma.hip: with fewer
-    // than 8 x 32 queries the waves of a workgroup share query tiles and split the rows); counts of
-    // rows above a cutoff are only kept by the VALU pass
+    // One contraction pass on the matrix cores for all of them (gsim_batch_mfma.hip: with fewer
+    // than 8 x 32 queries the waves of a workgroup share query tiles and split the rows).  With a
+    // cutoff it needs the matrix-core sample pass (large tables), which also estimates how many
+    // rows the cutoff keeps: a cutoff that keeps many sets bit 3 of the flags and the kernel leaves
+    // the batch to the VALU pass (the callers re-enqueue with allow_mfma = false).
     static const int mfma_min_q = env_int("GSIM_BATCH_MFMA_MIN_Q", 4);
-    if (mfma_min_q > 0 && nq >= static_cast<uint32_t>(mfma_min_q) && nq <= static_cast<uint32_t>(gsim::kMfmaQueries) &&
-        !(cutoff > 0.0f) && gsim::batch_mfma_supported(s.W)) {
+    if (allow_mfma && mfma_min_q > 0 && nq >= static_cast<uint32_t>(mfma_min_q) &&
+        nq <= static_cast<uint32_t>(gsim::kMfmaQueries) && gsim::batch_mfma_supported(s.W) &&
+        (!(cutoff > 0.0f) || gsim::batch_mfma_sample_applies(s.W, s.nrows, nq, k, s.num_cus))) {
         a.q0 = 0;
         a.nq = nq;
         GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, results,
@@ -1044,7 +1047,22 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                                    db->row_base + static_cast<uint32_t>(s.first_row), nullptr);
                 if (rc != GSIM_OK) return rc;
             }
-            bool overflow = false;
+            bool overflow = false, dense_cutoff = false;
+            for (auto& s : db->shards) {
+                if (s.nrows == 0) continue;
+                GSIM_HIP(hipSetDevice(s.device));
+                rc = wait_stream(s.stream);
+                if (rc != GSIM_OK) return rc;
+                if (s.h_bflags[0] & 8u) dense_cutoff = true;
+            }
+            if (dense_cutoff) { // the cutoff keeps too many rows for the matrix-core pass: VALU pass
+                for (auto& s : db->shards) {
+                    if (s.nrows == 0) continue;
+                    rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta,
+                                       db->row_base + static_cast<uint32_t>(s.first_row), nullptr, false);
+                    if (rc != GSIM_OK) return rc;
+                }
+            }
             for (auto& s : db->shards) {
                 if (s.nrows == 0) continue;
                 GSIM_HIP(hipSetDevice(s.device));
@@ -1138,6 +1156,12 @@ int gsim_db_search_batch_device(gsim_db* db, const uint32_t* queries, uint32_t n
             GSIM_HIP(hipSetDevice(s.device));
             rc = wait_stream(s.stream);
             if (rc != GSIM_OK) return rc;
+            if (s.h_bflags[0] & 8u) { // the cutoff keeps too many rows for the matrix-core pass: VALU pass
+                rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, db->row_base, out + base * blk, false);
+                if (rc != GSIM_OK) return rc;
+                rc = wait_stream(s.stream);
+                if (rc != GSIM_OK) return rc;
+            }
             redo = (s.h_bflags[0] & 5u) != 0;
         }
         if (redo) { // those cases are rare: the whole chunk goes through the single-query pipeline

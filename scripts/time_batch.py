@@ -16,14 +16,16 @@ BITS = int(os.environ.get("BB_BITS", "2048"))
 Q = int(os.environ.get("BB_Q", "256"))
 K = int(os.environ.get("BB_K", "1000"))
 REPS = int(os.environ.get("BB_REPS", "3"))
+CUTOFF = float(os.environ.get("BB_CUTOFF", "0"))
 W = BITS // 32
 t = capi.Table(BITS)
 t.generate(bench.DB_SEED, 0, 0, N, 0)
 qs = np.stack([bench.synth_row(bench.DB_SEED, 0, bench.query_row(i, N), W) for i in range(Q)])
 kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
-t.search(qs, K, 0.0, **kw)
+t.search(qs, K, CUTOFF, **kw)
 t0 = time.perf_counter()
 for _ in range(REPS):
-    t.search(qs, K, 0.0, **kw)
+    hits, approx = t.search(qs, K, CUTOFF, **kw)
 el = (time.perf_counter() - t0) / REPS
-print("%s rows=%d bits=%d Q=%d: %.2f ms/batch, %.3e pairs/s" % (os.environ.get("GSIM_LIB", "default"), N, BITS, Q, el * 1e3, Q * N / el))
+print("%s rows=%d bits=%d Q=%d cutoff=%g: %.2f ms/batch, %.3e pairs/s, mean approx %.1f" % (
+    os.environ.get("GSIM_LIB", "default"), N, BITS, Q, CUTOFF, el * 1e3, Q * N / el, float(np.mean(approx))))

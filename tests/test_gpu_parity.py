@@ -739,3 +739,24 @@ def test_matrix_core_pass_large_k_and_tiny_tables(W, n, nq, k):
     batch_check(t, db, qs, k, 0.0, ctx="mfma W=%d n=%d nq=%d k=%d" % (W, n, nq, k))
     batch_check(t, db, qs[:5], k, 0.0, ctx="mfma small batch W=%d n=%d k=%d" % (W, n, k))
     t.close()
+
+
+@pytest.mark.parametrize("W,n", [(32, 20_000_000), (64, 17_000_000)])
+def test_matrix_core_pass_with_cutoff(W, n):
+    """Batches with a cutoff on tables large enough for the matrix-core sample pass: a selective
+    cutoff stays on the matrix cores (rows at or above it are counted on the exact path), a cutoff
+    that keeps a large part of the table is flagged by the sample pass and re-run on the VALU pass.
+    Either way hits AND approximate counts equal the single-query pipeline's."""
+    t = capi.Table(W * 32)
+    t.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
+    own = [O.synth_rows(0x5EED0001, 0, O.query_row(i, n), 1, W)[0] for i in range(40)]
+    fresh = [O.synth_rows(0x5EED0002, 0, 700 + i, 1, W)[0] for i in range(8)]
+    qs = np.stack(own + fresh)
+    for cutoff, kw in [(0.2, {}), (0.12, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))),
+                       (0.02, {}), (1.5, {})]:
+        hits, approx = t.search(qs, 100, np.float32(cutoff), **kw)
+        for i in range(len(qs)):
+            one, ap1 = t.search(qs[i], 100, np.float32(cutoff), **kw)
+            assert int(approx[i]) == int(ap1[0]), "W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], ap1[0])
+            assert_hits_equal(hits[i], one[0], "W=%d cutoff=%g q=%d" % (W, cutoff, i))
+    t.close()
