@@ -728,7 +728,8 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
     return true;
 }
 
-// The scan of one pass (a.nq <= kMfmaQueries queries from a.q0) for cutoff <= 0; thresholds come
+// The scan of one pass (a.nq <= kMfmaQueries queries from a.q0); with a cutoff only after
+// launch_batch_mfma_sample (it flags cutoffs that keep too many rows); thresholds come
 // from the sample passes launched before it, finish with launch_batch_finish.
 hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s)
 {

@@ -62,7 +62,7 @@ def test_fuzz_against_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(3))
 def test_fuzz_large_batches_against_oracle(seed):
-    """Batches of 64..200 queries (the matrix-core pass for 1024/2048-bit rows and cutoff <= 0, the
+    """Batches of 64..200 queries (the matrix-core pass for 256..2048-bit rows and cutoff <= 0, the
     VALU pass otherwise), random table shapes, metrics and k."""
     rng = np.random.default_rng(0xBA7C4 + seed)
     for case in range(8):

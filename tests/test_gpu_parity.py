@@ -545,7 +545,7 @@ def test_multi_query_pass_fallbacks():
 
 
 # ---------------------------------------------------------------------------
-# multi-query pass on the matrix cores (gsim_batch_mfma.hip): cutoff <= 0,
+# multi-query pass on the matrix cores (gsim_batch_mfma.hip): cutoff <= 0 (with a cutoff: large tables),
 # 1024- and 2048-bit rows
 # ---------------------------------------------------------------------------
 
