@@ -83,6 +83,7 @@ struct MfmaShared {
     float kap_v[kMWaves][kMaxMT][2][16];
     uint32_t tau[kMWaves][32 * kMaxMT];
     uint32_t qpop[kMWaves][32 * kMaxMT];
+    uint32_t kept[kMWaves][32 * kMaxMT]; // rows at or above the cutoff seen by the wave, per query
     uint32_t stage_row[kMWaves][kMStage]; // pairs that passed the pre-filter: row, (common << 16) + popc(row),
     uint32_t stage_cb[kMWaves][kMStage];  // query of the tile -- scored exactly in bulk (drain_stage)
     uint32_t stage_q[kMWaves][kMStage];
@@ -227,6 +228,7 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
     };
     if (lane < QW) {
         const bool valid = q0t + lane < nq;
+        sh.kept[wq][lane] = 0;
         sh.qpop[wq][lane] = valid ? a.qpop[a.q0 + q0t + lane] : 0u;
         set_query_constants(valid ? *((g_u32p) &qstate[q0t + lane].gtau) : static_cast<uint32_t>(kBBins));
     }
@@ -254,9 +256,7 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
             sc = apply_cutoff(sc, a.cutoff);
             const uint32_t bin = batch_bin(sc);
             const bool keep = have && (!has_cutoff || sc != 0.0f); // fingerprintdb_cuda.cu:265-271
-            if (has_cutoff && keep)
-                __hip_atomic_fetch_add((__attribute__((address_space(1))) u64*) &qstate[q0t + qi].kept, 1ull, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+            if (has_cutoff && keep) atomicAdd(&sh.kept[wq][qi], 1u); // LDS; one global add per wave and query at the end
             const bool cand = keep && bin >= sh.tau[wq][qi];
             const u64 mc = __ballot(cand);
             if (cand) {
@@ -519,6 +519,8 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
         for (int d = 0; d < 9; d++) atomicAdd(&rr.flags[2 + d], static_cast<uint32_t>(tacc[d] >> 6));
 #endif
     if (staged) drain_stage();
+    if (has_cutoff && lane < QW && q0t + lane < nq && sh.kept[wq][lane])
+        atomicAdd(&qstate[q0t + lane].kept, static_cast<u64>(sh.kept[wq][lane]));
     if (lane == 0) {
         rr.seg_count[w] = cursor < rr.seg_cap ? cursor : rr.seg_cap;
         if (cursor > rr.seg_cap) atomicOr(rr.flags, 1u); // segment overflow: the host falls back
