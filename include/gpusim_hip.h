@@ -153,7 +153,10 @@ int gsim_db_shard_count(const gsim_db* db);
  *   reference's own order depends on heap addresses, :366).
  * hits: caller-allocated nq*k entries, query q's hits at hits[q*k ..];
  * counts[q] = number of valid hits; approx may be NULL.  alpha/beta are used by
- * GSIM_METRIC_TVERSKY only. */
+ * GSIM_METRIC_TVERSKY only.  Four or more queries in one call share table passes
+ * (up to 256 per pass; on the matrix cores for 256..2048-bit rows) -- purely an
+ * execution detail: every query gets exactly the result a call with nq = 1 would
+ * return. */
 int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
                    float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
                    uint32_t* counts, uint64_t* approx);
