@@ -105,7 +105,8 @@ def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k
     Q = args.batch_queries
     kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
     nb = args.warmup + args.steps
-    batches = [np.stack([synth_row(DB_SEED, kind, query_row(b * Q + i, total_rows), W) for i in range(Q)])
+    batches = [np.ascontiguousarray(np.stack([synth_row(DB_SEED, kind, query_row(b * Q + i, total_rows), W)
+                                              for i in range(Q)]), dtype=np.uint32)
                for b in range(min(nb, 4))]  # a few distinct batches, cycled
     sb = None
     if sharded_path:
@@ -115,10 +116,12 @@ def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k
         with torch.cuda.stream(stream):
             sb = ShardedBatchSearch(local_batch, k, Q, dev, stream_ptr=stream.cuda_stream)
     last = {}
+    bufs = table.make_search_buffers(Q, k)  # caller-owned outputs of the synchronous C-ABI call
 
     def one_batch(qs):
         if not sharded_path:
-            last["hits"], last["approx"] = table.search(qs, k, 0.0, **kw)
+            table.search_into(qs, k, bufs, 0.0, **kw)
+            last["hits"] = [bufs[0][0, :bufs[1][0]]]
             return
         with torch.cuda.stream(stream):
             sb.enqueue(qs)

@@ -36,6 +36,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "../../include/gpusim_hip.h"
@@ -308,6 +309,7 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
 #endif
     constexpr int PER = kBBins / 64; // histogram bins per lane in a threshold update
     uint32_t turn = blockIdx.x;      // rotates the query whose threshold this wave refreshes
+    const int rshift = nblocks >= 64ull * gridDim.x ? 2 : 0; // every fourth block; every block on small tables
     for (; blk < nblocks; blk += gridDim.x, buf ^= 1, turn++) {
         MF_T(tb0);
         const u64 next = blk + gridDim.x;
@@ -317,8 +319,8 @@ template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mf
         // over the workgroups), gets its threshold recomputed from the table-wide histogram of
         // emitted rows.  All updates are monotone (atomicMax).
         uint32_t gt = 0;
-        const int qref = q0t + static_cast<int>(((turn >> 2) + rgroup * (QW / ngroups)) & (QW - 1));
-        const bool refresh = wave_has_queries && qref < nq && (turn & 3u) == 0;
+        const int qref = q0t + static_cast<int>(((turn >> rshift) + rgroup * (QW / ngroups)) & (QW - 1));
+        const bool refresh = wave_has_queries && qref < nq && (turn & ((1u << rshift) - 1u)) == 0;
         if (wave_has_queries && lane < QW && q0t + lane < nq)
             gt = __hip_atomic_load((g_u32p) &qstate[q0t + lane].gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MF_T(tb2);
@@ -695,6 +697,15 @@ uint32_t batch_mfma_waves(int num_cus)
     return static_cast<uint32_t>(num_cus) * kMWaves;
 }
 
+// Row blocks in the sample: about a million rows, never more than 1/16 of the table.
+static uint32_t batch_mfma_sample_blocks(uint32_t W, uint64_t nrows)
+{
+    const uint32_t rb = kMChunks / (W / 4);
+    const u64 nblocks = (nrows + rb - 1) / rb;
+    const u64 nsb = std::min<u64>((1u << 20) / rb, nblocks / 16);
+    return static_cast<uint32_t>(nsb ? nsb : 1);
+}
+
 // Does the matrix-core sample pass apply to this table?  (Large tables only; batches with a cutoff
 // need it: it also estimates how many rows the cutoff keeps.)
 bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus)
@@ -703,8 +714,8 @@ bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t
     if (!enabled || k == 0 || nq > static_cast<uint32_t>(kMfmaQueries) || !batch_mfma_supported(W)) return false;
     const uint32_t rb = kMChunks / (W / 4);
     const u64 nblocks = (nrows + rb - 1) / rb;
-    const uint32_t nsb = (1u << 20) / rb; // about a million sampled rows
-    if (nblocks < 16ull * nsb) return false; // never more than 1/16 of the table
+    if (nblocks < 64) return false; // tiny tables: the scan's own threshold upkeep is enough
+    const uint32_t nsb = batch_mfma_sample_blocks(W, nrows);
     return (static_cast<u64>(nsb) + num_cus - 1) / num_cus * rb <= 60000u; // 16-bit LDS counters per workgroup
 }
 
@@ -716,7 +727,7 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
     if (!batch_mfma_sample_applies(a.W, a.nrows, a.nq, a.k, num_cus)) return false;
     const uint32_t rb = kMChunks / (a.W / 4);
     const u64 nblocks = (a.nrows + rb - 1) / rb;
-    const uint32_t nsb = (1u << 20) / rb;
+    const uint32_t nsb = batch_mfma_sample_blocks(a.W, a.nrows);
     const u64 stride = nblocks / nsb;
     if (a.W == 64)
         hipLaunchKernelGGL((batch_mfma_sample_kernel<64>), dim3(num_cus), dim3(kMBlock), 0, s, a, nsb, stride);
