@@ -421,14 +421,14 @@ __global__ __launch_bounds__(256) void batch_select_kernel(BatchArgs a, uint32_t
         }
         return;
     }
-    const uint32_t first = blockIdx.x * 256;
-    if (first < m2) {
+    if (blockIdx.x * 256 < m2) {
         const u64* fk = a.rare->fin_key + static_cast<size_t>(q) * kSelectCap;
         const uint32_t npad = (m2 + 1u) & ~1u;
         for (uint32_t i = tid; i < npad; i += 256) keys[i] = i < m2 ? fk[i] : 0ull;
         __syncthreads();
-        const uint32_t i = first + tid;
-        if (i < m2) {
+        // the workgroups of a query stride over its finalists (a few hundred to a few thousand: four
+        // workgroups per query instead of kSelectCap / 256 keep the launch small)
+        for (uint32_t i = blockIdx.x * 256 + tid; i < m2; i += gridDim.x * 256) {
             const u64 mine = keys[i];
             const uint32_t cb = a.rare->fin_cb[static_cast<size_t>(q) * kSelectCap + i];
             uint32_t rank = 0;
@@ -512,7 +512,7 @@ hipError_t launch_batch_finish(const BatchArgs& a, uint32_t nwaves, uint32_t row
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch_select_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(batch_select_kernel, dim3(kSelectCap / 256, a.nq), dim3(256), lds, s, a, row_base,
+    hipLaunchKernelGGL(batch_select_kernel, dim3(4, a.nq), dim3(256), lds, s, a, row_base,
                        reinterpret_cast<unsigned char*>(results), block_bytes);
     return hipGetLastError();
 }
