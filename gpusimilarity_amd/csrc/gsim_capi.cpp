@@ -14,10 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "gsim_device.h"
@@ -116,11 +118,21 @@ struct Shard {
 
 } // namespace
 
+// resize() without zero-filling: the rows are copied in right away, by several threads, which then
+// also take the first-touch page faults in parallel
+template <class T> struct NoInitAllocator : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAllocator<U>;
+    };
+    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
+};
+
 struct gsim_db {
     uint32_t fp_bits = 0;
     uint32_t W = 0;
     uint64_t nrows = 0;
-    std::vector<uint32_t> host_rows; // host copy (reference: m_data)
+    std::vector<uint32_t, NoInitAllocator<uint32_t>> host_rows; // host copy (reference: m_data)
     bool has_host_copy = false;
     bool finalized = false;
     std::vector<Shard> shards;
@@ -418,6 +430,65 @@ void fold_rows_mt(const uint32_t* rows, uint64_t nrows, uint32_t W, uint32_t F, 
     }
     for (auto& th : pool) th.join();
 }
+
+// memcpy on several host threads (a single thread moves ~7 GB/s here; table loading is startup
+// time, not the hot path, but a 128 GB table should not take half a minute)
+void parallel_memcpy(void* dst, const void* src, size_t bytes)
+{
+    const size_t kMin = size_t(8) << 20;
+    unsigned nt = std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    if (bytes < 2 * kMin || nt < 2) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    nt = static_cast<unsigned>(std::min<size_t>(nt, bytes / kMin));
+    const size_t per = (bytes / nt + 4095) & ~size_t(4095);
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; i++) {
+        const size_t off = per * i;
+        if (off >= bytes) break;
+        const size_t n = std::min(per, bytes - off);
+        th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, n); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// Pageable host memory -> device through two pinned staging buffers: the (threaded) copy into one
+// buffer overlaps the DMA of the other (pageable hipMemcpy: 10 GB/s).
+int upload_rows(void* d_dst, const void* h_src, size_t bytes, hipStream_t stream)
+{
+    const size_t kChunk = size_t(64) << 20;
+    if (bytes <= kChunk) {
+        GSIM_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+        return GSIM_OK;
+    }
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = GSIM_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc(&stage[i], kChunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    size_t off = 0;
+    for (int i = 0; e == hipSuccess && off < bytes; i ^= 1) {
+        const size_t n = std::min(kChunk, bytes - off);
+        e = hipEventSynchronize(done[i]); // the previous DMA out of this buffer (no-op the first time)
+        if (e != hipSuccess) break;
+        parallel_memcpy(stage[i], static_cast<const char*>(h_src) + off, n);
+        e = hipMemcpyAsync(static_cast<char*>(d_dst) + off, stage[i], n, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(done[i], stream);
+        off += n;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) rc = fail_hip(e, "upload_rows");
+    for (int i = 0; i < 2; i++) {
+        if (done[i]) (void) hipEventDestroy(done[i]);
+        if (stage[i]) (void) hipHostFree(stage[i]);
+    }
+    return rc;
+}
+
 
 std::mutex g_rr_mutex;
 int g_next_device = 0;
@@ -782,7 +853,9 @@ int gsim_db_add_rows(gsim_db* db, const uint32_t* rows, uint64_t nrows)
     if (db->nrows + nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
     try {
         db->slice_first.push_back(db->nrows);
-        db->host_rows.insert(db->host_rows.end(), rows, rows + nrows * db->W);
+        const size_t old_words = db->host_rows.size();
+        db->host_rows.resize(old_words + static_cast<size_t>(nrows) * db->W);
+        parallel_memcpy(db->host_rows.data() + old_words, rows, static_cast<size_t>(nrows) * db->W * 4);
     } catch (const std::bad_alloc&) {
         return fail(GSIM_ERR_NOMEM, "out of host memory");
     }
@@ -882,8 +955,10 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
         const size_t bytes = static_cast<size_t>(s.nrows) * row_bytes;
         GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
         s.owns_rows = true;
-        if (bytes)
-            GSIM_HIP(hipMemcpy(s.d_rows, db->host_rows.data() + s.first_row * db->W, bytes, hipMemcpyHostToDevice));
+        if (bytes) {
+            const int urc = upload_rows(s.d_rows, db->host_rows.data() + s.first_row * db->W, bytes, nullptr);
+            if (urc != GSIM_OK) return urc;
+        }
         int rc = setup_shard(db, s);
         if (rc != GSIM_OK) return rc;
     }
