@@ -143,10 +143,12 @@ __device__ __forceinline__ void prefilter_constants(int metric, float alpha, flo
 
 // MT = query tiles per wave: the expanded row operand of a tile is used by MT MFMAs per class, so
 // the operand work per MFMA is 5 / MT instructions; 2 W MT registers hold the queries.
-template <int WORDS, int MT> __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
+// NT = row tiles in flight per wave (accumulators: 16 MT NT registers; two independent MFMA chains
+// per wave are worth having, except when that leaves half of the waves without a row tile).
+template <int WORDS, int MT, int NT = (MT == 1 ? 2 : 1)>
+__global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
 {
     constexpr int QW = 32 * MT;         // queries per wave
-    constexpr int NT = MT == 1 ? 2 : 1; // row tiles in flight per wave (accumulators: 16 MT NT registers)
     constexpr int KG = WORDS / 8;       // 256-bit groups per row
     constexpr int CPR = WORDS / 4;      // 16-byte chunks per row
     constexpr int RPLN = 16 / CPR;      // rows per 256-byte LDS line
@@ -750,6 +752,8 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
     if (a.nq > static_cast<uint32_t>(kMfmaQueries) || a.nrows == 0) return hipErrorInvalidValue;
     if (a.W == 64) {
         const u64 nblocks = (a.nrows + (kMChunks / 16) - 1) / (kMChunks / 16);
+        // (with one query tile only four of the eight row groups find a pair of row tiles; single
+        // tiles for all eight waves -- NT = 1 -- were 20-50 % slower: one MFMA chain per wave)
         hipLaunchKernelGGL((batch_mfma_kernel<64, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
     } else if (a.W == 32) {
         const u64 nblocks = (a.nrows + (kMChunks / 8) - 1) / (kMChunks / 8);
