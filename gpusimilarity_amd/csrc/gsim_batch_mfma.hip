@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     constexpr int NTB = RB / 32;        // 32-row tiles per block
     static_assert(WORDS % 8 == 0 && CPR <= 16 && NTB >= 2 && NTB % 2 == 0, "unsupported row width");
     static_assert(MT >= 1 && MT <= kMaxMT && 2 * WORDS * MT <= 128, "query operands must fit in registers");
+    static_assert(NT >= 1 && NT <= 4 && NTB % NT == 0, "row tiles in flight");
     __shared__ MfmaShared sh;
 
     const int lane = threadIdx.x & 63;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
 #pragma unroll
                     for (int tt = 0; tt < NT; tt++) any = any || (active[tt] && mx[tt] >= pbf[tt] - 0.01f);
                     // which accumulator registers hold a passing pair (bit 16 tt + r: row tile tt)
-                    uint32_t bits = 0, rmask = 0;
+                    u64 bits = 0, rmask = 0;
                     if (__ballot(any) != 0) {
                         const f32x4* kap = reinterpret_cast<const f32x4*>(sh.kap_a[wq][m][h]);
                         const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][m][h]);
@@ -432,34 +433,43 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
 #pragma unroll
                                 for (int tt = 0; tt < NT; tt++)
                                     bits |= (active[tt] && acc[m][tt][r] >= __builtin_fmaf(vb[e], pbf[tt], va[e]))
-                                                ? (1u << (16 * tt + r))
-                                                : 0u;
+                                                ? (1ull << (16 * tt + r))
+                                                : 0ull;
                             }
                         }
-                        uint32_t o = bits; // OR over the wavefront
-                        o |= dpp<0xB1>(o);
-                        o |= dpp<0x4E>(o);
-                        o |= dpp<0x141>(o);
-                        o |= dpp<0x140>(o);
-                        o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 16, 64));
-                        o |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(o), 32, 64));
-                        rmask = __builtin_amdgcn_readfirstlane(o);
+                        // OR over the wavefront, 32 bits at a time
+                        uint32_t o[2] = {static_cast<uint32_t>(bits), static_cast<uint32_t>(bits >> 32)};
+#pragma unroll
+                        for (int half = 0; half < (NT > 2 ? 2 : 1); half++) {
+                            uint32_t v = o[half];
+                            v |= dpp<0xB1>(v);
+                            v |= dpp<0x4E>(v);
+                            v |= dpp<0x141>(v);
+                            v |= dpp<0x140>(v);
+                            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 16, 64));
+                            v |= static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), 32, 64));
+                            o[half] = __builtin_amdgcn_readfirstlane(v);
+                        }
+                        rmask = o[0] | (NT > 2 ? static_cast<u64>(o[1]) << 32 : 0ull);
                     }
                     // rare: stage the pairs that passed
                     while (rmask) {
-                        const int bit = __builtin_ctz(rmask);
+                        const int bit = __builtin_ctzll(rmask);
                         rmask &= rmask - 1;
                         const int r = bit & 15;
-                        const int tt = NT > 1 ? bit >> 4 : 0;
+                        const int tsel = bit >> 4;
                         float cf = acc[m][0][r];
                         uint32_t pbs = pb[0];
                         u64 rws = rowi[0];
-                        if (NT > 1 && tt == 1) {
-                            cf = acc[m][NT - 1][r];
-                            pbs = pb[NT - 1];
-                            rws = rowi[NT - 1];
+#pragma unroll
+                        for (int tt = 1; tt < NT; tt++) {
+                            if (tsel == tt) {
+                                cf = acc[m][tt][r];
+                                pbs = pb[tt];
+                                rws = rowi[tt];
+                            }
                         }
-                        const bool pass = (bits >> bit) & 1u;
+                        const bool pass = (bits >> bit) & 1ull;
                         const u64 mp = __ballot(pass);
                         if (pass) {
                             const uint32_t slot = staged + lane_rank(mp);
@@ -760,6 +770,8 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
         static const int mt_env = std::getenv("GSIM_BATCH_MFMA_MT") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_MT")) : 0;
         // two query tiles per wave halve the operand work: 8 % faster at 256 queries, even at 128,
         // slower below (fewer row groups per query tile)
+        // (two row tiles in flight per wave is the sweet spot: four -- NT = 4 -- was 5 % slower here,
+        // MT = NT = 2 does not fit the registers)
         if (mt_env ? mt_env == 2 : a.nq > 128)
             hipLaunchKernelGGL((batch_mfma_kernel<32, 2>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
         else
