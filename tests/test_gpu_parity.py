@@ -760,3 +760,26 @@ def test_matrix_core_pass_with_cutoff(W, n):
             assert int(approx[i]) == int(ap1[0]), "W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], ap1[0])
             assert_hits_equal(hits[i], one[0], "W=%d cutoff=%g q=%d" % (W, cutoff, i))
     t.close()
+
+
+def test_bench_contract_lines():
+    """bench.py prints exactly one JSON line with the contract's keys, in the headline mode (through
+    the sharded code path as well) and in the batch mode (BASELINE configs[4] shape, small)."""
+    import subprocess
+    import sys
+    common = ["--steps", "3", "--warmup", "2", "--rows-per-gpu", "400000"]
+    for extra in (["--no-cpu-baseline"], ["--no-cpu-baseline", "--force-sharded-path"],
+                  ["--fp-bits", "2048", "--batch-queries", "64"],
+                  ["--fp-bits", "2048", "--batch-queries", "64", "--force-sharded-path"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, cwd=ROOT,
+                           capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-500:]
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                    "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in d, key
+        assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "workload" in d["config"]
+        assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["peak"] > 0
