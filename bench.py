@@ -110,11 +110,7 @@ def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k
                for b in range(min(nb, 4))]  # a few distinct batches, cycled
     sb = None
     if sharded_path:
-        def local_batch(qs, kk, blocks):
-            table.search_batch_device(qs, kk, blocks.data_ptr(), 0.0, **kw)
-
-        with torch.cuda.stream(stream):
-            sb = ShardedBatchSearch(local_batch, k, Q, dev, stream_ptr=stream.cuda_stream)
+        sb = ShardedBatchSearch(table, k, Q, dev, stream=stream, search_kwargs=kw)
     last = {}
     bufs = table.make_search_buffers(Q, k)  # caller-owned outputs of the synchronous C-ABI call
 
@@ -123,9 +119,8 @@ def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k
             table.search_into(qs, k, bufs, 0.0, **kw)
             last["hits"] = [bufs[0][0, :bufs[1][0]]]
             return
-        with torch.cuda.stream(stream):
-            sb.enqueue(qs)
-        stream.synchronize()
+        sb.enqueue(qs)
+        sb.synchronize()
 
     for b in range(args.warmup):
         one_batch(batches[b % len(batches)])
@@ -234,11 +229,7 @@ def main():
     bufs = table.make_search_buffers(1, k)
     ss = None
     if sharded_path:
-        def local_search(q, kk, block):
-            table.search_device(q, kk, block.data_ptr())  # enqueued on `stream`, result stays in HBM
-
-        with torch.cuda.stream(stream):
-            ss = ShardedSearch(local_search, k, dev, stream_ptr=stream.cuda_stream)
+        ss = ShardedSearch(table, k, dev, stream=stream)  # local result block stays in HBM
 
     def one_query(q):
         if not sharded_path:
@@ -247,9 +238,8 @@ def main():
             # the call returns when they are there
             table.search_into(q, k, bufs)
             return
-        with torch.cuda.stream(stream):
-            ss.enqueue(q)  # local top-k -> RCCL all-gather (k*12+16 B per GPU) -> rank merge -> D2H
-        stream.synchronize()  # the query is done when its k hits are in host memory
+        ss.enqueue(q)  # local top-k -> RCCL all-gather (k*12+16 B per GPU) -> rank merge -> D2H
+        ss.synchronize()  # the query is done when its k hits are in host memory
 
     def last_result():
         if not sharded_path:

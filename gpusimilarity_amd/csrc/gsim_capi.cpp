@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -55,6 +56,8 @@ int env_int(const char* name, int dflt)
 }
 
 constexpr int kTimingRing = 1024;
+// single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart)
+constexpr size_t kSummBytes = 4096 * 4 + static_cast<size_t>(gsim::kFusedCheckpoints) * 9 * 128;
 constexpr int kQueryRing = 16;
 
 struct Shard {
@@ -68,6 +71,7 @@ struct Shard {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr; // the stream in use (own or caller's)
     gsim::ScanGeometry geo{};
+    gsim::ScanGeometry fgeo{}; // single-launch path: fewer waves on small tables (every wave gets >= 4 chunks)
     bool state_dirty = false; // set when an enqueue failed: the device state is re-zeroed before the next one
     int sample_chunks = 4; // chunks per scan wave scored by the sample kernel (0 = off)
     uint32_t* d_query = nullptr;
@@ -78,6 +82,13 @@ struct Shard {
     unsigned long long* d_final = nullptr;
     uint32_t* d_final_cb = nullptr;
     uint32_t final_cap = 0;
+    bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)
+    void* d_pub = nullptr;      // single-launch path: table-wide published-candidate list (1 MB)
+    uint32_t* d_summ = nullptr; // single-launch path: per-wave checkpoint summaries (16 KB, zero between queries)
+    uint32_t* h_done = nullptr; // single-launch path: pinned word the kernel stores the query's epoch into
+    uint32_t epoch = 0;
+    bool last_fused = false;    // the last synchronous enqueue went through the single-launch path
+    unsigned long long* d_dbg = nullptr; // GSIM_FUSED_DEBUG: per-workgroup phase timestamps
     void* d_result = nullptr;
     size_t result_bytes = 0;
     // pinned host staging; queries go through a ring so that back-to-back
@@ -92,7 +103,7 @@ struct Shard {
     // timing
     std::vector<hipEvent_t> ev; // 3 per slot
     uint32_t ev_used = 0;
-    unsigned long long base_ncand = 0, base_nfinal = 0; // device totals when timing was enabled
+    unsigned long long base_ncand = 0, base_nfinal = 0, base_nredo = 0; // device totals when timing was enabled
     // multi-query batches (allocated on first use)
     gsim::ScanGeometry bgeo{};
     uint32_t bq_cap = 0;          // queries the batch buffers hold
@@ -163,6 +174,10 @@ int free_shard(Shard& s)
     if (s.d_seg_count) (void) hipFree(s.d_seg_count);
     if (s.d_final) (void) hipFree(s.d_final);
     if (s.d_result) (void) hipFree(s.d_result);
+    if (s.d_pub) (void) hipFree(s.d_pub);
+    if (s.d_summ) (void) hipFree(s.d_summ);
+    if (s.d_dbg) (void) hipFree(s.d_dbg);
+    if (s.h_done) (void) hipHostFree(s.h_done);
     if (s.h_query) (void) hipHostFree(s.h_query);
     if (s.h_result) (void) hipHostFree(s.h_result);
     if (s.h_state) (void) hipHostFree(s.h_state);
@@ -212,16 +227,19 @@ int setup_shard(gsim_db* db, Shard& s)
     if (s.W == 0) s.W = db->W;
     s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, unroll);
     s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
-    const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
+    s.fgeo = s.geo;
+    if (s.geo.nchunks < 4ull * s.geo.nwaves) { // small table: threshold checkpoints need a few trips per wave
+        uint64_t nw = s.geo.nchunks / 4 / 4 * 4;
+        s.fgeo.nwaves = static_cast<uint32_t>(nw < 4 ? 4 : nw);
+    }
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(s.W) * 4));
     GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
-    GSIM_HIP(hipMemset(s.d_state, 0, sizeof(gsim::QueryState))); // the select kernel keeps it zero between queries
-    GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
-    GSIM_HIP(hipMalloc(&s.d_cand_cb, static_cast<size_t>(slots) * 4));
-    GSIM_HIP(hipMalloc(&s.d_seg_count, static_cast<size_t>(s.geo.nwaves) * 4));
-    s.final_cap = next_pow2_u32(slots);
-    GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
-    GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
+    GSIM_HIP(hipMemset(s.d_state, 0, sizeof(gsim::QueryState))); // the kernels keep it zero between queries
+    GSIM_HIP(hipMalloc(&s.d_pub, static_cast<size_t>(gsim::kFusedPubCap) * 16));
+    GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_summ), kSummBytes));
+    GSIM_HIP(hipMemset(s.d_summ, 0, kSummBytes));
+    GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_done), 64, hipHostMallocDefault));
+    std::memset(s.h_done, 0, 64);
     GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(s.W) * 4 * kQueryRing, hipHostMallocDefault));
     for (int i = 0; i < kQueryRing; i++) {
         hipEvent_t e;
@@ -229,6 +247,26 @@ int setup_shard(gsim_db* db, Shard& s)
         s.q_ev.push_back(e);
     }
     GSIM_HIP(hipHostMalloc(&s.h_state, sizeof(gsim::QueryState), hipHostMallocDefault));
+    return GSIM_OK;
+}
+
+// Scratch of the four-kernel pipeline (per-wave candidate segments + finalists: the worst case is
+// every row a candidate, 24 B per row).  The single-launch path keeps its candidates in LDS and
+// needs none of it, so it is only allocated when a query takes the classic pipeline: k above
+// kFusedMaxK, widths without a specialised scan, or a query the single-launch path handed back
+// (heavy ties, adversarial row orders).
+int ensure_classic_scratch(Shard& s)
+{
+    if (s.classic_ready) return GSIM_OK;
+    GSIM_HIP(hipSetDevice(s.device));
+    const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
+    GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
+    GSIM_HIP(hipMalloc(&s.d_cand_cb, static_cast<size_t>(slots) * 4));
+    GSIM_HIP(hipMalloc(&s.d_seg_count, static_cast<size_t>(s.geo.nwaves) * 4));
+    s.final_cap = next_pow2_u32(slots);
+    GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
+    GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
+    s.classic_ready = true;
     return GSIM_OK;
 }
 
@@ -258,19 +296,44 @@ uint32_t popcount_words(const uint32_t* q, uint32_t W)
     return a;
 }
 
+enum QueryMode { kAuto = 0, kClassic = 1 };
+
+bool fused_applies(const Shard& s, uint32_t k)
+{
+    static const int enabled = env_int("GSIM_FUSED", 1);
+    static const long long max_rows = std::getenv("GSIM_FUSED_MAX_ROWS") ? std::atoll(std::getenv("GSIM_FUSED_MAX_ROWS")) : -1;
+    if (!enabled || k == 0 || k > gsim::kFusedMaxK || s.nrows == 0 || !gsim::fused_supported(s.fgeo)) return false;
+    // thresholds need >= k summary keys; without them every row is published (tiny tables only)
+    if (gsim::fused_summary_keys(s.fgeo.nwaves, k) == 0 && s.nrows > 8192) return false;
+    return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
+}
+
 // Enqueue one query on one shard; the result block ends up at `out`, which is
-// device memory or device-visible pinned host memory (zero-copy).  The stream
-// carries three kernels: scan -> compact -> select.  The query is read by the scan
-// straight from a pinned ring slot (no upload op) and the select kernel re-zeroes
-// the per-query state (no memset op).  Nothing here synchronises with the host
-// unless k > kSelectCap.
+// device memory or device-visible pinned host memory (zero-copy).
+//
+// Single-launch path (fused_applies): ONE kernel does scan + publish + select.  Synchronous
+// callers (caller_syncs) get the query's epoch stored into s.h_done when the block is complete
+// and check header flag 2 ("handed back": re-run with mode kClassic).  Enqueue-only callers
+// (the RCCL path) get the four classic kernels enqueued behind it, gated on QueryState::redo:
+// they return at once unless the single launch handed the query back.
+//
+// Classic path: sample -> scan -> compact -> select.  The query is read by the kernels straight
+// from a pinned ring slot (no upload op) and the last kernel re-zeroes the per-query state (no
+// memset op).  Nothing here synchronises with the host unless k > kSelectCap.
 int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                       float beta, uint32_t row_base, void* out, bool caller_syncs)
+                       float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode)
 {
     GSIM_HIP(hipSetDevice(s.device));
     if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
         GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, ncand_sum), s.stream));
+        GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
         s.state_dirty = false;
+    }
+    const bool fused = mode == kAuto && fused_applies(s, k);
+    const bool classic = !fused || !caller_syncs;
+    if (classic) {
+        const int rc = ensure_classic_scratch(s);
+        if (rc != GSIM_OK) return rc;
     }
     const uint32_t slot = s.q_next++ % kQueryRing;
     uint32_t* hq = s.h_query + static_cast<size_t>(slot) * s.W;
@@ -296,6 +359,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
     a.cand_cb = s.d_cand_cb;
     a.seg_count = s.d_seg_count;
     a.state = s.d_state;
+    a.gate = nullptr;
     if (s.geo.lanes_per_row == 0 || s.nrows == 0) {
         // generic-width scan reads the query per word: give it a device copy
         GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(s.W) * 4, hipMemcpyHostToDevice, s.stream));
@@ -313,15 +377,45 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         }
         ev = &s.ev[3 * s.ev_used];
     }
+    s.last_fused = false;
+    if (fused) {
+        gsim::FusedArgs f{};
+        f.pub = s.d_pub;
+        f.summ = s.d_summ;
+        f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k);
+        f.tickets = s.d_summ + 4096;
+        f.result = out;
+        f.row_base = row_base;
+        f.done_flag = caller_syncs ? s.h_done : nullptr;
+        f.epoch = ++s.epoch;
+        if (s.epoch == 0) f.epoch = ++s.epoch; // 0 is the flag's initial value
+        static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
+        if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
+        f.dbg = s.d_dbg;
+        static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
+        f.xflags = static_cast<uint32_t>(xflags);
+        if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+        GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
+        if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
+        if (caller_syncs) {
+            s.last_fused = true;
+            if (ev) {
+                GSIM_HIP(hipEventRecord(ev[2], s.stream));
+                s.ev_used++;
+            }
+            return GSIM_OK;
+        }
+        a.gate = &s.d_state->redo; // the classic kernels behind it run only if it handed the query back
+    }
     if (s.nrows > 0 && s.sample_chunks > 0)
         GSIM_HIP(gsim::launch_sample(a, s.geo, static_cast<uint32_t>(s.sample_chunks), s.stream));
-    if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+    if (ev && !fused) GSIM_HIP(hipEventRecord(ev[0], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
     if (!caller_syncs) { // the ring slot is free once the scan has run
         GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream));
         s.q_pending[slot] = true;
     }
-    if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
+    if (ev && !fused) GSIM_HIP(hipEventRecord(ev[1], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
     if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
         GSIM_HIP(gsim::launch_select(a, s.d_final, s.d_final_cb, s.final_cap, row_base, out, s.stream));
@@ -346,9 +440,9 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
 }
 
 int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                  float beta, uint32_t row_base, void* out, bool caller_syncs)
+                  float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode = kAuto)
 {
-    const int rc = enqueue_query_impl(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, caller_syncs);
+    const int rc = enqueue_query_impl(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, caller_syncs, mode);
     if (rc != GSIM_OK) s.state_dirty = true;
     return rc;
 }
@@ -372,13 +466,14 @@ int drain_timing(gsim_db* db, Shard& s)
 }
 
 // Running candidate / finalist totals kept on the device by the select kernel.
-int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal)
+int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal, unsigned long long* nredo = nullptr)
 {
     GSIM_HIP(hipSetDevice(s.device));
     GSIM_HIP(hipMemcpyAsync(s.h_state, s.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost, s.stream));
     GSIM_HIP(hipStreamSynchronize(s.stream));
     *ncand = s.h_state->ncand_sum;
     *nfinal = s.h_state->nfinal_sum;
+    if (nredo) *nredo = s.h_state->redo_sum;
     return GSIM_OK;
 }
 
@@ -393,6 +488,75 @@ int wait_stream(hipStream_t st)
     }
     GSIM_HIP(hipStreamSynchronize(st));
     return GSIM_OK;
+}
+
+// Wait for the result block of the last synchronous enqueue on `s` (it was given s.h_result or any
+// pinned block `out`).  The single-launch path signals through the pinned epoch word -- the block
+// is complete when it changes, a few microseconds before the stream reports the kernel retired;
+// a query it handed back (header flag 2) is re-run by the classic kernels here.
+int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                      float beta, uint32_t row_base, void* out)
+{
+    if (!s.last_fused) return wait_stream(s.stream);
+    s.last_fused = false;
+    volatile uint32_t* flag = s.h_done;
+    const uint32_t want = s.epoch;
+    bool done = false;
+    for (uint64_t spins = 0;; spins++) {
+        if (*flag == want) {
+            done = true;
+            break;
+        }
+        if ((spins & 0x3FFu) == 0x3FFu) { // now and then: did the launch fail or end without the flag?
+            const hipError_t e = hipStreamQuery(s.stream);
+            if (e == hipSuccess) {
+                done = *flag == want;
+                break;
+            }
+            if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
+    if (s.d_dbg && done) { // phase profile of this query (instrumented runs only)
+        const size_t nwg = s.fgeo.nwaves / 4;
+        std::vector<unsigned long long> t(nwg * 24 + 8);
+        (void) hipStreamSynchronize(s.stream);
+        (void) hipMemcpy(t.data(), s.d_dbg, t.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull;
+        for (size_t g = 0; g < nwg; g++) t0 = std::min(t0, t[g * 24]);
+        auto stat = [&](int slot, int nslots, double* mn, double* av, double* mx) {
+            double lo = 1e30, hi = 0, sum = 0;
+            size_t n = 0;
+            for (size_t g = 0; g < nwg; g++)
+                for (int q = 0; q < nslots; q++) {
+                    const unsigned long long v = t[g * 24 + slot + q];
+                    if (v < t0 || v - t0 > 100000000ull) continue;
+                    const double us = (v - t0) / 100.0;
+                    lo = std::min(lo, us), hi = std::max(hi, us), sum += us, n++;
+                }
+            *mn = n ? lo : 0, *mx = hi, *av = n ? sum / n : 0;
+        };
+        double a, b, c;
+        std::fprintf(stderr, "fused phases, us after the first workgroup started (min/avg/max over workgroups):\n");
+        const char* names[] = {"start", "scan-end(w0)", "compacted", "arrived", "sel:all-arrived", "sel:loaded", "sel:ranked", "sel:fenced",
+                               "tau-first-seen", "ckpt0-done", "elect-start", "elect-end"};
+        for (int i = 0; i < 12; i++) {
+            stat(i, 1, &a, &b, &c);
+            std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", names[i], a, b, c);
+        }
+        stat(16, 1, &a, &b, &c);
+        std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "elect-loaded", a, b, c);
+        stat(12, 4, &a, &b, &c);
+        std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n  end %.2f\n", "wave scan-end", a, b, c, (t[nwg * 24] - t0) / 100.0);
+        (void) hipMemset(s.d_dbg, 0, t.size() * 8);
+    }
+    if (done && !(h->flags & 2u)) return GSIM_OK;
+    if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
+    // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
+    int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic);
+    if (rc != GSIM_OK) return rc;
+    return wait_stream(s.stream);
 }
 
 bool hit_before(const gsim_hit& x, const gsim_hit& y)
@@ -646,7 +810,8 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
     merged.clear();
     for (auto& s : db->shards) {
         GSIM_HIP(hipSetDevice(s.device));
-        int rc = wait_stream(s.stream);
+        int rc = finish_query_sync(db, s, query, k, cutoff, metric, alpha, beta,
+                                   db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
         if (rc != GSIM_OK) return rc;
         const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
         const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
@@ -703,7 +868,7 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
         for (size_t i = 0; i < db->shards.size(); i++) {
             Shard& s = db->shards[i];
             GSIM_HIP(hipSetDevice(s.device));
-            int rc = wait_stream(s.stream);
+            int rc = finish_query_sync(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result);
             if (rc != GSIM_OK) return rc;
             const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
             const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
@@ -1378,10 +1543,12 @@ int gsim_db_enable_timing(gsim_db* db, int enable)
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
         unsigned long long c = 0, f = 0;
-        rc = read_totals(s, &c, &f);
+        unsigned long long r = 0;
+        rc = read_totals(s, &c, &f, &r);
         if (rc != GSIM_OK) return rc;
         s.base_ncand = c;
         s.base_nfinal = f;
+        s.base_nredo = r;
     }
     db->acc = gsim_timing{};
     return GSIM_OK;
@@ -1392,14 +1559,17 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
     if (!db || !out) return fail(GSIM_ERR_INVALID, "NULL argument");
     db->acc.candidates_sum = 0;
     db->acc.finalists_sum = 0;
+    db->acc.handed_back = 0;
     for (auto& s : db->shards) {
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
         unsigned long long c = 0, f = 0;
-        rc = read_totals(s, &c, &f);
+        unsigned long long r = 0;
+        rc = read_totals(s, &c, &f, &r);
         if (rc != GSIM_OK) return rc;
         db->acc.candidates_sum += c - s.base_ncand;
         db->acc.finalists_sum += f - s.base_nfinal;
+        db->acc.handed_back += r - s.base_nredo;
     }
     *out = db->acc;
     return GSIM_OK;

@@ -14,6 +14,7 @@ constexpr int kScanBins = 1024;
 // Largest finalist count the single-workgroup LDS select handles.
 constexpr int kSelectCap = 8192;
 constexpr int kScanBlock = 256; // 4 wavefronts
+constexpr int kFusedCheckpoints = 16; // single-launch path: threshold checkpoints (trip counts 1, 8, 64, ... and 3/4 of the trips)
 
 // Device-resident per-query state, zeroed before every scan.
 // Device-resident per-query state.  Zero when a query starts: allocated zeroed,
@@ -26,11 +27,18 @@ struct QueryState {
     uint32_t nfinal;             // finalists appended by the compaction
     uint32_t done;               // select-kernel workgroups that have finished (ticket)
     uint32_t gtau;               // table-wide threshold bin shared by all workgroups of the scan (monotone)
-    uint32_t pad0;
+    uint32_t redo;               // single-launch path gave up (candidate overflow, heavy ties): the gated
+                                 // classic kernels behind it run the query; their select kernel clears it
+    // --- single-launch path (fused_kernel) ---
+    uint32_t npub;               // candidates published to the table-wide list by finished workgroups
+    uint32_t arrived;            // workgroups that have finished scanning and publishing (ticket)
+    uint32_t sel_done;           // selector workgroups that have written their hits (ticket)
+    uint32_t final_ready;        // small tables: the threshold of the end-of-scan checkpoint has been published
     // --- not reset per query: running totals for gsim_db_get_timing ---
     unsigned long long ncand_sum;
     unsigned long long nfinal_sum;
     unsigned long long queries;
+    unsigned long long redo_sum; // queries the single-launch path handed back to the four-kernel pipeline
 };
 
 struct ScanGeometry {
@@ -57,7 +65,32 @@ struct ScanArgs {
     uint32_t* cand_cb;        // device, nwaves*seg_cap (common << 16 | popc_db), parallel to cand
     uint32_t* seg_count;      // device, nwaves
     QueryState* state;        // device
+    const uint32_t* gate;     // NULL, or device word: the classic kernels return at once unless *gate != 0
+                              // (they are enqueued behind the single-launch path as its fallback)
 };
+
+// ---- single-launch path: scan + publish + select in ONE kernel (small and mid-size tables) ----
+constexpr uint32_t kFusedMaxK = 2048;       // largest k the single-launch path serves
+constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
+constexpr int kFusedSelectors = 128;        // last-arriving workgroups that run the select
+constexpr uint32_t kFusedPubCap = 1u << 16; // entries of the table-wide published-candidate list (16 B each)
+
+struct FusedArgs {
+    void* pub;            // device, kFusedPubCap x 16 B {key, cb, 0}
+    uint32_t* summ;       // device, nwaves score keys: the waves' checkpoint summaries (zero between queries)
+    uint32_t summ_keys;   // M: every wave reports its M-th best key (fused_summary_keys), 0 = no checkpoints
+    uint32_t* tickets;    // device, kFusedCheckpoints x 9 counters 128 B apart (8 per-group + 1 top), zero between queries
+    void* result;         // result block: device memory or device-visible pinned host memory
+    uint32_t row_base;
+    uint32_t* done_flag;  // NULL, or device-visible pinned host word that receives `epoch` when the block is complete
+    uint32_t epoch;
+    uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 1 no polls, 2 no checkpoints, 4 no LDS histogram
+    unsigned long long* dbg; // NULL, or 8 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
+};
+
+hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s);
+bool fused_supported(const ScanGeometry& g);
+uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k);
 
 // Geometry of the scan grid for a table (host side, no device work).
 ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll);

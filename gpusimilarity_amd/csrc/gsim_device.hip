@@ -2,21 +2,33 @@
 //
 // Replaces the Thrust pipeline of the reference's FingerprintDB::search_storage
 // (fingerprintdb_cuda.cu:228-339: sequence / transform(TanimotoFunctor) /
-// remove_if / sort_by_key over ALL rows) with
+// remove_if / sort_by_key over ALL rows).  Two routes, same results bit for bit:
 //
+// Single-launch path (fused_kernel; k <= kFusedMaxK, the usual case): ONE persistent
+//   launch streams the table, keeps candidates in LDS, exchanges per-wave top-M score
+//   summaries to raise a table-wide score threshold, publishes the survivors and lets
+//   the last-arriving workgroups rank them -- no grid barrier, no histogram, no scratch
+//   in global memory beyond a 1 MB list.  See the comment above fused_kernel.
+//
+// Four-kernel pipeline (the general route: any k, any width, heavy ties, adversarial
+//   row orders; also what the single launch hands a query back to):
+//   K0 sample_kernel   scores a strided sample, histograms it, publishes a starting
+//                      threshold bin for the scan.
 //   K1 scan_kernel     one streaming pass over the table, 16 B per lane coalesced
 //                      loads (a wave64 load instruction = 1 KiB of consecutive
 //                      rows), AND+v_bcnt_u32_b32 popcounts, DPP reduction across
 //                      the lanes of a row, the reference's f32 divide, cutoff, and
-//                      an in-scan streaming top-k filter: every wavefront keeps a
-//                      private coarse score histogram in LDS and only rows at or
-//                      above its running k-th-best bin are written out
-//                      (candidates, 8 B each) -- no per-row score array exists.
-//   K2 compact_kernel  finds the coarse bin of the global k-th best score from
-//                      the merged histogram and keeps the candidates at or above it.
-//   K3 select_kernel   one workgroup: bitonic sort of the finalists' unique 64-bit
-//                      keys (score desc, row asc) in LDS, emits the first k rows
-//                      with their integer popcounts.
+//                      an in-scan streaming top-k filter: the workgroups share a
+//                      table-wide coarse score histogram (device atomics) and a
+//                      monotone threshold bin derived from it; only rows at or above
+//                      it are written out (candidates, 12 B each, per-wave segments)
+//                      -- no per-row score array exists.
+//   K2 compact_kernel  finds the coarse bin of the k-th best score from the now
+//                      complete histogram and keeps the candidates at or above it.
+//   K3 select_kernel   32 workgroups: every finalist's output slot is its rank (the
+//                      number of larger unique 64-bit keys), counted from LDS; more
+//                      than kSelectCap finalists: one workgroup runs an MSD radix
+//                      select; k > kSelectCap: global-memory bitonic sort.
 //
 // This is HBM-bound bit arithmetic: no MFMA anywhere (the work is AND + popcount,
 // not a contraction).  Wave size is hard-wired to 64.
@@ -74,6 +86,8 @@ constexpr uint32_t kFirstPush = 64;
 
 // Per-wave view of the filter (members wave-uniform except `kept`).
 struct WaveFilter {
+    static constexpr bool kFused = false;
+    __device__ __forceinline__ void checkpoint(uint32_t, int) {}
     BlockFilter* sh;
     QueryState* st;
     u64* seg;         // this wave's private candidate segment (keys)
@@ -338,22 +352,14 @@ __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q
     }
 }
 
-template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_kernel(ScanArgs a, ScanGeometry g)
+// The streaming loop of one wavefront: chunks w, w + nwaves, ... of the table through filter f.
+template <int LPR, int U, typename Filter>
+__device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry& g, Filter& f, const u32x4& q, uint32_t w,
+                                          int lane)
 {
-    __shared__ BlockFilter s_filter;
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    block_filter_init(&s_filter, a.k, a.state->gtau);
-
     constexpr int RPL = 64 / LPR; // rows per load instruction
     constexpr int CH = U * RPL;   // rows per chunk
-    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
     const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
-    if (w == 0 && lane < LPR && a.query_dev != a.query) reinterpret_cast<u32x4*>(a.query_dev)[lane] = q;
-
-    WaveFilter f;
-    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
-           a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
     uint32_t gt = 0; // table-wide threshold, loaded ahead of its use
     uint32_t trip = 0;
     const uint32_t wib = w % (kScanBlock / 64);
@@ -381,12 +387,15 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
             // (first 64 chunks), then every 32nd, then every 128th; the waves take turns so that
             // no single wave pays for all polls.  A poll is one more entry in the loop's vmcnt
             // queue: its latency is exposed whenever it exceeds the prefetch's (~1 us each).
+            // (Single-launch path: every chunk of the first 32, in turns -- a small table is over
+            // after 16 trips and its first threshold arrives around the 10th.)
             {
-                const uint32_t period = trip < 64u ? 8u : (trip < 512u ? 32u : 128u);
+                const uint32_t period = (Filter::kFused && trip < 32u) ? 1u : (trip < 64u ? 8u : (trip < 512u ? 32u : 128u));
                 if ((trip & (period - 1u)) == 0 && ((trip / period) & (kScanBlock / 64 - 1)) == wib) gt = f.load_gtau();
                 trip++;
             }
             reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
+            if (Filter::kFused) f.checkpoint(trip, lane);
             if (c == last) break;
         }
     }
@@ -403,8 +412,686 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
         f.refresh(f.load_gtau(), lane);
         reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
     }
+}
+
+template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_kernel(ScanArgs a, ScanGeometry g)
+{
+    __shared__ BlockFilter s_filter;
+    if (a.gate && *a.gate == 0) return; // enqueued as the fallback of the single-launch path, which succeeded
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
+    block_filter_init(&s_filter, a.k, a.state->gtau);
+
+    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
+    if (w == 0 && lane < LPR && a.query_dev != a.query) reinterpret_cast<u32x4*>(a.query_dev)[lane] = q;
+
+    WaveFilter f;
+    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
+           a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+    scan_rows<LPR, U>(a, g, f, q, w, lane);
     f.finish(w, a, lane);
     block_filter_flush(&s_filter, a);
+}
+
+// ---------------------------------------------------------------------------
+// The single-launch path: scan, publish, select and the result block in ONE kernel
+// ---------------------------------------------------------------------------
+//
+// The four-kernel pipeline costs ~110 us of launches, boundaries and host turn-around on
+// top of the streaming time (1 M x 1024-bit rows stream in 18 us), and its table-wide
+// histogram costs ~12 ns per device atomic, serialised per cache line: pushing a 256-row
+// histogram from 256 workgroups is tens of microseconds.  This kernel does the whole query
+// in one persistent launch with NO grid barrier, NO histogram and NO global atomics beyond
+// tickets:
+//
+//   1. every wave streams its chunks (scan_rows) and keeps the rows at or above the current
+//      threshold in its own LDS store (kFusedWaveCap slots; compacted in place when the
+//      threshold has risen).  The threshold is an exact 32-bit score key (order_key), 0 at
+//      the start: until the first one arrives every row is stored -- LDS writes only;
+//   2. checkpoints (after 1, 4, 16, ... trips and after 3/4 of them): every wave writes the
+//      M best score keys it holds to its slot of a small table-wide array (plain
+//      write-through stores, no waiting); the last wave of a workgroup takes a ticket, the
+//      last workgroup reads all nwaves x M keys and publishes the k-th largest as the new
+//      threshold.  Valid because every key is a distinct row really scanned: at least k rows
+//      score at or above it, so no top-k row is below it -- and a slot read early or stale
+//      only holds smaller keys, which only lowers the threshold;
+//   3. a workgroup that has finished filters its stores against the freshest threshold,
+//      appends the survivors to the table-wide published list (one reservation atomic,
+//      16-byte write-through stores) and takes an arrival ticket.  All but the last
+//      kFusedSelectors arrivers exit at once;
+//   4. the last kFusedSelectors arrivers wait (bounded spin; they are the only waiters, so the
+//      grid needs no co-residency guarantee) until every workgroup has arrived, load the
+//      published list (a few thousand rows) into LDS and each ranks the rows it owns (hash of
+//      the row) by counting larger keys -- the output slot of a hit is its rank, keys are
+//      unique -- writing the hits of rank < k straight into the result block;
+//   5. the last selector writes the header, re-zeroes the per-query state and, for the
+//      synchronous API, stores the query's epoch into a pinned host word the caller polls: the
+//      hits (in pinned host memory) are complete when it changes, without waiting for the
+//      kernel's end-of-launch bookkeeping.
+//
+// Whatever the path cannot hold (a store that stays full after compaction, more published
+// rows than a selector's LDS takes: heavy ties, rows in ascending score order) sets
+// QueryState::redo and header flag 2; the four-kernel pipeline then runs the query.
+constexpr int kFusedPubLds = 8192;   // published rows a selector ranks (LDS)
+constexpr int kFusedMineCap = 2048;  // ... of which it owns at most this many
+constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder/elector, poller)
+
+struct FusedShared {
+    union {
+        struct { // while streaming
+            u64 key[kScanBlock / 64][kFusedWaveCap];
+            uint32_t cb[kScanBlock / 64][kFusedWaveCap];
+        } store;
+        struct { // selectors
+            u64 fkey[kFusedPubLds];
+            uint32_t mine_idx[kFusedMineCap];
+            uint32_t mine_cb[kFusedMineCap];
+        } sel;
+    };
+    uint32_t tau;       // workgroup's copy of the score-key threshold (monotone; kept fresh by the service wave)
+    uint32_t overflow;  // a wave's store overflowed
+    uint32_t nemit;     // rows stored by the workgroup (statistics)
+    uint32_t scan_done; // streaming waves that have finished
+    uint32_t elect_req; // forwarder -> poller: this workgroup took the last ticket of a checkpoint, run the election
+    uint32_t ck_cnt[kFusedCheckpoints];             // streaming waves that have left their summary for checkpoint j
+    uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
+    uint32_t wcount[kScanBlock / 64];
+    uint32_t base, ticket, nmine, ok;
+};
+
+__device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-wide max, DPP within the 16-lane rows and four readlanes (a shuffle chain costs ~700 cycles)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    uint32_t o;
+    o = dpp<0xB1>(v);  v = o > v ? o : v;
+    o = dpp<0x4E>(v);  v = o > v ? o : v;
+    o = dpp<0x141>(v); v = o > v ? o : v;
+    o = dpp<0x140>(v); v = o > v ? o : v;
+    const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+// wave-wide sum, same shape
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+    v += dpp<0xB1>(v);
+    v += dpp<0x4E>(v);
+    v += dpp<0x141>(v);
+    v += dpp<0x140>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+// checkpoint j is due after 4^j trips; the last one after 3/4 of the trips every wave makes
+struct FusedSchedule {
+    uint32_t min_trips, last_ck;
+    __device__ __forceinline__ void init(uint32_t min_trips_)
+    {
+        min_trips = min_trips_;
+        uint32_t np = 0;
+        while (np < 14 && (1u << (2 * np)) < min_trips) np++;
+        last_ck = np;
+    }
+    __device__ __forceinline__ uint32_t trip(uint32_t j) const
+    {
+        if (j < last_ck) return 1u << (2 * j);
+        if (j == last_ck) {
+            const uint32_t t = min_trips - min_trips / 4;
+            return (min_trips >= 32 && t > (1u << (2 * (last_ck - 1)))) ? t : 0xFFFFFFFFu;
+        }
+        return 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ uint32_t count() const // number of checkpoints inside the streaming loop
+    {
+        return last_ck + (trip(last_ck) != 0xFFFFFFFFu ? 1u : 0u);
+    }
+    // Small tables: a threshold takes ~12 us from checkpoint to every workgroup (tickets, election,
+    // polls) and the table is over in 20-60: the last in-loop threshold is drawn from a small part
+    // of the rows and would publish far more than k of them.  Such tables get one more checkpoint
+    // AFTER the loop, over all rows, and the workgroups wait (bounded) for its threshold before
+    // they publish: one more hop, ~1.7 k rows published instead of 10-20 k.
+    __device__ __forceinline__ bool final_wait() const { return min_trips < 64; }
+};
+
+// A streaming wave's view.  Its loop touches global memory only through the table loads: the
+// threshold comes from LDS (the service wave keeps it fresh), summaries go to LDS.  gfx950 counts
+// loads, stores and atomics in ONE in-order counter, so a single global store or atomic inside
+// the loop would drain the prefetch at the next wait (1-4 us each).
+struct FusedFilter {
+    static constexpr bool kFused = true;
+    FusedShared* sh;
+    QueryState* st;
+    u64* skey;      // this wave's LDS store
+    uint32_t* scb;
+    uint32_t M, wv, w;
+    uint32_t k, tau, staged, kept, emitted;
+    float cutoff;
+    bool has_cutoff, store_off;
+    FusedSchedule sched;
+    uint32_t next_ck, ck_j;
+    u64* dbg;
+
+    __device__ __forceinline__ uint32_t load_gtau() const { return 0u; } // (no polls from the streaming loop)
+
+    __device__ __forceinline__ void refresh(uint32_t g, int lane)
+    {
+        const uint32_t t = __hip_atomic_load(&sh->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dbg && tau == 0 && (t | g) != 0 && lane == 0 && wv == 0) dbg[8] = wall_clock64();
+        tau = t > tau ? t : tau;
+        if (g > tau) {
+            tau = g;
+            if (lane == 0) atomicMax(&sh->tau, g);
+        }
+    }
+
+    // The M-th best score key of this wave's store -> the workgroup's LDS summary: "this wave holds M
+    // distinct rows scoring at least this".  Every lane keeps the best four of the entries it visits,
+    // then M rounds of wave-wide max + pop (a lane that holds more than four of the wave's M best
+    // under-reports: a smaller key, for which the statement still holds).
+    __device__ __forceinline__ void write_summary(int lane)
+    {
+        uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (uint32_t i = lane; i < staged; i += 64) {
+            const uint32_t v = static_cast<uint32_t>(skey[i] >> 32);
+            if (v > t3) {
+                t3 = v;
+                if (t3 > t2) { const uint32_t x = t2; t2 = t3; t3 = x; }
+                if (t2 > t1) { const uint32_t x = t1; t1 = t2; t2 = x; }
+                if (t1 > t0) { const uint32_t x = t0; t0 = t1; t1 = x; }
+            }
+        }
+        uint32_t mth = 0;
+        for (uint32_t r = 0; r < M; r++) {
+            mth = wave_max_u32(t0);
+            const u64 b = __ballot(t0 == mth);
+            if (lane == __builtin_ctzll(b)) {
+                t0 = t1;
+                t1 = t2;
+                t2 = t3;
+                t3 = 0;
+            }
+        }
+        if (lane == 0) sh->wsum[wv] = mth; // 0: fewer than M rows so far
+    }
+
+    // called once per trip of the streaming loop with the number of chunks this wave has finished
+    __device__ __forceinline__ void checkpoint(uint32_t trips_done, int lane)
+    {
+        if (trips_done != next_ck) return;
+        write_summary(lane);
+        if (lane == 0) atomicAdd(&sh->ck_cnt[ck_j], 1u); // (LDS, after the summary: a wave's LDS operations execute in order)
+        if (dbg && lane == 0 && wv == 0 && ck_j == 0) dbg[9] = wall_clock64();
+        ck_j++;
+        next_ck = M ? sched.trip(ck_j) : 0xFFFFFFFFu;
+    }
+
+    // drop the stored rows below the current threshold, in place.  One wave; LDS operations of a
+    // wave execute in order: a batch is read completely before its survivors are written at or
+    // below the positions just read.
+    __device__ __forceinline__ void compact_store(int lane)
+    {
+        uint32_t out = 0;
+        for (uint32_t base = 0; base < staged; base += 64) {
+            const uint32_t i = base + lane;
+            const bool in = i < staged;
+            const u64 key = in ? skey[i] : 0ull;
+            const uint32_t cb = in ? scb[i] : 0u;
+            const bool keep = in && static_cast<uint32_t>(key >> 32) >= tau;
+            const u64 m = __ballot(keep);
+            if (keep) {
+                const uint32_t slot = out + lane_rank(m);
+                skey[slot] = key;
+                scb[slot] = cb;
+            }
+            out += static_cast<uint32_t>(__popcll(m));
+        }
+        staged = out;
+    }
+
+    // One row per lane (or an inactive lane).
+    __device__ __forceinline__ void offer(bool active, uint32_t row, float raw_score, uint32_t cb, int lane)
+    {
+        const float s = apply_cutoff(raw_score, cutoff);
+        const bool keep = active && (!has_cutoff || s != 0.0f);
+        kept += keep ? 1u : 0u;
+        const uint32_t okey = order_key(s);
+        const bool cand = keep && okey >= tau;
+        const u64 m = __ballot(cand);
+        if (m == 0) return;
+        const uint32_t n = static_cast<uint32_t>(__popcll(m));
+        emitted += n;
+        if (store_off) return;
+        if (cand) {
+            const uint32_t slot = staged + lane_rank(m);
+            skey[slot] = (static_cast<u64>(okey) << 32) | static_cast<u64>(~row);
+            scb[slot] = cb;
+        }
+        staged += n;
+        if (staged > static_cast<uint32_t>(kFusedWaveCap - 64)) {
+            refresh(agent_load(&st->gtau), lane);
+            compact_store(lane);
+            if (staged > static_cast<uint32_t>(kFusedWaveCap - 64)) {
+                store_off = true; // ties / rows in ascending score order: the four-kernel pipeline takes the query
+                if (lane == 0) __hip_atomic_store(&sh->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+};
+
+// The election: every wave reported its M-th best score key, so each of the r = ceil(k / M) largest
+// reports stands for M distinct rows at or above it: at least k rows score at or above the r-th
+// largest report, which is published as the threshold (to 15 leading bits, rounded down).  One wave.
+__device__ __forceinline__ void fused_elect(FusedShared& sh, QueryState* st, uint32_t* summ, uint32_t nvals, uint32_t k,
+                                            int lane, u64* dbg)
+{
+    if (dbg && lane == 0) dbg[10] = wall_clock64();
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(summ, 0, nvals * 4u, 0x00020000);
+    uint32_t v[64];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { // (reads past nvals return 0)
+        const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (i * 64 + lane) * 16, 0, /*sc1*/ 16);
+        v[4 * i + 0] = x.x;
+        v[4 * i + 1] = x.y;
+        v[4 * i + 2] = x.z;
+        v[4 * i + 3] = x.w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dbg && lane == 0) dbg[16] = wall_clock64();
+    // (k here is the rank r.)  Keys of kept rows with a score in [0, 2) have bit 31 set and bit 30 clear; the selection runs
+    // on bits 29..15 (the exponent and 8 bits of the mantissa), two 15-bit values per register.
+    // Anything else is reported smaller than it is (negative scores as absent, scores >= 2 clamped):
+    // under-reporting only lowers the threshold.  y >= c  <=>  bit 15 of (y + 0x8000 - c).
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 y[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        uint32_t q[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t x = v[2 * i + h];
+            const uint32_t m = (x & 0x7FFFFFFFu) >> 15;
+            q[h] = (x & 0x80000000u) ? (m > 0x7FFFu ? 0x7FFFu : m) : 0u;
+        }
+        y[i] = u16x2{static_cast<unsigned short>(q[0]), static_cast<unsigned short>(q[1])};
+    }
+    const uint32_t pairs = (nvals + 127) / 128; // registers in use per lane (values past nvals are 0)
+    uint32_t p15 = 0;
+#pragma unroll 1
+    for (int bit = 14; bit >= 0; bit--) { // rolled: this code runs once per checkpoint, from a cold instruction cache
+        const uint32_t cand = p15 | (1u << bit);
+        const unsigned short kk = static_cast<unsigned short>(0x8000u - cand);
+        const u16x2 kv{kk, kk};
+        u16x2 c0{0, 0}, c1{0, 0};
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            if (static_cast<uint32_t>(gq * 8) < pairs) {
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    c0 += (y[8 * gq + i] + kv) >> 15;
+                    c1 += (y[8 * gq + i + 1] + kv) >> 15;
+                }
+            }
+        }
+        const u16x2 cs = c0 + c1;
+        const uint32_t c = static_cast<uint32_t>(cs.x) + static_cast<uint32_t>(cs.y);
+        if (wave_sum_dpp(c) >= k) p15 = cand;
+    }
+    const uint32_t prefix = p15 ? (0x80000000u | (p15 << 15)) : 0u; // p15 == 0: fewer than r reports so far
+    if (prefix != 0 && lane == 0) {
+        atomicMax(&st->gtau, prefix);
+        atomicMax(&sh.tau, prefix);
+    }
+    if (dbg && lane == 0) dbg[11] = wall_clock64();
+}
+
+// The service waves: everything of the threshold protocol that touches global memory.
+//
+// Wave 4 (forwarder): when the four streaming waves have left their summaries for checkpoint j,
+// copies them (4 keys) to the table-wide array and takes the checkpoint's ticket -- two
+// levels, one counter per XCD-sized group of workgroups (b % 8) and one on top, 128 bytes apart:
+// 256 arrivals on one word serialise at ~12 ns each.  The last arriver runs the election.  The
+// stores are not waited for: a slot read before its store lands holds smaller keys (older or
+// zero), which only lowers the threshold.
+// Wave 5 (poller): keeps the workgroup's LDS copy of the table-wide threshold fresh; it polls
+// every microsecond at first (a small table is over in 20) and backs off to one poll per ~16 us.
+__device__ __forceinline__ void fused_forwarder(FusedShared& sh, QueryState* st, const FusedArgs& fa, const FusedSchedule& sched,
+                                                int lane)
+{
+    const uint32_t M = fa.summ_keys;
+    if (M == 0) return;
+    const bool final_wait = sched.final_wait();
+    const uint32_t nloop = sched.count(), nck = nloop + (final_wait ? 1u : 0u);
+    const uint32_t nwg = gridDim.x;
+    const uint32_t x = blockIdx.x % 8u;
+    const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
+    for (uint32_t j = 0, spins = 0; j < nck; spins++) {
+        if (__hip_atomic_load(&sh.ck_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != kScanBlock / 64) {
+            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) {
+                // the streaming loop is over: in-loop checkpoints it did not reach no longer matter
+                if (!final_wait) break;
+                if (j < nloop) j = nloop;
+                continue;
+            }
+            if (spins > (1u << 24)) break;
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        if (lane < kScanBlock / 64)
+            __hip_atomic_store(&fa.summ[static_cast<u64>(blockIdx.x) * (kScanBlock / 64) + lane], sh.wsum[lane], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t* tk = fa.tickets + static_cast<size_t>(j) * 9 * 32;
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&tk[x * 32], 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t == group_size - 1) {
+            if (lane == 0) t = atomicAdd(&tk[8 * 32], 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t == ngroups - 1 && lane == 0) // the poller wave runs the election: this wave stays free for the next checkpoint
+                __hip_atomic_store(&sh.elect_req, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        j++;
+    }
+}
+
+__device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, const FusedArgs& fa, const FusedSchedule& sched,
+                                             uint32_t nwaves, uint32_t k, int lane, u64* dbg)
+{
+    const bool final_wait = fa.summ_keys != 0 && sched.final_wait();
+    const uint32_t jfinal = sched.count() + 1; // elect_req value of the end-of-scan checkpoint
+    for (uint32_t spins = 0; spins < (1u << 24); spins++) {
+        const uint32_t g = agent_load(&st->gtau);
+        if (lane == 0 && g > __hip_atomic_load(&sh.tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.tau, g);
+        if (final_wait && agent_load(&st->final_ready)) return;
+        // ~0.25 us naps for the first 30 us (a small table is over in 20), then ~1 us, later 16 of those per poll
+        const uint32_t naps = spins < 512u ? 1u : 16u;
+        for (uint32_t i = 0; i < naps; i++) {
+            if (!final_wait && __hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
+            const uint32_t req = __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (req) {
+                if (lane == 0) __hip_atomic_store(&sh.elect_req, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
+                if (final_wait && req == jfinal) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the threshold is out before the flag
+                    if (lane == 0) __hip_atomic_store(&st->final_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+            if (spins < 64u) __builtin_amdgcn_s_sleep(32);
+            else __builtin_amdgcn_s_sleep(127);
+        }
+    }
+}
+
+template <int LPR, int U>
+__global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeometry g, FusedArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
+    FusedShared& sh = *reinterpret_cast<FusedShared*>(fused_smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    QueryState* st = a.state;
+    u64* dbg = fa.dbg ? fa.dbg + static_cast<u64>(blockIdx.x) * 24 : nullptr;
+#define GSIM_STAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+    GSIM_STAMP(0);
+    if (tid == 0) {
+        sh.tau = 0;
+        sh.overflow = 0;
+        sh.nemit = 0;
+        sh.scan_done = 0;
+        sh.elect_req = 0;
+    }
+    if (tid < kFusedCheckpoints) sh.ck_cnt[tid] = 0;
+    __syncthreads();
+    FusedSchedule sched;
+    sched.init(static_cast<uint32_t>((a.nrows / (U * (64 / LPR))) / g.nwaves));
+    if (wv == kScanBlock / 64) {
+        fused_forwarder(sh, st, fa, sched, lane);
+        return;
+    }
+    if (wv == kScanBlock / 64 + 1) {
+        fused_poller(sh, st, fa, sched, g.nwaves, a.k, lane, dbg);
+        return;
+    }
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wv);
+
+    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
+    FusedFilter f;
+    f.sh = &sh;
+    f.st = st;
+    f.skey = sh.store.key[wv];
+    f.scb = sh.store.cb[wv];
+    f.M = (fa.xflags & 2u) ? 0u : fa.summ_keys;
+    f.wv = static_cast<uint32_t>(wv);
+    f.w = w;
+    f.k = a.k;
+    f.tau = 0;
+    f.staged = 0;
+    f.kept = 0;
+    f.emitted = 0;
+    f.cutoff = a.cutoff;
+    f.has_cutoff = a.cutoff > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
+    f.store_off = false;
+    f.sched = sched;
+    f.ck_j = 0;
+    f.next_ck = f.M ? sched.trip(0) : 0xFFFFFFFFu;
+    f.dbg = dbg;
+    scan_rows<LPR, U>(a, g, f, q, w, lane);
+    const bool final_wait = f.M != 0 && sched.final_wait();
+    if (final_wait) { // the end-of-scan checkpoint: this wave's M-th best over all its rows
+        f.write_summary(lane);
+        if (lane == 0) atomicAdd(&sh.ck_cnt[sched.count()], 1u);
+    }
+    if (lane == 0) atomicAdd(&sh.scan_done, 1u);
+    if (f.has_cutoff) {
+        const uint32_t tot = wave_sum(f.kept);
+        if (lane == 0 && tot) atomicAdd(&st->kept, static_cast<u64>(tot));
+    }
+    if (dbg && lane == 0) dbg[12 + wv] = wall_clock64();
+    if (dbg && lane == 0 && wv == 0) dbg[1] = wall_clock64();
+
+    // ---- 3. publish this workgroup's survivors ----------------------------------------------
+    if (final_wait) {
+        if (wv == 0 && lane == 0) {
+            for (uint32_t spins = 0; agent_load(&st->final_ready) == 0 && spins < (1u << 16); spins++) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads(); // (released once the service waves have exited too)
+    }
+    f.refresh(agent_load(&st->gtau), lane);
+    if (!f.store_off) f.compact_store(lane);
+    if (lane == 0) {
+        sh.wcount[wv] = f.store_off ? 0u : f.staged;
+        if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
+    }
+    __syncthreads();
+    GSIM_STAMP(2);
+    const uint32_t nwg = gridDim.x;
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < kScanBlock / 64; i++) tot += sh.wcount[i];
+        uint32_t base = 0;
+        if (tot) base = atomicAdd(&st->npub, tot);
+        if (sh.overflow || base + tot > kFusedPubCap) {
+            atomicOr(&st->redo, 1u);
+            base = kFusedPubCap; // nothing is stored
+        }
+        sh.base = base;
+        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit));
+    }
+    __syncthreads();
+    {
+        uint32_t off = sh.base;
+        for (int i = 0; i < wv; i++) off += sh.wcount[i];
+        if (sh.base < kFusedPubCap && !f.store_off) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, kFusedPubCap * 16u, 0x00020000);
+            for (uint32_t i = lane; i < f.staged; i += 64) {
+                const u64 key = f.skey[i];
+                const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, (off + i) * 16u, 0, /*sc1: write-through*/ 16);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries are out
+    __syncthreads();
+    if (tid == 0) sh.ticket = atomicAdd(&st->arrived, 1u);
+    __syncthreads();
+    GSIM_STAMP(3);
+    const uint32_t ticket = sh.ticket;
+    const uint32_t nsel = nwg < static_cast<uint32_t>(kFusedSelectors) ? nwg : static_cast<uint32_t>(kFusedSelectors);
+    if (ticket + nsel < nwg) return; // not one of the last arrivers
+
+    // ---- 4. select (the last nsel arrivers) -------------------------------------------------
+    const uint32_t r = ticket - (nwg - nsel);
+    if (tid == 0) {
+        uint32_t ok = 1;
+        for (uint32_t spins = 0; agent_load(&st->arrived) < nwg; spins++) {
+            __builtin_amdgcn_s_sleep(2);
+            if (spins > (1u << 24)) { // a workgroup never arrived (seconds): give the query to the classic kernels
+                ok = 0;
+                atomicOr(&st->redo, 1u);
+                break;
+            }
+        }
+        sh.ok = ok;
+        sh.nmine = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    GSIM_STAMP(4);
+    // the first 2048 published rows are requested before their count is known (the list has room)
+    constexpr int PL = 8; // published entries in flight per thread
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, kFusedPubCap * 16u, 0x00020000);
+    u32x4 e[PL];
+#pragma unroll
+    for (int u = 0; u < PL; u++)
+        e[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (u * kScanBlock + tid) * 16u, 0, /*sc1*/ 16);
+    const uint32_t npub = agent_load(&st->npub);
+    bool good = sh.ok && agent_load(&st->redo) == 0 && npub <= static_cast<uint32_t>(kFusedPubLds);
+    if (good) {
+        for (uint32_t i0 = 0; i0 < npub; i0 += kScanBlock * PL) {
+#pragma unroll
+            for (int u = 0; u < PL; u++) {
+                const uint32_t i = i0 + u * kScanBlock + tid;
+                if (i < npub) {
+                    sh.sel.fkey[i] = (static_cast<u64>(e[u].y) << 32) | e[u].x;
+                    const uint32_t row = ~e[u].x;
+                    if (((row * 2654435761u) >> 16) % nsel == r) { // this selector ranks it
+                        const uint32_t mp = atomicAdd(&sh.nmine, 1u);
+                        if (mp < static_cast<uint32_t>(kFusedMineCap)) {
+                            sh.sel.mine_idx[mp] = i;
+                            sh.sel.mine_cb[mp] = e[u].z;
+                        }
+                    }
+                }
+            }
+            if (i0 + kScanBlock * PL < npub) { // (rare: more than 2048 published rows)
+#pragma unroll
+                for (int u = 0; u < PL; u++)
+                    e[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (i0 + kScanBlock * PL + u * kScanBlock + tid) * 16u, 0, /*sc1*/ 16);
+            }
+        }
+        if (tid == 0 && (npub & 1u)) sh.sel.fkey[npub] = 0ull; // pad to a pair for the b128 reads (npub < kFusedPubLds or even)
+        __syncthreads();
+        GSIM_STAMP(5);
+        const uint32_t nmine = sh.nmine;
+        good = nmine <= static_cast<uint32_t>(kFusedMineCap);
+        if (good) {
+            gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
+            gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+            const uint32_t npair = (npub + 1u) >> 1;
+            const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.sel.fkey);
+            // RG lanes share one row: each counts the larger keys among every RG-th pair
+            // (ds_read_b128, two keys per read, several reads in flight), then a shuffle sum
+            constexpr int RG = 16;
+            const uint32_t sub = static_cast<uint32_t>(tid % RG);
+            for (uint32_t t0 = 0; t0 < nmine; t0 += kScanBlock / RG) {
+                const uint32_t t = t0 + static_cast<uint32_t>(tid / RG);
+                const bool have = t < nmine;
+                const u64 mine = have ? sh.sel.fkey[sh.sel.mine_idx[t]] : ~0ull;
+                uint32_t rank = 0;
+                for (uint32_t j0 = sub; j0 < npair; j0 += RG * 8) { // eight reads in flight
+                    ulonglong2 kk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t j = j0 + u * RG;
+                        kk[u] = k2[j < npair ? j : npair - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool in = j0 + u * RG < npair;
+                        rank += (in && kk[u].x > mine) ? 1u : 0u;
+                        rank += (in && kk[u].y > mine) ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int d = RG / 2; d > 0; d >>= 1) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), d, 64));
+                if (have && sub == 0 && rank < a.k) {
+                    const uint32_t cb = sh.sel.mine_cb[t];
+                    gsim_hit h;
+                    h.row = ~static_cast<uint32_t>(mine) + fa.row_base;
+                    h.score = key_score(static_cast<uint32_t>(mine >> 32));
+                    h.common = static_cast<uint16_t>(cb >> 16);
+                    h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
+                    hits[rank] = h;
+                }
+            }
+        }
+    }
+    if (!good && tid == 0) atomicOr(&st->redo, 1u);
+    // ---- 5. the last selector closes the query -----------------------------------------------
+    GSIM_STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its hits have left the CU
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // one write-back for the workgroup (system scope)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sh.ticket = atomicAdd(&st->sel_done, 1u);
+    }
+    __syncthreads();
+    GSIM_STAMP(7);
+    if (sh.ticket != nsel - 1) return;
+    const uint32_t redo = agent_load(&st->redo);
+    if (tid == 0) {
+        gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
+        hdr->count = redo ? 0u : (npub < a.k ? npub : a.k);
+        hdr->flags = redo ? 2u : 0u;
+        hdr->approx = a.cutoff > 0.0f ? __hip_atomic_load(&st->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nrows;
+        st->ncand_sum += __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st->nfinal_sum += redo ? 0u : npub;
+        st->queries += redo ? 0u : 1u;
+        st->redo_sum += redo ? 1u : 0u;
+        __hip_atomic_store(&st->final_ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->kept, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->ncand, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->gtau, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->npub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
+    { // the summaries: zero again for the next query (16-byte stores)
+        uint4* sm = reinterpret_cast<uint4*>(fa.summ);
+        const uint32_t n16 = (g.nwaves + 3) / 4;
+        for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0};
+    }
+    if (fa.done_flag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(fa.done_flag, fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (dbg && tid == 0) fa.dbg[static_cast<u64>(gridDim.x) * 24] = wall_clock64(); // the very end
+#undef GSIM_STAMP
 }
 
 // K0 sample_kernel: a valid starting threshold for the scan.
@@ -433,6 +1120,7 @@ __global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t
 {
     __shared__ uint32_t s_hist[kScanBins];
     __shared__ uint32_t s_last;
+    if (a.gate && *a.gate == 0) return;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
     for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
@@ -488,6 +1176,7 @@ __global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t
 __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, ScanGeometry g)
 {
     __shared__ BlockFilter s_filter;
+    if (a.gate && *a.gate == 0) return;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
     block_filter_init(&s_filter, a.k, a.state->gtau);
@@ -537,6 +1226,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_kernel(ScanArgs a, ScanGeo
     __shared__ u64 s_stage[kCompactStage];
     __shared__ uint32_t s_stage_cb[kCompactStage];
     __shared__ uint32_t s_n, s_base;
+    if (a.gate && *a.gate == 0) return;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
     if (threadIdx.x == 0) s_n = 0;
@@ -756,6 +1446,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
     uint32_t* dhist = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kSelectCap) * sizeof(u64));
     uint32_t* ctl = dhist + 256; // [0] digit, [1] remaining, [2] gather cursor, [3] last-workgroup flag
     const int tid = threadIdx.x;
+    if (a.gate && *a.gate == 0) return; // every workgroup reads the gate before the last one can clear it (ticket below)
     gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
     gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
     uint32_t m2 = a.k ? a.state->nfinal : 0;
@@ -811,6 +1502,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
             a.state->nfinal = 0;
             a.state->done = 0;
             a.state->gtau = 0;
+            a.state->redo = 0;
         }
         for (int i = tid; i < kScanBins; i += kSelectThreads) a.state->ghist[i] = 0;
     }
@@ -827,6 +1519,7 @@ __global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st)
         st->nfinal = 0;
         st->done = 0;
         st->gtau = 0;
+        st->redo = 0;
     }
     for (int i = threadIdx.x; i < kScanBins; i += 256) st->ghist[i] = 0;
 }
@@ -1077,6 +1770,55 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
     hipLaunchKernelGGL(scan_generic_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
     return hipGetLastError();
+}
+
+template <int LPR, int U>
+hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
+{
+    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    static bool attr_done = false; // (the attribute is per function, not per device, on this runtime)
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel<LPR, U>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(FusedShared)));
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((fused_kernel<LPR, U>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
+    return hipGetLastError();
+}
+
+bool fused_supported(const ScanGeometry& g)
+{
+    return g.lanes_per_row != 0 && g.unroll == 8;
+}
+
+// M of the checkpoint summaries ("my M-th best key"): about 2k / nwaves, so that the election's rank
+// r = ceil(k / M) sits in the middle of the reports; 0 when even M = 16 leaves r above the number of
+// waves (tiny grids: no thresholds, every row is published) or the reports would not fit the
+// electing wave's registers (64 x 64 keys).
+uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k)
+{
+    if (nwaves == 0 || nwaves > 4096) return 0;
+    uint32_t m = (2 * k + nwaves - 1) / nwaves;
+    if (m < 1) m = 1;
+    if (m > 16) m = 16;
+    if ((k + m - 1) / m > nwaves) return 0;
+    return m;
+}
+
+hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
+{
+#define GSIM_CASE(L) \
+    if (g.lanes_per_row == L && g.unroll == 8) return launch_fused_t<L, 8>(a, g, f, s);
+    GSIM_CASE(1)
+    GSIM_CASE(2)
+    GSIM_CASE(4)
+    GSIM_CASE(8)
+    GSIM_CASE(16)
+    GSIM_CASE(32)
+    GSIM_CASE(64)
+#undef GSIM_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned long long* finalists,

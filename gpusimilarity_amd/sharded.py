@@ -13,6 +13,14 @@ host (fingerprintdb_cuda.cu:356-380).  Scheme:
 
 Exactness: the global top-k is a subset of the union of the local top-k lists and
 the canonical order (score desc, GLOBAL row asc) is shard-invariant.
+
+Stream contract.  On a GPU the local search, the gather, the merge and the copy of
+the merged block to pinned host memory are all ordered on ONE stream.  Pass the
+:class:`capi.Table` itself and the classes here own that contract: they create (or
+take) the torch stream, hand it to the table (``gsim_db_set_stream``) and run every
+step under it.  A bare callable is accepted too (the CPU tests supply the local
+search from the oracle); on a GPU the caller is then responsible for having put the
+table on the stream given as ``stream``.
 """
 from __future__ import annotations
 
@@ -30,85 +38,143 @@ def shard_range(total_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return first, min(per, total_rows - first)
 
 
-class ShardedSearch:
-    """Gather + merge of per-rank result blocks.
+class _Gather:
+    """What both classes share: process group facts, the stream, the block gather."""
 
-    ``local_search(query, k, block)`` must leave this rank's result block in the
-    uint8 tensor ``block`` (device tensor: enqueue on the current stream; CPU
-    tensor: fill synchronously).  On a GPU that is ``Table.search_device``.
-    """
-
-    def __init__(self, local_search: Callable, k: int, device, group=None, stream_ptr: Optional[int] = None):
+    def _setup(self, local, device, group, stream, search_kwargs):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.k = k
         self.device = torch.device(device)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.on_gpu = self.device.type == "cuda"
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        # gloo cannot move device memory: blocks are staged through pinned host buffers (a test
+        # configuration -- two ranks sharing one GPU, which RCCL refuses; production is nccl = RCCL)
+        self.staged = self.on_gpu and self.world > 1 and self.backend != "nccl"
+        self.stream = None
+        if self.on_gpu:
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self.table = None
+        if isinstance(local, capi.Table):
+            if not self.on_gpu:
+                raise ValueError("a capi.Table searches on a GPU: device must be cuda:N")
+            self.table = local
+            self.table.set_stream(self.stream.cuda_stream)  # every later enqueue is ordered on self.stream
+        self.kw = dict(search_kwargs or {})
+        self.local_search = local if self.table is None else None
+
+    def _stream_ctx(self):
+        if self.on_gpu:
+            return self.torch.cuda.stream(self.stream)
+        import contextlib
+        return contextlib.nullcontext()
+
+    def _all_gather(self, gathered, local, h_local=None, h_gathered=None):
+        """gathered = concatenation of every rank's `local`, stream-ordered on a GPU."""
+        if self.world == 1:
+            gathered.copy_(local)
+        elif self.staged:
+            h_local.copy_(local, non_blocking=True)
+            self.stream.synchronize()
+            self.dist.all_gather_into_tensor(h_gathered, h_local, group=self.group)
+            gathered.copy_(h_gathered, non_blocking=True)
+        else:
+            self.dist.all_gather_into_tensor(gathered, local, group=self.group)
+
+    def synchronize(self):
+        """Wait until the last enqueued result is in host memory."""
+        if self.on_gpu:
+            self.stream.synchronize()
+
+    def describe(self):
+        """Facts about this rank's place in the group (bench.py puts them into its JSON line)."""
+        d = {"rank": self.rank, "world": self.world, "backend": self.backend,
+             "device": str(self.device), "staged_gather": bool(self.staged)}
+        if self.on_gpu:
+            p = self.torch.cuda.get_device_properties(self.device)
+            d["device_name"] = p.name
+            d["pci_bus_id"] = getattr(p, "pci_bus_id", None)
+        return d
+
+
+class ShardedSearch(_Gather):
+    """Gather + merge of per-rank result blocks, one query at a time.
+
+    ``local`` is this rank's :class:`capi.Table` (GPU) or a callable
+    ``local_search(query, k, block)`` that leaves the rank's result block in the uint8
+    tensor ``block`` (device tensor: enqueue on the current stream; CPU tensor: fill
+    synchronously).
+    """
+
+    def __init__(self, local, k: int, device, group=None, stream=None, search_kwargs: Optional[dict] = None):
+        self._setup(local, device, group, stream, search_kwargs)
+        torch = self.torch
+        self.k = k
         self.blk = capi.result_block_bytes(k)
-        self.local_search = local_search
-        self.stream_ptr = stream_ptr
         self.local = torch.zeros(self.blk, dtype=torch.uint8, device=self.device)
         self.gathered = torch.zeros(self.blk * self.world, dtype=torch.uint8, device=self.device)
         self.merged = torch.zeros(self.blk, dtype=torch.uint8, device=self.device)
-        self.on_gpu = self.device.type == "cuda"
         self.host_out = torch.zeros(self.blk, dtype=torch.uint8)
+        self.h_local = self.h_gathered = None
         if self.on_gpu:
             self.host_out = self.host_out.pin_memory()
+            if self.staged:
+                self.h_local = torch.zeros(self.blk, dtype=torch.uint8).pin_memory()
+                self.h_gathered = torch.zeros(self.blk * self.world, dtype=torch.uint8).pin_memory()
+            torch.cuda.current_stream(self.device).synchronize()  # the zero fills ran on the current stream
 
     def enqueue(self, query) -> None:
-        """Local search, all-gather, merge; on a GPU everything is stream-ordered and
-        nothing here waits for the host."""
-        self.local_search(query, self.k, self.local)
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.gathered, self.local, group=self.group)
-        else:
-            self.gathered.copy_(self.local)
-        if self.on_gpu:
-            capi.merge_device(self.device.index or 0, self.stream_ptr or 0, self.gathered.data_ptr(), self.world,
-                              self.blk, self.k, self.merged.data_ptr())
-            self.host_out.copy_(self.merged, non_blocking=True)
-        else:
-            out = capi.merge_host(self.gathered.numpy().tobytes(), self.world, self.blk, self.k)
-            self.host_out.copy_(self.torch.frombuffer(bytearray(out), dtype=self.torch.uint8))
+        """Local search, all-gather, merge; on a GPU everything is ordered on self.stream and
+        (with the nccl backend) nothing here waits for the host."""
+        with self._stream_ctx():
+            if self.table is not None:
+                self.table.search_device(query, self.k, self.local.data_ptr(), **self.kw)
+            else:
+                self.local_search(query, self.k, self.local)
+            self._all_gather(self.gathered, self.local, self.h_local, self.h_gathered)
+            if self.on_gpu:
+                capi.merge_device(self.device.index or 0, self.stream.cuda_stream, self.gathered.data_ptr(),
+                                  self.world, self.blk, self.k, self.merged.data_ptr())
+                self.host_out.copy_(self.merged, non_blocking=True)
+            else:
+                out = capi.merge_host(self.gathered.numpy().tobytes(), self.world, self.blk, self.k)
+                self.host_out.copy_(self.torch.frombuffer(bytearray(out), dtype=self.torch.uint8))
 
     def result(self):
-        """(hits, approx, flags) of the last enqueued query (after the stream is synchronised)."""
+        """(hits, approx, flags) of the last enqueued query (after :meth:`synchronize`)."""
         return capi.parse_result_block(self.host_out.numpy().tobytes(), self.k)
 
 
-class ShardedBatchSearch:
+class ShardedBatchSearch(_Gather):
     """The same gather + merge for batches of nq queries (BASELINE config 5: 256 queries per call).
 
-    ``local_search(queries, k, blocks)`` leaves this rank's nq result blocks (query-major) in the
-    uint8 tensor ``blocks`` -- on a GPU ``Table.search_batch_device``.  ONE all-gather of
-    nq * (16 + 12 k) bytes per rank, then one merge launch for all queries.
+    ``local`` is this rank's :class:`capi.Table` or a callable ``local_search(queries, k, blocks)``
+    that leaves the rank's nq result blocks (query-major) in the uint8 tensor ``blocks``.  ONE
+    all-gather of nq * (16 + 12 k) bytes per rank, then one merge launch for all queries.
     """
 
-    def __init__(self, local_search: Callable, k: int, max_queries: int, device, group=None,
-                 stream_ptr: Optional[int] = None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
+    def __init__(self, local, k: int, max_queries: int, device, group=None, stream=None,
+                 search_kwargs: Optional[dict] = None):
+        self._setup(local, device, group, stream, search_kwargs)
+        torch = self.torch
         self.k = k
         self.max_queries = max_queries
-        self.device = torch.device(device)
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.blk = capi.result_block_bytes(k)
-        self.local_search = local_search
-        self.stream_ptr = stream_ptr
         n = self.blk * max_queries
         self.local = torch.zeros(n, dtype=torch.uint8, device=self.device)
         self.gathered = torch.zeros(n * self.world, dtype=torch.uint8, device=self.device)
         self.merged = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        self.on_gpu = self.device.type == "cuda"
         self.host_out = torch.zeros(n, dtype=torch.uint8)
+        self.h_local = self.h_gathered = None
         if self.on_gpu:
             self.host_out = self.host_out.pin_memory()
+            if self.staged:
+                self.h_local = torch.zeros(n, dtype=torch.uint8).pin_memory()
+                self.h_gathered = torch.zeros(n * self.world, dtype=torch.uint8).pin_memory()
+            torch.cuda.current_stream(self.device).synchronize()
         self.nq = 0
 
     def enqueue(self, queries) -> None:
@@ -117,26 +183,29 @@ class ShardedBatchSearch:
             raise ValueError("batch larger than max_queries")
         self.nq = nq
         n = self.blk * nq
-        local = self.local[:n]
-        self.local_search(queries, self.k, local)
-        gathered = self.gathered[:n * self.world]
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(gathered, local, group=self.group)
-        else:
-            gathered.copy_(local)
-        if self.on_gpu:
-            capi.merge_device_batch(self.device.index or 0, self.stream_ptr or 0, gathered.data_ptr(), self.world, nq,
-                                    self.blk, self.k, self.merged.data_ptr())
-            self.host_out[:n].copy_(self.merged[:n], non_blocking=True)
-        else:
-            raw = gathered.numpy().tobytes()
-            out = bytearray()
-            for q in range(nq):  # the lists of query q: block q of every rank
-                lists = b"".join(raw[(r * nq + q) * self.blk:(r * nq + q + 1) * self.blk] for r in range(self.world))
-                out += capi.merge_host(lists, self.world, self.blk, self.k)
-            self.host_out[:n].copy_(self.torch.frombuffer(out, dtype=self.torch.uint8))
+        with self._stream_ctx():
+            local = self.local[:n]
+            if self.table is not None:
+                self.table.search_batch_device(queries, self.k, local.data_ptr(), **self.kw)
+            else:
+                self.local_search(queries, self.k, local)
+            gathered = self.gathered[:n * self.world]
+            self._all_gather(gathered, local, self.h_local[:n] if self.staged else None,
+                             self.h_gathered[:n * self.world] if self.staged else None)
+            if self.on_gpu:
+                capi.merge_device_batch(self.device.index or 0, self.stream.cuda_stream, gathered.data_ptr(),
+                                        self.world, nq, self.blk, self.k, self.merged.data_ptr())
+                self.host_out[:n].copy_(self.merged[:n], non_blocking=True)
+            else:
+                raw = gathered.numpy().tobytes()
+                out = bytearray()
+                for q in range(nq):  # the lists of query q: block q of every rank
+                    lists = b"".join(raw[(r * nq + q) * self.blk:(r * nq + q + 1) * self.blk]
+                                     for r in range(self.world))
+                    out += capi.merge_host(lists, self.world, self.blk, self.k)
+                self.host_out[:n].copy_(self.torch.frombuffer(out, dtype=self.torch.uint8))
 
     def results(self):
-        """[(hits, approx, flags)] of the last enqueued batch (after the stream is synchronised)."""
+        """[(hits, approx, flags)] of the last enqueued batch (after :meth:`synchronize`)."""
         raw = self.host_out.numpy().tobytes()
         return [capi.parse_result_block(raw[q * self.blk:(q + 1) * self.blk], self.k) for q in range(self.nq)]

@@ -74,6 +74,7 @@ typedef struct {
     double select_ms_sum;    /* sum of compaction + final select kernel durations */
     uint64_t candidates_sum; /* rows that survived the in-scan threshold filter   */
     uint64_t finalists_sum;  /* rows handed to the final select                   */
+    uint64_t handed_back;    /* queries the single-launch path handed back to the four-kernel pipeline */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */

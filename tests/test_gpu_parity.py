@@ -665,11 +665,9 @@ def test_batch_device_blocks_and_batched_merge():
         assert_hits_equal(hits, want, "batched merge q=%d" % i)
     # wrapper, world size 1 (no process group): local blocks -> merge -> pinned host
     whole = make_table(db)
-    whole.set_stream(stream)
-    sb = ShardedBatchSearch(lambda q, kk, blocks: whole.search_batch_device(q, kk, blocks.data_ptr(), 0.0, **kw),
-                            k, 128, "cuda:0", stream_ptr=stream)
+    sb = ShardedBatchSearch(whole, k, 128, "cuda:0", search_kwargs=kw)  # owns its stream, hands it to the table
     sb.enqueue(qs[:65])
-    torch.cuda.synchronize()
+    sb.synchronize()
     for i, (hits, approx, _) in enumerate(sb.results()):
         want, wap = O.search(qs[i], db, k, 0.0, nthreads=8, **kw)
         assert approx == wap
