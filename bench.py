@@ -4,21 +4,29 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one query: the packed table resident in HBM is scanned once, the exact
-top-k is selected, (N > 1: per-GPU top-k blocks are all-gathered over RCCL/xGMI and
-merged), and the k hits land in host memory.  Weak scaling: every rank holds
---rows-per-gpu rows (default 100 M at N = 1 = BASELINE.json configs[2], the
-HBM-bound roofline run; 125 M at N > 1 so that 8 GPUs hold the 1 B-row table of
-configs[3]).  value = rows of the whole table * steps / max-over-ranks time.
+`--gpus N` (N > 1) without a launcher starts its own N ranks (one process per GPU, 127.0.0.1
+rendezvous); under torch.distributed.run the ranks are taken from the environment.
 
-Prints ONE JSON line (rank 0).  The `roofline` object is the scan kernel's
-algorithmic bytes (128 B per fingerprint per pass) over its HIP-event duration on
-the stream it runs on; `cpu_baseline` times the reference's host functor path
-(oracle/_ref when present, else the oracle port) on a bounded sample.
+A "step" is one pass of the hot path over one batch of synthetic input: --queries-per-step
+(default 16) single queries, one after the other -- for each, the packed table resident in HBM
+is scanned once, the exact top-k is selected, (N > 1: the per-GPU top-k blocks are all-gathered
+over RCCL/xGMI and merged), and the k hits land in host memory.  Weak scaling: every rank holds
+--rows-per-gpu rows (default 100 M at N = 1 = BASELINE.json configs[2], the HBM-bound roofline
+run; 125 M at N > 1 so that 8 GPUs hold the 1 B-row table of configs[3]).
+value = rows of the whole table * queries / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel's algorithmic bytes (128 B per
+fingerprint per pass) over its HIP-event duration on the stream it runs on.  At N = 1 the line
+also carries `configs`: every single-GPU BASELINE config measured in this run (configs[1]: 1 M
+rows; configs[2]: the headline; configs[4]'s per-GPU shape: 125 M x 2048-bit, Tversky, 256-query
+batches), and `cpu_baseline`: the reference's host functor path + top-k on this box's cores
+(oracle/_ref when present, else the oracle port) on bounded samples.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,16 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402  (first: one HIP runtime in the process, see capi.load)
-import torch.distributed as dist  # noqa: E402
-
-from gpusimilarity_amd import capi  # noqa: E402
-from gpusimilarity_amd.sharded import ShardedBatchSearch, ShardedSearch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-FP4, MI355X_MICROARCH.md (measured 9099)
 DB_SEED = 0x5EED0001
 GOLDEN = 0x9E3779B97F4A7C15
 M64 = (1 << 64) - 1
+SYNTH_SPARSE, SYNTH_DENSE = 0, 1
 
 
 def _splitmix64(x):
@@ -51,7 +56,7 @@ def synth_row(seed, kind, row, W):
     out = np.zeros(W, dtype=np.uint32)
     for j in range(W):
         ctr = row * W + j
-        if kind == capi.SYNTH_DENSE:
+        if kind == SYNTH_DENSE:
             out[j] = _splitmix64((seed + ctr * GOLDEN) & M64) & 0xFFFFFFFF
         else:
             h0 = _splitmix64((seed + (2 * ctr) * GOLDEN) & M64)
@@ -64,127 +69,271 @@ def query_row(q, nrows):
     return _splitmix64((0xC0FFEE + q) & M64) % nrows
 
 
-def cpu_baseline(fp_bits, k, kind, budget_s=12.0):
-    """The reference's host functor path on this box's cores, bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    W = fp_bits // 32
-    cores = os.cpu_count() or 1
-    n = 8_000_000  # 1 GB of fingerprints: larger than the host's last-level caches
-    db = O.synth_rows(DB_SEED, kind, 0, n, W)
-    q = db[query_row(0, n)]
-    use_ref = O.ref_lib() is not None
-    if use_ref:
-        tab = O.RefTable(db)
-        run = lambda: tab.scan(q, nthreads=cores)  # noqa: E731
-        what = "reference TanimotoFunctorCPU (calculation_functors.cpp compiled in place, oracle/_ref), scoring only"
-    else:
-        run = lambda: O.search(q, db, k, 0.0, nthreads=cores)  # noqa: E731
-        what = "oracle port gso_search (scan + heap top-%d)" % k
+# ---------------------------------------------------------------------------------------------
+# self-spawn: `python bench.py --gpus N` without a launcher
+# ---------------------------------------------------------------------------------------------
+
+def spawn_ranks(n):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, the
+    contract of torch.distributed.run) and wait for them.  Rank 0 inherits stdout (the JSON line)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GSIM_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------
+
+def _timed(run, budget_s, max_reps=1000):
     run()
     reps, t0 = 0, time.perf_counter()
     while True:
         run()
         reps += 1
         el = time.perf_counter() - t0
-        if el > budget_s or reps >= 1000:
-            break
-    return {"value": n * reps / el, "unit": "fingerprints/s", "cores": cores,
+        if el > budget_s or reps >= max_reps:
+            return reps, el
+
+
+def cpu_baseline(fp_bits, k, kind):
+    """The reference's host path on this box's cores, bounded samples:
+    TanimotoFunctorCPU on all hardware threads + the canonical top-k by selection, on configs[1]
+    (1 M rows) and an 8 M-row slice; the reference's own top_results_bubble_sort
+    (fingerprintdb_cuda.cpp:92-103, what search_cpu really runs) at 1 M rows for k = 10 and k;
+    and configs[0] (test/small.fsim, top-10)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    W = fp_bits // 32
+    cores = os.cpu_count() or 1
+    use_ref = O.ref_lib() is not None and hasattr(O.ref_lib(), "gsref_search_topk")
+    parts = []
+
+    def search_rate(n, budget):
+        db = O.synth_rows(DB_SEED, kind, 0, n, W)
+        q = db[query_row(0, n)]
+        nt = min(cores, max(1, n // 4096))
+        if use_ref:
+            tab = O.RefTable(db)
+            run = lambda: tab.search_topk(q, k, nthreads=nt)  # noqa: E731
+        else:
+            run = lambda: O.search(q, db, k, 0.0, nthreads=nt)  # noqa: E731
+        reps, el = _timed(run, budget)
+        return {"rows": n, "threads": nt, "queries": reps, "seconds": round(el, 2), "ms_per_query": 1e3 * el / reps,
+                "fingerprints_per_s": n * reps / el, "GB_per_s": n * (fp_bits // 8) * reps / el / 1e9}, db, q
+
+    big, _, _ = search_rate(8_000_000, 8.0)  # 1 GB of fingerprints: larger than the host's last-level caches
+    parts.append(dict(big, what="scan + top-%d, 8 M-row slice" % k))
+    one, db1, q1 = search_rate(1_000_000, 3.0)
+    parts.append(dict(one, what="scan + top-%d, configs[1] (1 M rows)" % k))
+    # the reference's own partial bubble sort over the 1 M scores (O(k N)): what FingerprintDB::search_cpu pays
+    sort = O.ref_sort_lib()
+    scores = O.tanimoto_raw(q1, db1)[0]
+    for kk in (10, k):
+        idx = np.arange(len(scores), dtype=np.int32)
+        if sort is not None:
+            import ctypes as C
+            sort.gsref_bubble_sort.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int, C.c_int]
+            i2, s2 = idx.copy(), scores.copy()
+            t0 = time.perf_counter()
+            sort.gsref_bubble_sort(i2.ctypes.data_as(C.POINTER(C.c_int)), s2.ctypes.data_as(C.POINTER(C.c_float)), len(idx), kk)
+            el = time.perf_counter() - t0
+            src = "reference top_results_bubble_sort (fingerprintdb_cuda.cpp compiled in place)"
+        else:
+            t0 = time.perf_counter()
+            O.bubble_sort(idx, scores, kk)
+            el = time.perf_counter() - t0
+            src = "oracle port of top_results_bubble_sort"
+        parts.append({"what": "%s, 1 M scores, k = %d, 1 thread" % (src, kk), "rows": len(idx), "threads": 1,
+                      "seconds": round(el, 3), "ms_per_query": 1e3 * el})
+    try:  # configs[0]: the reference's own fixture, CPU path, top-10
+        from gpusimilarity_amd.fsim import read_fsim
+        f = read_fsim(os.path.join(ROOT, "tests", "golden", "small.fsim"))
+        small = np.ascontiguousarray(np.concatenate(f.fp_blocks), dtype=np.uint32)
+        reps, el = _timed(lambda: O.search_cpu(small[0], small, 10), 0.5, 20000)
+        parts.append({"what": "configs[0]: test/small.fsim (%d rows), search_cpu top-10 (oracle port), 1 thread" % len(small),
+                      "rows": int(len(small)), "threads": 1, "queries": reps, "ms_per_query": 1e3 * el / reps})
+    except Exception as e:  # a report, never a reason to fail
+        parts.append({"what": "configs[0] small.fsim not timed: %r" % (e,)})
+    return {"value": big["fingerprints_per_s"], "unit": "fingerprints/s", "cores": big["threads"],
             "kind": "reference" if use_ref else "port",
-            "sample": "%d queries over a %d-row x %d-bit synthetic slice, %d threads, %.1f s; %s" %
-                      (reps, n, fp_bits, cores, el, what)}
+            "sample": "%d queries over a %d-row x %d-bit synthetic slice, %d threads, %.1f s; %s" % (
+                big["queries"], big["rows"], fp_bits, big["threads"], big["seconds"],
+                "reference TanimotoFunctorCPU (calculation_functors.cpp compiled in place, oracle/_ref) + canonical top-%d "
+                "by per-thread selection and merge" % k if use_ref else "oracle port gso_search (scan + heap top-%d)" % k),
+            "parts": parts}
 
 
-MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-FP4, MI355X_MICROARCH.md (measured 9099)
+# ---------------------------------------------------------------------------------------------
+# GPU runs
+# ---------------------------------------------------------------------------------------------
 
+def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps, sharded):
+    """steps x qps single queries (after warmup x qps), barrier + synchronize on both sides, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from gpusimilarity_amd.sharded import ShardedSearch
+    W = fp_bits // 32
+    nq = (warmup + steps) * qps
+    distinct = min(nq, 64)  # distinct queries, cycled
+    queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(distinct)]
+    bufs = table.make_search_buffers(1, k)
+    ss = ShardedSearch(table, k, ctx["dev"], stream=ctx["stream"]) if sharded else None
 
-def run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k, sharded_path, json_fd):
-    """BASELINE configs[4]: Tversky(0.3, 0.7), Q-query batches, top-k per query; a step = one batch.
-    Rows shard over the ranks, every rank scores all Q queries against its shard (the matrix-core
-    pass), ONE all-gather of Q result blocks per step, one merge launch."""
-    Q = args.batch_queries
-    kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
-    nb = args.warmup + args.steps
-    batches = [np.ascontiguousarray(np.stack([synth_row(DB_SEED, kind, query_row(b * Q + i, total_rows), W)
-                                              for i in range(Q)]), dtype=np.uint32)
-               for b in range(min(nb, 4))]  # a few distinct batches, cycled
-    sb = None
-    if sharded_path:
-        sb = ShardedBatchSearch(table, k, Q, dev, stream=stream, search_kwargs=kw)
-    last = {}
-    bufs = table.make_search_buffers(Q, k)  # caller-owned outputs of the synchronous C-ABI call
-
-    def one_batch(qs):
-        if not sharded_path:
-            table.search_into(qs, k, bufs, 0.0, **kw)
-            last["hits"] = [bufs[0][0, :bufs[1][0]]]
+    def one_query(q):
+        if not sharded:
+            # the C ABI's synchronous entry point (FingerprintDB::search): the kernels write the hits
+            # into pinned host memory, the call returns when they are there
+            table.search_into(q, k, bufs)
             return
-        sb.enqueue(qs)
-        sb.synchronize()
+        ss.enqueue(q)  # local top-k -> all-gather (k*12+16 B per GPU) -> rank merge -> D2H
+        ss.synchronize()  # the query is done when its k hits are in host memory
 
-    for b in range(args.warmup):
-        one_batch(batches[b % len(batches)])
-    if args.warmup:
-        b = (args.warmup - 1) % len(batches)
-        first = sb.results()[0][0] if sharded_path else last["hits"][0]
-        assert int(first["row"][0]) == query_row(b * Q, total_rows) and first["score"][0] == 1.0, "self hit missing"
+    for i in range(warmup * qps):
+        one_query(queries[i % distinct])
+    if warmup:
+        if sharded:
+            hits, approx, _ = ss.result()
+        else:
+            hits, approx = bufs[0][0, :bufs[1][0]], int(bufs[2][0])
+        want_row = query_row((warmup * qps - 1) % distinct, total_rows)
+        assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
+            "self hit missing: %r" % (hits[:3],)
+        assert approx == total_rows
+    table.enable_timing(True)
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
-    for b in range(args.warmup, nb):
+    for i in range(warmup * qps, nq):
+        one_query(queries[i % distinct])
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if ctx["world"] > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx["dev"] if ctx["backend"] == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = table.timing()
+    table.enable_timing(False)
+    n = max(1, tm["queries"])
+    kernel_ms = tm["scan_ms_sum"] / n
+    algo = R * (fp_bits // 8)  # bytes per launch of the dominant kernel on one GPU
+    achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    res = {
+        "seconds": elapsed, "queries": steps * qps, "ms_per_query": 1e3 * elapsed / (steps * qps),
+        "fingerprints_per_s": total_rows * steps * qps / elapsed,
+        "whole_path_hbm_frac": (total_rows * (fp_bits // 8) / (elapsed / (steps * qps))) / (HBM_PEAK_GBS * 1e9 * ctx["world"]),
+        "roofline": {
+            "kernel": ("fused_kernel<%d,8> (single launch: scan + publish + select)" % (W // 4)) if table_uses_fused(k, tm) else
+                      "scan_kernel<%d,8>" % (W // 4),
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "traffic_note": "HBM bytes per launch from PMC counters are collected by separate rocprofv3 --pmc passes "
+                            "(profiles/); bench.py cannot run them",
+            "kernel_ms_avg": kernel_ms, "other_kernels_ms_avg": tm["select_ms_sum"] / n,
+            "algorithmic_bytes_per_launch": algo,
+            "candidates_per_query": tm["candidates_sum"] / n, "published_per_query": tm["finalists_sum"] / n,
+            "queries_handed_back": tm["handed_back"], "timed_with_hip_events": tm["queries"],
+        },
+    }
+    return res, ss
+
+
+def table_uses_fused(k, tm):
+    return k <= 2048 and os.environ.get("GSIM_FUSED", "1") != "0" and tm["handed_back"] < max(1, tm["queries"])
+
+
+def time_batches(ctx, table, total_rows, R, fp_bits, kind, k, Q, steps, warmup, sharded):
+    """BASELINE configs[4]: Tversky(0.3, 0.7), Q-query batches, top-k per query; a step = one batch.
+    Rows shard over the ranks, every rank scores all Q queries against its shard (the matrix-core
+    pass), ONE all-gather of Q result blocks per step, one merge launch."""
+    import torch
+    import torch.distributed as dist
+    from gpusimilarity_amd import capi
+    from gpusimilarity_amd.sharded import ShardedBatchSearch
+    W = fp_bits // 32
+    kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    nb = warmup + steps
+    batches = [np.ascontiguousarray(np.stack([synth_row(DB_SEED, kind, query_row(b * Q + i, total_rows), W)
+                                              for i in range(Q)]), dtype=np.uint32)
+               for b in range(min(nb, 3))]  # a few distinct batches, cycled
+    sb = ShardedBatchSearch(table, k, Q, ctx["dev"], stream=ctx["stream"], search_kwargs=kw) if sharded else None
+    bufs = table.make_search_buffers(Q, k)  # caller-owned outputs of the synchronous C-ABI call
+
+    def one_batch(qs):
+        if not sharded:
+            table.search_into(qs, k, bufs, 0.0, **kw)
+            return
+        sb.enqueue(qs)
+        sb.synchronize()
+
+    for b in range(warmup):
+        one_batch(batches[b % len(batches)])
+    if warmup:
+        b = (warmup - 1) % len(batches)
+        first = sb.results()[0][0] if sharded else bufs[0][0, :bufs[1][0]]
+        assert int(first["row"][0]) == query_row(b * Q, total_rows) and first["score"][0] == 1.0, "self hit missing"
+    table.enable_timing(True)
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for b in range(warmup, nb):
         one_batch(batches[b % len(batches)])
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if ctx["world"] > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx["dev"] if ctx["backend"] == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
-        steps = args.steps
-        per = elapsed / steps
-        pairs = Q * total_rows / per
-        tflops = 2.0 * Q * R * args.fp_bits / per / 1e12  # one GPU: 0/1 multiply-adds of the contraction
-        out = {
-            "metric": "(query, fingerprint) pairs scored/sec (%d-bit Tversky(0.3,0.7), %d-query batches, top-%d)" % (
-                args.fp_bits, Q, k),
-            "value": pairs, "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * per, "queries_per_s": Q / per, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 bits as MX-FP4 {0,1} operands, f32 accumulate (exact)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4] shape: %d x %d-bit rows per GPU x %d GPU(s), Tversky a=0.3 b=0.7, "
-                                   "%d-query batch, top-%d" % (R, args.fp_bits, world, Q, k),
-                       "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "batch": Q,
-                       "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of Q result blocks" if world > 1 else "")},
-            "roofline": {"kernel": "batch_mfma_kernel", "bound": "mfma",
-                         "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS,
-                         "traffic": None,
-                         "note": "whole step (sample passes, contraction, compaction, select, host) per GPU; "
-                                 "table bytes read once per batch: %.1f GB/s effective" % (R * args.fp_bits / 8 / per / 1e9)},
-        }
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+    tm = table.timing()
+    table.enable_timing(False)
+    per = elapsed / steps
+    kms = tm["batch_kernel_ms_sum"] / max(1, tm["batches"])
+    flops = 2.0 * Q * R * fp_bits  # one GPU, one batch: the 0/1 multiply-adds of the contraction
+    tf_kernel = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    return {
+        "seconds": elapsed, "batches": steps, "ms_per_batch": 1e3 * per, "pairs_per_s": Q * total_rows / per,
+        "queries_per_s": Q / per,
+        "roofline": {"kernel": "batch_mfma_kernel<%d> (MX-FP4 contraction of the packed bits, f32 accumulate: exact)" % W,
+                     "bound": "mfma", "achieved": tf_kernel, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf_kernel / MFMA_FP4_PEAK_TFLOPS, "traffic": None, "kernel_ms_avg": kms,
+                     "whole_step_tflops": flops / per / 1e12,
+                     "timed_with_hip_events": tm["batches"],
+                     "table_bytes_read_once_per_batch_GBs": R * fp_bits / 8 / per / 1e9},
+    }
 
 
 def main():
     # stdout carries exactly ONE JSON line: route everything else that may write to fd 1
     # (RCCL prints a version banner from C) to stderr
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--queries-per-step", type=int, default=16,
+                    help="single queries per step (a step is one pass of the hot path over one batch of input)")
     ap.add_argument("--rows-per-gpu", type=int, default=0)
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--fp-bits", type=int, default=1024)
     ap.add_argument("--kind", choices=["sparse", "dense"], default="sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configs (N = 1 only)")
     ap.add_argument("--batch-queries", type=int, default=0,
                     help="BASELINE configs[4] instead of the headline run: Tversky(0.3, 0.7) batches of this many "
                          "queries per step (use with --fp-bits 2048); a step is one batch")
@@ -192,138 +341,152 @@ def main():
                     help="run the N>1 code path (device result blocks, all-gather, device merge) even at N=1")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))  # no launcher: start the ranks ourselves
+
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch  # (first: one HIP runtime in the process, see capi.load)
+    import torch.distributed as dist
+    from gpusimilarity_amd import capi
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available() or capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test-only: all ranks on cuda:0 over gloo (a one-GPU box cannot give every rank its own device and RCCL
+    # refuses two ranks per device); the line says so and its value is not a scaling number
+    share = os.environ.get("GSIM_BENCH_SHARE_GPU", "") == "1" and world > 1
+    if not share and world > capi.device_count():
+        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, capi.device_count()))
+    device_index = 0 if share else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    backend = None
     if world > 1 or args.force_sharded_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if share else "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = {"dev": dev, "world": world, "rank": rank, "backend": backend, "stream": torch.cuda.Stream(device=dev)}
 
     R = args.rows_per_gpu or (100_000_000 if world == 1 else 125_000_000)
     total_rows = R * world
     kind = capi.SYNTH_SPARSE if args.kind == "sparse" else capi.SYNTH_DENSE
-    W = args.fp_bits // 32
     k = args.k
+    sharded = world > 1 or args.force_sharded_path
 
-    table = capi.Table(args.fp_bits)
-    table.generate(DB_SEED, kind, rank * R, R, local_rank)  # this rank's contiguous shard, made in HBM
-    table.set_row_base(rank * R)
-    stream = torch.cuda.Stream(device=dev)
-    table.set_stream(stream.cuda_stream)
+    def make_table(rows, bits, first_row):
+        t = capi.Table(bits)
+        t.generate(DB_SEED, kind, first_row, rows, device_index)  # this rank's contiguous shard, made in HBM
+        t.set_row_base(first_row)
+        return t
 
-    sharded_path = world > 1 or args.force_sharded_path
+    # who is in the job: every rank's device, gathered through the process group the data path uses
+    me = {"rank": rank, "device": str(dev), "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None),
+          "device_name": torch.cuda.get_device_properties(dev).name}
+    members = [me]
+    if dist.is_initialized():
+        members = [None] * world
+        dist.all_gather_object(members, me)
+    collective = {"backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend), "world": dist.get_world_size() if dist.is_initialized() else 1,
+                  "ranks": members, "launcher": "self-spawned" if os.environ.get("GSIM_BENCH_SPAWNED") else
+                  ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "WORLD_SIZE" in os.environ else "single process"),
+                  "data_path_collective": "one all_gather_into_tensor of the per-rank result blocks per step" if world > 1 else None}
+    if share:
+        collective["shared_gpu_test_mode"] = True
+
+    table = make_table(R, args.fp_bits, rank * R)
     if args.batch_queries:
-        run_batches(args, table, stream, dev, world, rank, R, total_rows, kind, W, k, sharded_path, json_fd)
-        return
-    nq = args.warmup + args.steps
-    queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(nq)]
-    bufs = table.make_search_buffers(1, k)
-    ss = None
-    if sharded_path:
-        ss = ShardedSearch(table, k, dev, stream=stream)  # local result block stays in HBM
-
-    def one_query(q):
-        if not sharded_path:
-            # single GPU: the C ABI's synchronous entry point (FingerprintDB::search): scan ->
-            # compact -> select, the select kernel writes the hits into pinned host memory,
-            # the call returns when they are there
-            table.search_into(q, k, bufs)
-            return
-        ss.enqueue(q)  # local top-k -> RCCL all-gather (k*12+16 B per GPU) -> rank merge -> D2H
-        ss.synchronize()  # the query is done when its k hits are in host memory
-
-    def last_result():
-        if not sharded_path:
-            return bufs[0][0, :bufs[1][0]], int(bufs[2][0])
-        hits, approx, _ = ss.result()
-        return hits, approx
-
-    for i in range(args.warmup):
-        one_query(queries[i])
-    # sanity on the last warm-up query: the self hit leads the result
-    if args.warmup:
-        hits, approx = last_result()
-        want_row = query_row(args.warmup - 1, total_rows)
-        assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
-            "self hit missing: %r" % (hits[:3],)
-        assert approx == total_rows
-
-    table.enable_timing(True)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, nq):
-        one_query(queries[i])
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tm = table.timing()
-
-    # HBM traffic of the scan kernel from the committed PMC pass (rocprofv3 cannot run inside bench.py):
-    # measured bytes / algorithmic bytes, applied to this run's algorithmic bytes
-    traffic_ratio, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            pm = json.load(f)
-        if pm["fp_bits"] == args.fp_bits:
-            traffic_ratio, traffic_src = pm["ratio"], pm["source"]
-    except Exception:
-        pass
-
-    if rank == 0:
-        steps = args.steps
-        ms = 1e3 * elapsed / steps
-        scan_ms = tm["scan_ms_sum"] / max(1, tm["queries"])
-        algo_bytes = R * (args.fp_bits // 8)  # per scan-kernel launch on one GPU
-        achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        Q = args.batch_queries
+        res = time_batches(ctx, table, total_rows, R, args.fp_bits, kind, k, Q, args.steps, args.warmup, sharded)
         out = {
-            "metric": "fingerprints scanned/sec (1024-bit Tanimoto top-1000)",
-            "value": total_rows * steps / elapsed,
-            "unit": "fingerprints/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": ms, "ms_per_query": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {
-                "workload": ("%d x %d-bit %s synthetic fingerprints per GPU x %d GPU(s) = %d rows, Tanimoto top-%d, "
-                             "cutoff 0; %s" % (R, args.fp_bits, args.kind, world, total_rows, k,
-                                               "BASELINE configs[2] (100M x 1024-bit, 1 MI355X, HBM-bound roofline run)"
-                                               if world == 1 and R == 100_000_000 else
-                                               "BASELINE configs[3] shape (1B x 1024-bit over 8 GPUs = 125M rows/GPU), "
-                                               "per-GPU top-k + RCCL all-gather + merge")),
-                "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "metric": "tanimoto",
-                "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of top-k blocks" if world > 1 else ""),
-            },
-            "whole_path_hbm_frac": (total_rows * (args.fp_bits // 8) / (elapsed / steps)) / (HBM_PEAK_GBS * 1e9 * world),
-            "roofline": {
-                "kernel": "scan_kernel<8,8>" if args.fp_bits == 1024 else "scan_kernel",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic_ratio * algo_bytes) if traffic_ratio else None, "traffic_unit": "bytes/launch",
-                "traffic_source": traffic_src,
-                "scan_ms_avg": scan_ms, "select_ms_avg": tm["select_ms_sum"] / max(1, tm["queries"]),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "candidates_per_query": tm["candidates_sum"] / max(1, tm["queries"]),
-                "finalists_per_query": tm["finalists_sum"] / max(1, tm["queries"]),
-            },
+            "metric": "(query, fingerprint) pairs scored/sec (%d-bit Tversky(0.3,0.7), %d-query batches, top-%d)" % (args.fp_bits, Q, k),
+            "value": res["pairs_per_s"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_batch"], "queries_per_s": res["queries_per_s"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 bits as MX-FP4 {0,1} operands, f32 accumulate (exact)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] shape: %d x %d-bit rows per GPU x %d GPU(s), Tversky a=0.3 b=0.7, "
+                                   "%d-query batch, top-%d" % (R, args.fp_bits, world, Q, k),
+                       "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "batch": Q,
+                       "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of Q result blocks" if world > 1 else "")},
+            "roofline": res["roofline"], "collective": collective,
         }
+        table.close()
+        if rank == 0:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    qps = max(1, args.queries_per_step)
+    res, _ss = time_queries(ctx, table, total_rows, R, args.fp_bits, kind, k, args.steps, args.warmup, qps, sharded)
+    table.close()
+    headline_cfg = {
+        "name": ("BASELINE configs[2]: 100M x 1024-bit, Tanimoto top-1000, 1 MI355X" if world == 1 and R == 100_000_000 and
+                 args.fp_bits == 1024 and k == 1000 else "headline"),
+        "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "ms_per_query": res["ms_per_query"],
+        "ms_per_step": res["ms_per_query"] * qps, "value": res["fingerprints_per_s"], "unit": "fingerprints/s",
+        "timed_region_s": res["seconds"], "whole_path_hbm_frac": res["whole_path_hbm_frac"], "roofline": res["roofline"]}
+    out = {
+        "metric": "fingerprints scanned/sec (1024-bit Tanimoto top-1000)",
+        "value": res["fingerprints_per_s"], "unit": "fingerprints/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_query"] * qps, "queries_per_step": qps, "ms_per_query": res["ms_per_query"],
+        "timed_region_s": res["seconds"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": ("%d x %d-bit %s synthetic fingerprints per GPU x %d GPU(s) = %d rows, Tanimoto top-%d, "
+                         "cutoff 0, %d single queries per step; %s" % (
+                             R, args.fp_bits, args.kind, world, total_rows, k, qps,
+                             "BASELINE configs[2] (100M x 1024-bit, 1 MI355X, HBM-bound roofline run)"
+                             if world == 1 and R == 100_000_000 else
+                             "BASELINE configs[3] shape (1B x 1024-bit over 8 GPUs = 125M rows/GPU), "
+                             "per-GPU top-k + RCCL all-gather + merge")),
+            "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "metric": "tanimoto",
+            "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of top-k blocks" if world > 1 else ""),
+        },
+        "whole_path_hbm_frac": res["whole_path_hbm_frac"],
+        "roofline": res["roofline"],
+        "collective": collective,
+    }
+    if world == 1 and not args.no_configs and not sharded:
+        # the other single-GPU BASELINE configs, measured in this run, each with its own dominant-kernel roofline
+        cfgs = []
+        t1 = make_table(1_000_000, 1024, 0)
+        r1, _ = time_queries(ctx, t1, 1_000_000, 1_000_000, 1024, kind, 1000, max(args.steps, 20), args.warmup, 64, False)
+        t1.close()
+        cfgs.append({"name": "BASELINE configs[1]: 1M x 1024-bit, Tanimoto top-1000, 1 MI355X", "rows_per_gpu": 1_000_000,
+                     "fp_bits": 1024, "k": 1000, "ms_per_query": r1["ms_per_query"], "ms_per_step": r1["ms_per_query"],
+                     "value": r1["fingerprints_per_s"], "unit": "fingerprints/s", "timed_region_s": r1["seconds"],
+                     "whole_path_hbm_frac": r1["whole_path_hbm_frac"], "roofline": r1["roofline"],
+                     "note": "latency-bound: the 128 MB table streams in 16 us at 8 TB/s; the rest is launch, the threshold "
+                             "exchange and the select inside the single launch"})
+        cfgs.append(headline_cfg)
+        try:
+            t4 = make_table(125_000_000, 2048, 0)
+            r4 = time_batches(ctx, t4, 125_000_000, 125_000_000, 2048, kind, 1000, 256, 8, 2, False)
+            t4.close()
+            cfgs.append({"name": "BASELINE configs[4], per-GPU shape: 125M x 2048-bit, Tversky(0.3,0.7), 256-query batch, top-1000",
+                         "rows_per_gpu": 125_000_000, "fp_bits": 2048, "k": 1000, "batch": 256,
+                         "ms_per_step": r4["ms_per_batch"], "value": r4["pairs_per_s"], "unit": "pairs/s",
+                         "queries_per_s": r4["queries_per_s"], "timed_region_s": r4["seconds"], "roofline": r4["roofline"]})
+        except Exception as e:  # never lose the headline over it
+            cfgs.append({"name": "BASELINE configs[4] per-GPU shape", "error": repr(e)})
+        out["configs"] = cfgs
+        out["configs_note"] = ("configs[0] (small.fsim, CPU path) is timed under cpu_baseline.parts; configs[3] (1B rows over 8 GPUs) "
+                               "is this script at --gpus 8")
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            table.close()
             try:
                 out["cpu_baseline"] = cpu_baseline(args.fp_bits, k, kind)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

@@ -537,7 +537,8 @@ hipError_t launch_batch_pass(const BatchArgs& a, const BatchRare& /*rare_host*/,
 // kBQ queries (they set the starting thresholds), ONE contraction pass for all a.nq
 // (<= kMfmaQueries) queries, then B* / compact / select for all of them.
 hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,
-                                  uint32_t row_base, void* results, size_t block_bytes, hipStream_t s)
+                                  uint32_t row_base, void* results, size_t block_bytes, hipStream_t s, hipEvent_t ev0,
+                                  hipEvent_t ev1)
 {
     hipError_t es = hipSuccess;
     const bool sampled = launch_batch_mfma_sample(a, num_cus, s, &es); // large tables: one launch for all queries
@@ -549,8 +550,10 @@ hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int
         const hipError_t e = launch_batch_scan(as, g, sample_chunks, s, true);
         if (e != hipSuccess) return e;
     }
+    if (ev0) (void) hipEventRecord(ev0, s); // timing: the contraction kernel alone
     const hipError_t e = launch_batch_mfma_scan(a, num_cus, s);
     if (e != hipSuccess) return e;
+    if (ev1) (void) hipEventRecord(ev1, s);
     return launch_batch_finish(a, batch_mfma_waves(num_cus), row_base, results, block_bytes, s);
 }
 

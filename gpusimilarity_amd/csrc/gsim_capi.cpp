@@ -103,6 +103,8 @@ struct Shard {
     // timing
     std::vector<hipEvent_t> ev; // 3 per slot
     uint32_t ev_used = 0;
+    std::vector<hipEvent_t> bev; // multi-query passes: 2 per slot
+    uint32_t bev_used = 0;
     unsigned long long base_ncand = 0, base_nfinal = 0, base_nredo = 0; // device totals when timing was enabled
     // multi-query batches (allocated on first use)
     gsim::ScanGeometry bgeo{};
@@ -198,6 +200,7 @@ int free_shard(Shard& s)
     if (s.h_bresult) (void) hipHostFree(s.h_bresult);
     if (s.d_bresult) (void) hipFree(s.d_bresult);
     for (auto e : s.ev) (void) hipEventDestroy(e);
+    for (auto e : s.bev) (void) hipEventDestroy(e);
     for (auto e : s.q_ev) (void) hipEventDestroy(e);
     if (s.own_stream) (void) hipStreamDestroy(s.own_stream);
     s = Shard{};
@@ -450,9 +453,16 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
 // Fold the recorded events of a shard into the handle's accumulators.
 int drain_timing(gsim_db* db, Shard& s)
 {
-    if (s.ev_used == 0) return GSIM_OK;
+    if (s.ev_used == 0 && s.bev_used == 0) return GSIM_OK;
     GSIM_HIP(hipSetDevice(s.device));
     GSIM_HIP(hipStreamSynchronize(s.stream));
+    for (uint32_t i = 0; i < s.bev_used; i++) {
+        float ms = 0.f;
+        GSIM_HIP(hipEventElapsedTime(&ms, s.bev[2 * i], s.bev[2 * i + 1]));
+        db->acc.batch_kernel_ms_sum += ms;
+        db->acc.batches++;
+    }
+    s.bev_used = 0;
     for (uint32_t i = 0; i < s.ev_used; i++) {
         float scan = 0.f, sel = 0.f;
         GSIM_HIP(hipEventElapsedTime(&scan, s.ev[3 * i], s.ev[3 * i + 1]));
@@ -767,6 +777,18 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     // cutoff it needs the matrix-core sample pass (large tables), which also estimates how many
     // rows the cutoff keeps: a cutoff that keeps many sets bit 3 of the flags and the kernel leaves
     // the batch to the VALU pass (the callers re-enqueue with allow_mfma = false).
+    hipEvent_t* bev = nullptr;
+    if (db->timing && s.bev_used < kTimingRing) {
+        if (s.bev.size() < static_cast<size_t>(2 * (s.bev_used + 1))) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t e;
+                GSIM_HIP(hipEventCreate(&e));
+                s.bev.push_back(e);
+            }
+        }
+        bev = &s.bev[2 * s.bev_used];
+        s.bev_used++;
+    }
     static const int mfma_min_q = env_int("GSIM_BATCH_MFMA_MIN_Q", 4);
     if (allow_mfma && mfma_min_q > 0 && nq >= static_cast<uint32_t>(mfma_min_q) &&
         nq <= static_cast<uint32_t>(gsim::kMfmaQueries) && gsim::batch_mfma_supported(s.W) &&
@@ -774,18 +796,21 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         a.q0 = 0;
         a.nq = nq;
         GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, results,
-                                              gsim_result_block_bytes(k), s.stream));
+                                              gsim_result_block_bytes(k), s.stream, bev ? bev[0] : nullptr,
+                                              bev ? bev[1] : nullptr));
         if (to_host)
             GSIM_HIP(hipMemcpyAsync(s.h_bresult, s.d_bresult, gsim_result_block_bytes(k) * nq, hipMemcpyDeviceToHost, s.stream));
         GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));
         return GSIM_OK;
     }
+    if (bev) GSIM_HIP(hipEventRecord(bev[0], s.stream));
     for (uint32_t q0 = 0; q0 < nq; q0 += gsim::kBQ) {
         a.q0 = q0;
         a.nq = std::min<uint32_t>(gsim::kBQ, nq - q0);
         GSIM_HIP(gsim::launch_batch_pass(a, rr, s.bgeo, sample, row_base, results, gsim_result_block_bytes(k),
                                          s.stream));
     }
+    if (bev) GSIM_HIP(hipEventRecord(bev[1], s.stream));
     if (to_host)
         GSIM_HIP(hipMemcpyAsync(s.h_bresult, s.d_bresult, gsim_result_block_bytes(k) * nq, hipMemcpyDeviceToHost, s.stream));
     GSIM_HIP(hipMemcpyAsync(s.h_bflags, s.d_bflags, 64, hipMemcpyDeviceToHost, s.stream));

@@ -178,7 +178,8 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
 bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err);
 bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus);
 hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,
-                                  uint32_t row_base, void* results, size_t block_bytes, hipStream_t s);
+                                  uint32_t row_base, void* results, size_t block_bytes, hipStream_t s,
+                                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows,
                            uint32_t W, hipStream_t s);

@@ -75,6 +75,9 @@ typedef struct {
     uint64_t candidates_sum; /* rows that survived the in-scan threshold filter   */
     uint64_t finalists_sum;  /* rows handed to the final select                   */
     uint64_t handed_back;    /* queries the single-launch path handed back to the four-kernel pipeline */
+    uint64_t batches;        /* multi-query passes timed (gsim_db_search with nq >= 4)                  */
+    double batch_kernel_ms_sum; /* sum of their dominant kernel's durations (the matrix-core contraction,
+                                   or all table passes of the VALU route)                               */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */

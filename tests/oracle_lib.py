@@ -202,6 +202,10 @@ def ref_lib():
         L.gsref_table_destroy.argtypes = [C.c_void_p]
         L.gsref_tanimoto_scan.restype = None
         L.gsref_tanimoto_scan.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_uint64, C.c_int]
+        if hasattr(L, "gsref_search_topk"):
+            L.gsref_search_topk.restype = C.c_int
+            L.gsref_search_topk.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_uint64, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int), C.POINTER(C.c_float)]
         L.gsref_fold.restype = None
         L.gsref_fold.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]
         _ref = L
@@ -222,6 +226,15 @@ class RefTable:
         ref_lib().gsref_tanimoto_scan(self.h, q.ctypes.data_as(C.POINTER(C.c_int)), _ptr(out, C.c_float), self.n,
                                       nthreads)
         return out
+
+    def search_topk(self, query, k, nthreads=1):
+        """The reference functor on nthreads threads + a canonical top-k selection -> (rows, scores)."""
+        q = np.ascontiguousarray(query, dtype=np.uint32).view(np.int32)
+        rows = np.empty(max(k, 1), dtype=np.int32)
+        scores = np.empty(max(k, 1), dtype=np.float32)
+        n = ref_lib().gsref_search_topk(self.h, q.ctypes.data_as(C.POINTER(C.c_int)), self.n, nthreads, k,
+                                        _ptr(rows, C.c_int), _ptr(scores, C.c_float))
+        return rows[:n], scores[:n]
 
     def close(self):
         if self.h:

@@ -765,7 +765,7 @@ def test_bench_contract_lines():
     the sharded code path as well) and in the batch mode (BASELINE configs[4] shape, small)."""
     import subprocess
     import sys
-    common = ["--steps", "3", "--warmup", "2", "--rows-per-gpu", "400000"]
+    common = ["--steps", "3", "--warmup", "2", "--rows-per-gpu", "400000", "--no-configs", "--queries-per-step", "4"]
     for extra in (["--no-cpu-baseline"], ["--no-cpu-baseline", "--force-sharded-path"],
                   ["--fp-bits", "2048", "--batch-queries", "64"],
                   ["--fp-bits", "2048", "--batch-queries", "64", "--force-sharded-path"]):
@@ -781,3 +781,4 @@ def test_bench_contract_lines():
             assert key in d, key
         assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "workload" in d["config"]
         assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["peak"] > 0
+        assert d["collective"]["world"] == 1 and d["collective"]["ranks"][0]["rank"] == 0
