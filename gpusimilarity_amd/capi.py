@@ -50,7 +50,7 @@ EXPORTS = [
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
     "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_db_enable_timing",
-    "gsim_db_get_timing", "gsim_debug_score_table", "gsim_last_error", "gsim_version",
+    "gsim_db_get_timing", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_last_error", "gsim_version",
 ]
 
 
@@ -106,6 +106,8 @@ def load():
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                              C.c_uint32, C.POINTER(C.c_float)]),
+        "gsim_debug_prefilter_constants": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_int, C.c_float,
+                                                      C.POINTER(C.c_float)]),
         "gsim_last_error": (C.c_char_p, []),
         "gsim_version": (C.c_char_p, []),
     }
@@ -322,4 +324,13 @@ def debug_score_table(metric, alpha, beta, a, max_b, max_c, device=0) -> np.ndar
     out = np.empty((max_c + 1, max_b + 1), dtype=np.float32)
     check(load().gsim_debug_score_table(device, metric, alpha, beta, a, max_b, max_c,
                                         out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def debug_prefilter_constants(metric, alpha, beta, max_qa, cutoff=None, device=0) -> np.ndarray:
+    """Pre-filter constants of the matrix-core pass, [max_qa+1, 512 (or 1 with a cutoff), 4]; device < 0: host twin."""
+    nlev = 1 if cutoff is not None else 512
+    out = np.empty((max_qa + 1, nlev, 4), dtype=np.float32)
+    check(load().gsim_debug_prefilter_constants(device, metric, alpha, beta, max_qa, 1 if cutoff is not None else 0,
+                                                0.0 if cutoff is None else cutoff, out.ctypes.data_as(C.POINTER(C.c_float))))
     return out

@@ -25,6 +25,7 @@
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
+#include "gsim_prefilter.h"
 
 namespace gsim
 {
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(kScanBlock) void batch_scan_kernel(BatchArgs a, Sca
     const uint32_t vqpop = lane < nq ? qpops[lane] : 0u;
     uint32_t vtau = 0, keptv = 0;
     float vtm = 0.0f;
-    const float cut_hi = __fmul_rn(a.cutoff, 1.0f + 4.76837158203125e-7f); // cutoff * (1 + 2^-21)
-    const float cut_lo = __fmul_rn(a.cutoff, 1.0f - 4.76837158203125e-7f);
+    // (the filter arithmetic lives in gsim_prefilter.h: shared with the host-side proof test)
+    const float cut_hi = valu_cutoff_hi(a.cutoff); // cutoff * (1 + 2^-21)
+    const float cut_lo = valu_cutoff_lo(a.cutoff);
     constexpr int CHR = 64 * RPL; // rows per wave iteration
     const u64 nchunks = SAMPLE ? nsample : (a.nrows + CHR - 1) / CHR;
     uint32_t trip = 0;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kScanBlock) void batch_scan_kernel(BatchArgs a, Sca
             vtau = lane < kBQ ? sh.tau[lane] : 0u;
             // pre-filter constant T- = tau/kBBins * (1 - 2^-21): cf < RN(T- * den) implies
             // RN(cf / den) < tau/kBBins, i.e. bin < tau (multi-query filter)
-            vtm = __fmul_rn(static_cast<float>(vtau) * (1.0f / kBBins), 1.0f - 4.76837158203125e-7f);
+            vtm = valu_filter_level(vtau);
         }
         trip++;
 
@@ -254,13 +256,13 @@ __global__ __launch_bounds__(kScanBlock) void batch_scan_kernel(BatchArgs a, Sca
                 const float den = score_den(a.metric, a.alpha, a.beta, qa, bb[r], cc);
                 const float cf = static_cast<float>(cc);
                 // division-free pre-filter: almost every pair ends here
-                const bool maybe = active[r] && !(cf < __fmul_rn(tm, den));
+                const bool maybe = active[r] && !valu_filter_rejects(tm, cf, den);
                 bool decided_kept = false;
                 if (!SAMPLE && has_cutoff) {
                     // rows counted as "kept" need RN(cf/den) >= cutoff: decided without the divide
                     // unless cf/den is within 2^-21 of the cutoff
-                    const bool surely = active[r] && den > 0.0f && cf >= __fmul_rn(cut_hi, den) && cc != 0;
-                    const bool surely_not = !active[r] || cf < __fmul_rn(cut_lo, den) || cc == 0;
+                    const bool surely = active[r] && valu_surely_kept(cut_hi, cf, den, cc);
+                    const bool surely_not = !active[r] || valu_surely_not_kept(cut_lo, cf, den, cc);
                     const bool unsure = !(surely || surely_not);
                     const u64 mu = __ballot(unsure || maybe);
                     if (mu == 0) { // nobody needs the exact score

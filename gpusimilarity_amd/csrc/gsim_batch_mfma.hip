@@ -41,6 +41,7 @@
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
+#include "gsim_prefilter.h"
 
 namespace gsim
 {
@@ -116,30 +117,7 @@ template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, v4i rb, v1
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, /*A fp4*/ 4, /*B fp4*/ 4, 0, sc, 0, sc);
 }
 
-// c >= ka + kb * popc(row) is implied by score >= T (see the file header); T <= 0, exotic weights
-// or an ill-conditioned bound switch the pre-filter off (everything passes).
-__device__ __forceinline__ void prefilter_constants(int metric, float alpha, float beta, uint32_t qa, float T,
-                                                    bool valid, float& ka, float& kb)
-{
-    ka = 0.0f;
-    kb = 0.0f;
-    if (!valid) { // padding query of the last tile: never a candidate
-        ka = 3.0e38f;
-        return;
-    }
-    const float al = metric == GSIM_METRIC_TVERSKY ? alpha : 1.0f;
-    const float be = metric == GSIM_METRIC_TVERSKY ? beta : 1.0f;
-    const float D = 1.0f - T * (1.0f - al - be);
-    if (!(T > 0.0f) || !(al >= 0.0f) || !(be >= 0.0f)) return;
-    if (T > 1.0f) { // scores never exceed 1 with non-negative weights
-        ka = 3.0e38f;
-        return;
-    }
-    if (!(D > 0.05f)) return;
-    const float f = T / D * (1.0f - 0.000244140625f); // (1 - 2^-12)
-    ka = f * al * static_cast<float>(qa);
-    kb = f * be;
-}
+// (the pre-filter arithmetic lives in gsim_prefilter.h: shared with the host-side proof test)
 
 // MT = query tiles per wave: the expanded row operand of a tile is used by MT MFMAs per class, so
 // the operand work per MFMA is 5 / MT instructions; 2 W MT registers hold the queries.
@@ -209,25 +187,14 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     auto set_query_constants = [&](uint32_t tau) { // lanes 0..QW-1: query `lane` of the wave
         const int m = lane >> 5;
         const bool valid = q0t + lane < nq;
-        float ka, kb;
-        // With a cutoff every pair at or above it has to reach the exact path (it is counted), so the
-        // level of the pre-filter is the cutoff, whatever the top-k threshold; without one it is the
-        // threshold.
-        const float level = has_cutoff ? __fmul_rn(a.cutoff, 1.0f - 4.76837158203125e-7f) // cutoff (1 - 2^-21)
-                                       : static_cast<float>(tau) * (1.0f / kBBins);
-        prefilter_constants(a.metric, a.alpha, a.beta, sh.qpop[wq][lane], level, valid, ka, kb);
+        const float level = prefilter_level(has_cutoff, a.cutoff, tau);
+        const PrefilterConstants pk = prefilter_constants(a.metric == GSIM_METRIC_TVERSKY, a.alpha, a.beta, sh.qpop[wq][lane],
+                                                          level, valid);
         const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i of a tile
-        sh.kap_a[wq][m][hh][r] = ka;
-        sh.kap_b[wq][m][hh][r] = kb;
-        // c >= ka + kb p - 0.05  <=>  c u + v >= p  with u = 1 / kb, v = (0.05 - ka) u; a vanishing kb
-        // (filter off, beta = 0) passes everything to the exact test, a padding query nothing
-        float u = 0.0f, v = ka > 1.0e38f ? -3.0e38f : 3.0e38f;
-        if (kb > 1.0e-6f && ka < 1.0e4f) { // (beyond: the rounding of c u + v could exceed the 0.05 slack)
-            u = 1.0f / kb;
-            v = (0.05f - ka) * u;
-        }
-        sh.kap_u[wq][m][hh][r] = u;
-        sh.kap_v[wq][m][hh][r] = v;
+        sh.kap_a[wq][m][hh][r] = pk.ka;
+        sh.kap_b[wq][m][hh][r] = pk.kb;
+        sh.kap_u[wq][m][hh][r] = pk.u;
+        sh.kap_v[wq][m][hh][r] = pk.v;
         sh.tau[wq][lane] = tau;
     };
     if (lane < QW) {
@@ -698,6 +665,50 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a,
     if (threadIdx.x == 0) *rr.ticket = 0;
 }
 
+
+
+// debug hook: the pre-filter constants as the device computes them, for qa = 0..max_qa and (no
+// cutoff) every threshold bin: out[(qa * nlev + lev) * 4 + {ka, kb, u, v}], nlev = 512 or 1
+__global__ __launch_bounds__(256) void prefilter_table_kernel(int tversky, float alpha, float beta, uint32_t max_qa, int has_cutoff,
+                                                              float cutoff, float* out)
+{
+    const uint32_t nlev = has_cutoff ? 1u : static_cast<uint32_t>(kBBins);
+    const u64 n = static_cast<u64>(max_qa + 1) * nlev;
+    const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t qa = static_cast<uint32_t>(i / nlev), lev = static_cast<uint32_t>(i % nlev);
+    const PrefilterConstants k = prefilter_constants(tversky != 0, alpha, beta, qa, prefilter_level(has_cutoff != 0, cutoff, lev), true);
+    out[4 * i + 0] = k.ka;
+    out[4 * i + 1] = k.kb;
+    out[4 * i + 2] = k.u;
+    out[4 * i + 3] = k.v;
+}
+
+} // namespace
+
+hipError_t launch_prefilter_table(int tversky, float alpha, float beta, uint32_t max_qa, int has_cutoff, float cutoff, float* d_out,
+                                  hipStream_t s)
+{
+    const u64 n = static_cast<u64>(max_qa + 1) * (has_cutoff ? 1u : static_cast<uint32_t>(kBBins));
+    hipLaunchKernelGGL(prefilter_table_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s, tversky, alpha, beta,
+                       max_qa, has_cutoff, cutoff, d_out);
+    return hipGetLastError();
+}
+
+void prefilter_table_host(int tversky, float alpha, float beta, uint32_t max_qa, int has_cutoff, float cutoff, float* out)
+{
+    const uint32_t nlev = has_cutoff ? 1u : static_cast<uint32_t>(kBBins);
+    for (uint32_t qa = 0; qa <= max_qa; qa++)
+        for (uint32_t lev = 0; lev < nlev; lev++) {
+            const PrefilterConstants k =
+                prefilter_constants(tversky != 0, alpha, beta, qa, prefilter_level(has_cutoff != 0, cutoff, lev), true);
+            float* o = out + 4 * (static_cast<size_t>(qa) * nlev + lev);
+            o[0] = k.ka, o[1] = k.kb, o[2] = k.u, o[3] = k.v;
+        }
+}
+
+namespace
+{
 } // namespace
 
 bool batch_mfma_supported(uint32_t W)

@@ -1618,4 +1618,28 @@ int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint
     return GSIM_OK;
 }
 
+int gsim_debug_prefilter_constants(int device, int metric, float alpha, float beta, uint32_t max_qa, int has_cutoff,
+                                   float cutoff, float* out)
+{
+    if (!out) return fail(GSIM_ERR_INVALID, "out is NULL");
+    if (max_qa > 32768) return fail(GSIM_ERR_INVALID, "max_qa too large");
+    const int tv = metric == GSIM_METRIC_TVERSKY ? 1 : 0;
+    if (device < 0) {
+        gsim::prefilter_table_host(tv, alpha, beta, max_qa, has_cutoff, cutoff, out);
+        return GSIM_OK;
+    }
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    GSIM_HIP(hipSetDevice(device));
+    const size_t n = static_cast<size_t>(max_qa + 1) * (has_cutoff ? 1 : gsim::kBBins) * 4;
+    float* d = nullptr;
+    GSIM_HIP(hipMalloc(&d, n * sizeof(float)));
+    hipError_t e = gsim::launch_prefilter_table(tv, alpha, beta, max_qa, has_cutoff, cutoff, d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "prefilter table");
+    return GSIM_OK;
+}
+
 } // extern "C"

@@ -181,6 +181,11 @@ hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int
                                   uint32_t row_base, void* results, size_t block_bytes, hipStream_t s,
                                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
+// debug hooks for the pre-filter of the matrix-core pass (gsim_prefilter.h): device and host twins
+hipError_t launch_prefilter_table(int tversky, float alpha, float beta, uint32_t max_qa, int has_cutoff, float cutoff,
+                                  float* d_out, hipStream_t s);
+void prefilter_table_host(int tversky, float alpha, float beta, uint32_t max_qa, int has_cutoff, float cutoff, float* out);
+
 hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows,
                            uint32_t W, hipStream_t s);
 

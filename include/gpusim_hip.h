@@ -228,6 +228,14 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out); /* synchronises the strea
 int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint32_t a,
                            uint32_t max_b, uint32_t max_c, float* out);
 
+/* The constants of the matrix-core pass's division-free pre-filter (gsim_prefilter.h) for query
+ * popcounts 0..max_qa: without a cutoff for every threshold bin, out[(qa * 512 + bin) * 4 + i],
+ * with one for the cutoff's level, out[qa * 4 + i]; i = {ka, kb, u, v}.  device >= 0: computed by
+ * a kernel on that device; device < 0: computed on the host by the same code.  The parity tests
+ * compare the two (the exhaustive filter-never-rejects-an-accepted-pair test runs on the host). */
+int gsim_debug_prefilter_constants(int device, int metric, float alpha, float beta, uint32_t max_qa,
+                                   int has_cutoff, float cutoff, float* out);
+
 const char* gsim_last_error(void);
 const char* gsim_version(void);
 

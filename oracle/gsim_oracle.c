@@ -94,6 +94,18 @@ float gso_score_one(int metric, float alpha, float beta, uint32_t a, uint32_t b,
     return (float) (int) c / (float) (total - (int) c);
 }
 
+/* the denominator of gso_score_one as its own step (twin of the device's score_den):
+ * gso_score_one(...) == (float) c / gso_score_den(...) bit for bit                            */
+float gso_score_den(int metric, float alpha, float beta, uint32_t a, uint32_t b, uint32_t c)
+{
+    if (metric == GSO_METRIC_TVERSKY) {
+        const float t1 = alpha * (float) (int32_t) (a - c);
+        const float t2 = beta * (float) (int32_t) (b - c);
+        return (t1 + t2) + (float) c;
+    }
+    return (float) ((int) (a + b) - (int) c);
+}
+
 void gso_tanimoto_raw(const uint32_t* query, const uint32_t* db, uint64_t nrows,
                       uint32_t W, float* scores, uint16_t* common, uint16_t* popc)
 {

@@ -59,6 +59,7 @@ void gso_tanimoto_raw(const uint32_t* query, const uint32_t* db, uint64_t nrows,
 float gso_score_one(int metric, float alpha, float beta, uint32_t a, uint32_t b,
                     uint32_t c);
 /* fingerprintdb_cuda.cu:99-102: score >= cutoff ? score : 0 (NaN -> 0). */
+float gso_score_den(int metric, float alpha, float beta, uint32_t a, uint32_t b, uint32_t c);
 float gso_apply_cutoff(float score, float cutoff);
 
 /* ---- search: fingerprintdb_cuda.cu:228-381 in canonical form --------------

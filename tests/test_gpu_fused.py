@@ -1,0 +1,135 @@
+"""The single-launch query path (fused_kernel): it is the route ordinary queries take, it matches the
+oracle bit for bit, and what it cannot hold is handed back to the four-kernel pipeline -- which stays
+covered for ordinary queries as well (GSIM_FUSED=0).  Reference: FingerprintDB::search_storage,
+fingerprintdb_cuda.cu:228-339."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpusimilarity_amd import capi
+from test_gpu_parity import assert_hits_equal, make_table
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def check(t, db, q, k, cutoff=0.0, ctx="", **kw):
+    hits, approx = t.search(q, k, cutoff, **kw)
+    want, wap = O.search(q, db, k, cutoff, nthreads=8, **kw)
+    assert int(approx[0]) == wap, ctx
+    assert_hits_equal(hits[0], want, ctx)
+
+
+@pytest.mark.parametrize("n,W", [(700, 32), (4_097, 32), (65_000, 32), (300_000, 32), (1_300_000, 32), (2_500_000, 8),
+                                 (400_000, 64), (250_000, 4), (120_000, 128), (90_000, 256)])
+def test_single_launch_path_is_taken_and_exact(n, W):
+    """Table sizes on either side of every geometry switch (tiny grids without thresholds, few trips
+    with the end-of-scan checkpoint, many trips), all specialised widths; k from 1 to the path's
+    limit, cutoffs, Tversky.  No query may be handed back on random data."""
+    db = O.synth_rows(0xF05ED + n, 0, 0, n, W)
+    t = make_table(db)
+    t.enable_timing(True)
+    nq = 0
+    for qi in range(3):
+        q = db[O.query_row(qi, n)]
+        for k in (1, 10, 1000, 2048):
+            check(t, db, q, k, 0.0, "n=%d W=%d k=%d" % (n, W, k))
+            nq += 1
+        check(t, db, q, 100, 0.05, "cutoff")
+        check(t, db, q, 100, 0.9, "high cutoff")
+        check(t, db, q, 50, 0.0, "tversky", metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+        nq += 3
+    fresh = O.synth_rows(0xF05EE, 0, 5, 1, W)[0]  # a query that is no row of the table
+    check(t, db, fresh, 1000, 0.0, "fresh")
+    check(t, db, np.zeros(W, dtype=np.uint32), 10, 0.0, "empty query (0/0 -> 0)")
+    nq += 2
+    tm = t.timing()
+    # the all-zero query scores 0 against every row: a table-wide tie, handed back unless the whole table fits a selector
+    expect_back = 1 if n > 8192 else 0
+    if W >= 32:
+        assert tm["handed_back"] == expect_back, tm
+    # (sparse 128/256-bit fingerprints have a dozen bits set: their scores are a handful of small fractions and
+    # the k-th best ties with thousands of rows -- handed back by design, exact either way)
+    assert tm["queries"] == nq + tm["handed_back"], tm  # (a handed-back query is timed twice)
+    t.close()
+
+
+def test_queries_the_path_cannot_hold_are_handed_back_and_stay_exact():
+    """Heavy ties (every row a duplicate of four fingerprints): the stores overflow, the four-kernel
+    pipeline (radix select over all ties) answers; rows in ascending score order: the threshold always
+    lags, the stores overflow as well.  Counted, and exact."""
+    W = 32
+    base = O.synth_rows(0x71E8, 0, 0, 4, W)
+    tied = np.ascontiguousarray(base[np.random.default_rng(11).integers(0, 4, size=700_000)])
+    t = make_table(tied)
+    t.enable_timing(True)
+    for k in (10, 1000):
+        check(t, tied, base[1], k, 0.0, "ties k=%d" % k)
+    assert t.timing()["handed_back"] == 2
+    t.close()
+    # ascending scores along the table: row i shares i * 900 / n bits with the query
+    n = 1_500_000
+    rng = np.random.default_rng(5)
+    q = np.zeros(W, dtype=np.uint32)
+    bits = rng.permutation(W * 32)[:900]
+    for b in bits:
+        q[b // 32] |= np.uint32(1) << np.uint32(b % 32)
+    db = np.zeros((n, W), dtype=np.uint32)
+    share = (np.arange(n, dtype=np.int64) * 900) // n
+    order = np.argsort(bits)
+    sb = bits[order]
+    # row i gets the first share[i] query bits (in sorted bit order): built word by word
+    for w in range(W):
+        in_w = sb[(sb >= 32 * w) & (sb < 32 * w + 32)]
+        first = int(np.searchsorted(sb, 32 * w))
+        for j, b in enumerate(in_w):
+            db[share > first + j, w] |= np.uint32(1) << np.uint32(b % 32)
+    t = make_table(db)
+    t.enable_timing(True)
+    check(t, db, q, 1000, 0.0, "ascending")
+    check(t, db, q, 100, 0.5, "ascending, cutoff")
+    tm = t.timing()
+    assert tm["queries"] == 2 + tm["handed_back"]  # (exact whichever route each query took; both are handed back today)
+    t.close()
+
+
+def test_enqueue_only_path_falls_back_on_the_device():
+    """gsim_db_search_device cannot look at the result on the host: the four classic kernels are enqueued
+    behind the single launch, gated on its hand-back flag.  Ties -> they run; random rows -> they return
+    at once.  Both blocks equal the oracle."""
+    import torch
+    W, k = 32, 200
+    base = O.synth_rows(0x71E9, 0, 0, 3, W)
+    tied = np.ascontiguousarray(base[np.random.default_rng(12).integers(0, 3, size=400_000)])
+    rnd = O.synth_rows(0x71EA, 0, 0, 400_000, W)
+    blk = capi.result_block_bytes(k)
+    st = torch.cuda.Stream(device=0)
+    for db, q in ((tied, base[2]), (rnd, rnd[77])):
+        t = make_table(db)
+        t.set_stream(st.cuda_stream)
+        out = torch.zeros(blk, dtype=torch.uint8, device="cuda:0")
+        for cutoff in (0.0, 0.06):
+            with torch.cuda.stream(st):
+                t.search_device(q, k, out.data_ptr(), cutoff)
+            st.synchronize()
+            hits, approx, _ = capi.parse_result_block(out.cpu().numpy().tobytes(), k)
+            want, wap = O.search(q, db, k, cutoff, nthreads=8)
+            assert approx == wap
+            assert_hits_equal(hits, want, "device block cutoff=%g" % cutoff)
+        t.close()
+
+
+def test_four_kernel_pipeline_still_covers_ordinary_queries():
+    """GSIM_FUSED=0 (read once per process, hence the child process): the classic pipeline on the same
+    parity tests."""
+    env = dict(os.environ, GSIM_FUSED="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
+                        "test_seeded_tables_match_oracle or test_ragged_and_edge_sizes or test_cutoff_semantics or "
+                        "test_tversky_matches_oracle or test_golden_synthetic_and_ties or test_device_result_blocks_and_merge"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

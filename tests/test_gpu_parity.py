@@ -33,6 +33,19 @@ def assert_hits_equal(got, want, ctx=""):
     assert (got["popc_db"] == want["popc_db"]).all(), ctx
 
 
+ORACLE_THREADS = min(64, os.cpu_count() or 1)
+_host_tables = {}
+
+
+def _host_table(seed, n, W):
+    """Synthetic table regenerated on the host (twin of gsim_db_generate), kept for the tests that share it."""
+    key = (seed, n, W)
+    if key not in _host_tables:
+        _host_tables.clear()  # one at a time: they are gigabytes
+        _host_tables[key] = O.synth_rows(seed, 0, 0, n, W)
+    return _host_tables[key]
+
+
 def make_table(db, device=0, ndevices=1):
     t = capi.Table(db.shape[1] * 32)
     t.add_rows(db)
@@ -715,6 +728,7 @@ def test_matrix_core_sample_pass_thresholds_are_safe(W, n):
     own = [O.synth_rows(0x5EED0001, 0, O.query_row(i, n), 1, W)[0] for i in range(70)]
     fresh = [O.synth_rows(0x5EED0002, 0, 900 + i, 1, W)[0] for i in range(10)]
     qs = np.stack(own + fresh)
+    results = {}
     for kw in ({}, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))):
         hits, approx = t.search(qs, 1000, 0.0, **kw)
         for i in range(len(qs)):
@@ -723,7 +737,16 @@ def test_matrix_core_sample_pass_thresholds_are_safe(W, n):
             assert_hits_equal(hits[i], one[0], "W=%d q=%d %r" % (W, i, sorted(kw)))
         for i in range(70):
             assert int(hits[i]["row"][0]) == O.query_row(i, n) and hits[i]["score"][0] == 1.0
+        results[tuple(sorted(kw))] = hits
     t.close()
+    # ... and a subset of the batch directly against the ORACLE on the whole table (regenerated on the host)
+    db = _host_table(0x5EED0001, n, W)
+    for kw in ({}, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))):
+        hits = results[tuple(sorted(kw))]
+        for i in (0, 13, 41, 69, 70, 79):
+            want, wap = O.search(qs[i], db, 1000, 0.0, nthreads=ORACLE_THREADS, **kw)
+            assert wap == n
+            assert_hits_equal(hits[i], want, "oracle W=%d q=%d %r" % (W, i, sorted(kw)))
 
 
 @pytest.mark.parametrize("W,n,nq,k", [(32, 50_000, 70, 8192), (64, 30_000, 130, 8192), (64, 300, 256, 300),
@@ -750,14 +773,24 @@ def test_matrix_core_pass_with_cutoff(W, n):
     own = [O.synth_rows(0x5EED0001, 0, O.query_row(i, n), 1, W)[0] for i in range(40)]
     fresh = [O.synth_rows(0x5EED0002, 0, 700 + i, 1, W)[0] for i in range(8)]
     qs = np.stack(own + fresh)
-    for cutoff, kw in [(0.2, {}), (0.12, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))),
-                       (0.02, {}), (1.5, {})]:
+    cases = [(0.2, {}), (0.12, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))),
+             (0.02, {}), (1.5, {})]
+    results = []
+    for cutoff, kw in cases:
         hits, approx = t.search(qs, 100, np.float32(cutoff), **kw)
         for i in range(len(qs)):
             one, ap1 = t.search(qs[i], 100, np.float32(cutoff), **kw)
             assert int(approx[i]) == int(ap1[0]), "W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], ap1[0])
             assert_hits_equal(hits[i], one[0], "W=%d cutoff=%g q=%d" % (W, cutoff, i))
+        results.append((hits, approx))
     t.close()
+    # ... and a subset directly against the ORACLE on the whole table: hits and approximate counts
+    db = _host_table(0x5EED0001, n, W)
+    for (cutoff, kw), (hits, approx) in zip(cases, results):
+        for i in (0, 17, 39, 40, 47):
+            want, wap = O.search(qs[i], db, 100, np.float32(cutoff), nthreads=ORACLE_THREADS, **kw)
+            assert int(approx[i]) == wap, "oracle W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], wap)
+            assert_hits_equal(hits[i], want, "oracle W=%d cutoff=%g q=%d" % (W, cutoff, i))
 
 
 def test_bench_contract_lines():

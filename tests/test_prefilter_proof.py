@@ -1,0 +1,76 @@
+"""The division-free pre-filters of the multi-query passes never reject a pair the exact test accepts.
+
+tests/cpp/prefilter_check.cpp includes the product's own arithmetic (gpusimilarity_amd/csrc/
+gsim_prefilter.h, the functions the kernels call) and enumerates EVERY (popc(query), popc(row),
+popc(query & row)) of 256...2048-bit fingerprints against every threshold bin, a grid of cutoffs,
+each pair's own score as the cutoff, Tanimoto and the Tversky weight corners -- tens of billions of
+checks on the host cores (the arithmetic is IEEE +, *, /, fmaf without contraction on both sides; the
+GPU test below compares the constants the device computes with the host's, bit for bit).
+Reference for the exact test: fingerprintdb_cuda.cu:100-102 (score >= cutoff ? score : 0)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "prefilter_check")
+THREADS = str(min(16, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def checker():
+    import oracle_lib as O
+    O.lib()  # builds oracle/libgsim_oracle.so if needed
+    src = os.path.join(ROOT, "tests", "cpp", "prefilter_check.cpp")
+    deps = [src, os.path.join(ROOT, "gpusimilarity_amd", "csrc", "gsim_prefilter.h"), os.path.join(ROOT, "oracle", "libgsim_oracle.so")]
+    if not os.path.exists(BIN) or any(os.path.getmtime(d) > os.path.getmtime(BIN) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-o", BIN, src,
+                               "-L" + os.path.join(ROOT, "oracle"), "-lgsim_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    return BIN
+
+
+def run(checker, *args):
+    r = subprocess.run([checker] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
+    words = r.stdout.split()
+    assert words[:1] == ["checked"], r.stdout + r.stderr
+    return int(words[1]), int(words[3]), r.stdout.strip()
+
+
+# (fp_bits, metric, alpha, beta, stride over popc(query), every n-th popc(query) gets the full sweep over the bins)
+CASES = [
+    (256, 0, 1, 1, 1, 1), (512, 0, 1, 1, 1, 4), (1024, 0, 1, 1, 2, 16), (2048, 0, 1, 1, 16, 64),
+    (512, 1, 0.3, 0.7, 1, 8), (1024, 1, 0.3, 0.7, 4, 16), (2048, 1, 0.3, 0.7, 16, 64),
+    (1024, 1, 0, 1, 8, 32), (1024, 1, 1, 0, 8, 32), (1024, 1, 0.5, 0.5, 8, 32), (1024, 1, 0.01, 0.99, 8, 32),
+    (1024, 1, 2, 2, 8, 32), (1024, 1, 1, 1, 8, 32), (512, 1, 0, 0, 4, 16),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dbit-%s-a%g-b%g" % (c[0], "tversky" if c[1] else "tanimoto", c[2], c[3]))
+def test_filters_never_reject_an_accepted_pair(checker, case):
+    checked, violations, text = run(checker, *case, THREADS)
+    assert checked > 1_000_000, text
+    assert violations == 0, text
+
+
+def test_the_checker_catches_an_over_eager_filter(checker):
+    """Negative control: bounds tightened by 0.05 % / 0.2 % must show up as violations."""
+    _, v1, text1 = run(checker, 256, 0, 1, 1, 1, 8, THREADS, 1.002)
+    _, v2, text2 = run(checker, 256, 1, 0.3, 0.7, 1, 8, THREADS, 1.0005)
+    assert v1 > 0 and v2 > 0, (text1, text2)
+
+
+@pytest.mark.gpu
+def test_device_filter_constants_equal_the_hosts():
+    """The proof above runs on the host; the kernel computes its constants on the device with the same
+    code: every constant for popc(query) = 0..2048, all 512 bins (and cutoff levels), bit for bit."""
+    from gpusimilarity_amd import capi
+    for metric, al, be in ((capi.METRIC_TANIMOTO, 1.0, 1.0), (capi.METRIC_TVERSKY, 0.3, 0.7), (capi.METRIC_TVERSKY, 0.0, 1.0),
+                           (capi.METRIC_TVERSKY, 0.01, 0.99)):
+        dev = capi.debug_prefilter_constants(metric, np.float32(al), np.float32(be), 2048, None, 0)
+        host = capi.debug_prefilter_constants(metric, np.float32(al), np.float32(be), 2048, None, -1)
+        assert (dev.view(np.uint32) == host.view(np.uint32)).all()
+        for cutoff in (0.05, 0.3333333, 0.7, 1.0):
+            dev = capi.debug_prefilter_constants(metric, np.float32(al), np.float32(be), 2048, np.float32(cutoff), 0)
+            host = capi.debug_prefilter_constants(metric, np.float32(al), np.float32(be), 2048, np.float32(cutoff), -1)
+            assert (dev.view(np.uint32) == host.view(np.uint32)).all()
