@@ -1084,11 +1084,13 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
     int ndev = 0;
     gsim_device_count(&ndev);
     if (ndev == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");
-    if (ndevices == 0) {
-        ndevices = ndev;
+    if (ndevices == 0) { // all devices from `device` on
         if (device < 0) device = 0;
+        if (device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+        ndevices = ndev - device;
     }
     if (ndevices < 0) return fail(GSIM_ERR_INVALID, "ndevices < 0");
+    if (device >= 0 && device + ndevices > ndev) return fail(GSIM_ERR_NO_DEVICE, "device range exceeds the GPUs present");
     // copyToGPU's factor adjustment, fingerprintdb_cuda.cu:170-173
     db->fold = db->fold_requested ? db->fold_requested : 1;
     while (db->W % db->fold != 0) db->fold++;
@@ -1258,6 +1260,7 @@ int gsim_db_set_stream(gsim_db* db, void* hip_stream)
 {
     if (!db || !db->finalized) return fail(GSIM_ERR_STATE, "table not finalized");
     if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "set_stream needs a single-shard handle");
+    std::lock_guard<std::mutex> guard(db->search_mutex); // (not under a running search)
     Shard& s = db->shards[0];
     s.stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s.own_stream;
     return GSIM_OK;
@@ -1284,18 +1287,22 @@ static int check_search_args(gsim_db* db, const uint32_t* queries, int metric)
     return GSIM_OK;
 }
 
-int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t kout, float cutoff, int metric,
                    float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
 {
     int rc = check_search_args(db, queries, metric);
     if (rc != GSIM_OK) return rc;
-    if ((!hits && k && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
+    if ((!hits && kout && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
     std::lock_guard<std::mutex> guard(db->search_mutex);
+    // kout is the stride of the caller's hits array; the search itself never asks for more hits than the
+    // table has rows (result blocks, pinned buffers and the select's capacity scale with k: a wild count
+    // from a client must not size them)
+    const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(kout, db->nrows));
     const size_t nsh = db->shards.size();
     std::vector<gsim_hit> merged;
     if (db->fold > 1) {
         if (metric != GSIM_METRIC_TANIMOTO) return fail(GSIM_ERR_INVALID, "folded tables support Tanimoto only");
-        return search_folded(db, queries, nq, k, cutoff, hits, counts, approx);
+        return search_folded(db, queries, nq, kout, cutoff, hits, counts, approx);
     }
     const bool batched = nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 && gsim::batch_supported(db->W) &&
                          env_int("GSIM_BATCH", 1) != 0;
@@ -1358,7 +1365,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                 }
                 if (nsh > 1) std::sort(merged.begin(), merged.end(), hit_before);
                 const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
-                if (n) std::memcpy(hits + static_cast<size_t>(base + q) * k, merged.data(), sizeof(gsim_hit) * n);
+                if (n) std::memcpy(hits + static_cast<size_t>(base + q) * kout, merged.data(), sizeof(gsim_hit) * n);
                 counts[base + q] = n;
                 if (approx) approx[base + q] = ap;
             }
@@ -1366,7 +1373,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             for (uint32_t q = 0; q < nb; q++) {
                 if (!redo[q]) continue;
                 rc = search_one(db, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta,
-                                hits + static_cast<size_t>(base + q) * k, &counts[base + q],
+                                hits + static_cast<size_t>(base + q) * kout, &counts[base + q],
                                 approx ? &approx[base + q] : nullptr, merged);
                 if (rc != GSIM_OK) return rc;
             }
@@ -1375,7 +1382,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
     }
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
-        rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * k, &counts[q],
+        rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout, &counts[q],
                         approx ? &approx[q] : nullptr, merged);
         if (rc != GSIM_OK) return rc;
     }
@@ -1562,6 +1569,7 @@ int gsim_db_search_cpu(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32
 int gsim_db_enable_timing(gsim_db* db, int enable)
 {
     if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
     db->timing = enable != 0;
     db->acc = gsim_timing{};
     for (auto& s : db->shards) {
@@ -1582,6 +1590,7 @@ int gsim_db_enable_timing(gsim_db* db, int enable)
 int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
 {
     if (!db || !out) return fail(GSIM_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
     db->acc.candidates_sum = 0;
     db->acc.finalists_sum = 0;
     db->acc.handed_back = 0;

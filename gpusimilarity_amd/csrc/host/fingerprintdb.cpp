@@ -43,6 +43,13 @@ size_t get_available_gpu_memory()
     return b;
 }
 
+size_t get_gpu_free_memory(unsigned int device)
+{
+    size_t b = 0;
+    gsim_device_free_bytes(static_cast<int>(device), &b);
+    return b;
+}
+
 FingerprintDB::FingerprintDB(int fp_bitcount, int fp_count, const std::string& dbkey,
                              std::vector<std::vector<char>>& data, std::vector<char*>& smiles_vector,
                              std::vector<char*>& ids_vector)
@@ -103,6 +110,9 @@ void FingerprintDB::search(const Fingerprint& query, const std::string& dbkey, u
         return;
     }
     if (static_cast<int>(query.size()) != m_fp_intsize) throw std::invalid_argument("query has the wrong width");
+    // no more hits than rows (the reference bounds its work by the row count, :282-287): a huge count from the
+    // socket must not size the buffers
+    if (max_return_count > count()) max_return_count = count();
     std::vector<gsim_hit> hits(max_return_count ? max_return_count : 1);
     uint32_t count = 0;
     uint64_t approx = 0;

@@ -23,6 +23,7 @@ typedef std::pair<float, ResultData> SortableResult; // fingerprintdb_cuda.h:30
 unsigned int get_gpu_count();                    // fingerprintdb_cuda.cu:40-52
 unsigned int get_next_gpu(size_t required_memory); // fingerprintdb_cuda.cu:54-68 (throws std::runtime_error)
 size_t get_available_gpu_memory();               // fingerprintdb_cuda.cu:401-413
+size_t get_gpu_free_memory(unsigned int device); // fingerprintdb_cuda.cu:33-38
 
 class FingerprintDB
 {

@@ -15,7 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <set>
+#include <unordered_map>
 #include <sstream>
 #include <stdexcept>
 
@@ -37,6 +37,87 @@ std::string base_name(const std::string& path)
 }
 } // namespace
 
+// Where the tables go and whether they have to be folded (gpusim.cpp:121-163 decides the fold factor
+// from the SUM of free memory but then places every storage whole on one GPU; here the decision is
+// made against the placement that will actually happen).
+//
+//   * requested == 1 (one GPU per table, round-robin like get_next_gpu): simulate that placement with
+//     every device's free memory.  If a table does not fit any single device but the devices together
+//     hold everything, the tables are sharded over all devices instead of failing or folding.
+//   * requested == 0 / n: every table is sharded over all / the first n devices: capacity = their sum.
+//   * Reserve per table: the four-kernel fallback pipeline's scratch (24 B per row, allocated on the
+//     first query that needs it) + 64 MB of fixed buffers.
+//   * What still does not fit is folded by ceil(bytes / capacity), and --gpu_bitcount may ask for more
+//     (never for less: the reference's std::invalid_argument, :146-149).
+struct TableFacts {
+    size_t bytes;
+    size_t rows;
+    int fp_bits;
+};
+
+struct PlacementPlan {
+    unsigned int fold_factor = 1;
+    int ndevices = 1; // argument of FingerprintDB::copyToGPU
+};
+
+static PlacementPlan plan_placement(const std::vector<TableFacts>& tables, int gpu_bitcount, int requested,
+                                    const std::vector<size_t>& free_bytes)
+{
+    PlacementPlan plan;
+    const int ndev = static_cast<int>(free_bytes.size());
+    plan.ndevices = requested < 0 ? 1 : (requested > ndev ? ndev : requested);
+    auto reserve = [](const TableFacts& t) { return t.rows * 24 + (size_t(64) << 20); };
+    size_t total = 0, total_reserve = 0;
+    int max_bits = 0;
+    for (const auto& t : tables) {
+        total += t.bytes;
+        total_reserve += reserve(t);
+        max_bits = std::max(max_bits, t.fp_bits);
+    }
+    auto pool = [&](int n) { // free memory of the first n devices (0 = all), minus the reserves
+        size_t sum = 0;
+        for (int d = 0; d < (n == 0 ? ndev : n) && d < ndev; d++) sum += free_bytes[d];
+        return sum > total_reserve ? sum - total_reserve : 0;
+    };
+    auto whole_tables_fit = [&]() { // round-robin, first device with room, as gsim_next_device does
+        std::vector<size_t> left = free_bytes;
+        int next = 0;
+        for (const auto& t : tables) {
+            const size_t need = t.bytes + reserve(t);
+            bool placed = false;
+            for (int i = 0; i < ndev && !placed; i++) {
+                const int d = next++ % ndev;
+                if (left[d] > need) {
+                    left[d] -= need;
+                    placed = true;
+                }
+            }
+            if (!placed) return false;
+        }
+        return true;
+    };
+    size_t capacity = pool(plan.ndevices);
+    if (plan.ndevices == 1) {
+        if (whole_tables_fit()) {
+            capacity = total; // fits as it is
+        } else if (ndev > 1 && pool(0) >= total) {
+            plan.ndevices = 0; // together the devices hold it: shard every table over all of them
+            capacity = pool(0);
+        } else {
+            capacity = pool(0); // the reference's sum; folded storages are placed one by one
+        }
+    }
+    std::fprintf(stderr, "Database:   %zu MB GPU Memory:  %zu MB\n", total / 1024 / 1024, capacity / 1024 / 1024);
+    if (total > capacity)
+        plan.fold_factor = static_cast<unsigned int>(std::ceil(static_cast<float>(total) / static_cast<float>(capacity ? capacity : 1)));
+    if (gpu_bitcount > 0) {
+        const unsigned int arg_fold_factor = static_cast<unsigned int>(max_bits / gpu_bitcount);
+        if (arg_fold_factor < plan.fold_factor) throw std::invalid_argument("GPU bitset not sufficiently small to fit on GPU");
+        plan.fold_factor = arg_fold_factor;
+    }
+    return plan;
+}
+
 GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int gpu_bitcount, bool open_socket,
                            bool use_gpu, int ndevices)
     : m_use_gpu(use_gpu)
@@ -45,6 +126,7 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
     std::fprintf(stderr, "Utilizing %u GPUs for calculation.\n", get_gpu_count());
     if (open_socket && !setupSocket()) return;
 
+    std::vector<TableFacts> facts;
     for (const auto& database_fname : database_fnames) {
         int fp_bitcount = 0, fp_count = 0;
         std::string dbkey;
@@ -57,43 +139,20 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
                                                    ids_vector);
         m_databases[base_name(database_fname)] = fps;
     }
-
-    // gpusim.cpp:121-163: does everything fit?  If not (or if --gpu_bitcount asks for it) the
-    // tables are folded exactly as the reference does.
-    size_t total_db_memory = 0;
-    unsigned int max_compounds_in_db = 0;
-    int max_fp_bitcount = 0;
-    for (auto& kv : m_databases) {
-        total_db_memory += kv.second->getFingerprintDataSize();
-        max_compounds_in_db = std::max(max_compounds_in_db, kv.second->count());
-        max_fp_bitcount = std::max(max_fp_bitcount, kv.second->getFingerprintBitcount());
+    if (!usingGPU()) {
+        std::fprintf(stderr, "Ready for searches.\n");
+        return;
     }
-    if (usingGPU()) {
-        size_t gpu_memory = get_available_gpu_memory();
-        // search scratch: ~24 bytes per row worst case (candidate + finalist slots)
-        const size_t scratch = static_cast<size_t>(max_compounds_in_db) * 24;
-        gpu_memory = gpu_memory > scratch ? gpu_memory - scratch : 0;
-        std::fprintf(stderr, "Database:   %zu MB GPU Memory:  %zu MB\n", total_db_memory / 1024 / 1024,
-                     gpu_memory / 1024 / 1024);
-        unsigned int fold_factor = 1;
-        if (total_db_memory > gpu_memory) {
-            fold_factor = static_cast<unsigned int>(
-                std::ceil(static_cast<float>(total_db_memory) / static_cast<float>(gpu_memory ? gpu_memory : 1)));
-        }
-        if (gpu_bitcount > 0) {
-            const unsigned int arg_fold_factor = static_cast<unsigned int>(max_fp_bitcount / gpu_bitcount);
-            if (arg_fold_factor < fold_factor) {
-                throw std::invalid_argument("GPU bitset not sufficiently small to fit on GPU"); // :146-149
-            }
-            fold_factor = arg_fold_factor;
-        }
-        std::fprintf(stderr, "Putting graphics card data up.\n");
-        if (fold_factor > 1) {
-            std::fprintf(stderr, "Folding databases by at least %u to fit in gpu memory\n", fold_factor);
-        }
-        for (auto& kv : m_databases) kv.second->copyToGPU(fold_factor, ndevices);
-        std::fprintf(stderr, "Finished putting graphics card data up.\n");
-    }
+    for (auto& kv : m_databases)
+        facts.push_back({kv.second->getFingerprintDataSize(), kv.second->count(), kv.second->getFingerprintBitcount()});
+    std::vector<size_t> free_bytes(get_gpu_count());
+    for (size_t d = 0; d < free_bytes.size(); d++) free_bytes[d] = get_gpu_free_memory(static_cast<unsigned int>(d));
+    const PlacementPlan plan = plan_placement(facts, gpu_bitcount, ndevices, free_bytes);
+    std::fprintf(stderr, "Putting graphics card data up.\n");
+    if (plan.fold_factor > 1) std::fprintf(stderr, "Folding databases by at least %u to fit in gpu memory\n", plan.fold_factor);
+    if (ndevices == 1 && plan.ndevices == 0) std::fprintf(stderr, "Sharding every database over all GPUs (no single GPU holds the largest)\n");
+    for (auto& kv : m_databases) kv.second->copyToGPU(plan.fold_factor, plan.ndevices);
+    std::fprintf(stderr, "Finished putting graphics card data up.\n");
     std::fprintf(stderr, "Ready for searches.\n");
 }
 
@@ -160,56 +219,70 @@ void GPUSimServer::searchDatabases(const Fingerprint& query, int results_request
                                    std::vector<char*>& results_smiles, std::vector<char*>& results_ids,
                                    std::vector<float>& results_scores, unsigned long& approximate_result_count)
 {
-    // (score, arrival order): the reference sorts (score, (smiles*, id*)) pairs and reverses,
-    // which leaves equal scores in heap-address order; here ties keep database order
-    // (map order) then row order -- deterministic.
-    struct Entry {
-        float score;
-        size_t seq;
-        char* smiles;
-        char* id;
+    // Every database returns its hits in canonical order (score desc, row asc), so the merged order
+    // -- score desc; equal scores: database (map) order, then row order -- comes out of a k-way merge
+    // on a small heap, and only as far as it is needed.  (The reference concatenates, std::sorts
+    // (score, (smiles*, id*)) pairs and reverses, gpusim.cpp:330-336, which leaves equal scores in
+    // heap-address order; this order is deterministic.)
+    struct List {
+        std::vector<char*> smiles, ids;
+        std::vector<float> scores;
+        size_t pos = 0;
     };
-    std::vector<Entry> sortable;
+    std::vector<List> lists;
     for (const auto& name_key : dbname_to_key) {
         const std::string& local_dbname = name_key.first;
         if (m_databases.find(local_dbname) == m_databases.end()) {
             std::fprintf(stderr, "Unknown database  %s  requested.\n", local_dbname.c_str());
             continue;
         }
-        std::vector<char*> l_smiles, l_ids;
-        std::vector<float> l_scores;
+        lists.emplace_back();
+        List& l = lists.back();
         unsigned long local_approx = 0; // the reference leaves it uninitialised on the CPU path
         similaritySearch(query, local_dbname, name_key.second, static_cast<unsigned int>(results_requested),
-                         similarity_cutoff, usingGPU() ? CalcType::GPU : CalcType::CPU, l_smiles, l_ids, l_scores,
+                         similarity_cutoff, usingGPU() ? CalcType::GPU : CalcType::CPU, l.smiles, l.ids, l.scores,
                          local_approx);
         approximate_result_count += local_approx;
-        for (size_t i = 0; i < l_smiles.size(); i++) sortable.push_back({l_scores[i], sortable.size(), l_smiles[i], l_ids[i]});
     }
-    std::stable_sort(sortable.begin(), sortable.end(), [](const Entry& a, const Entry& b) { return a.score > b.score; });
+    if (results_requested <= 0) return;
+    auto later = [&](size_t a, size_t b) { // "a comes after b": heap keeps the earliest entry on top
+        const float sa = lists[a].scores[lists[a].pos], sb = lists[b].scores[lists[b].pos];
+        return sa < sb || (sa == sb && a > b);
+    };
+    std::vector<size_t> heap;
+    for (size_t i = 0; i < lists.size(); i++)
+        if (!lists[i].scores.empty()) heap.push_back(i);
+    std::make_heap(heap.begin(), heap.end(), later);
 
-    std::map<std::string, std::string> smiles_to_ids;
-    for (const auto& r : sortable) {
-        const std::string smiles(r.smiles);
-        auto it = smiles_to_ids.find(smiles);
-        if (it != smiles_to_ids.end()) {
-            it->second += ";:;";
-            it->second += r.id;
+    // Hits with equal SMILES fold into one result whose id is the ids joined by ";:;" (:342-357); the
+    // merge stops with the entry that completes the results_requested-th distinct SMILES (:355).
+    struct Result {
+        float score;
+        char* smiles;
+        std::string ids;
+    };
+    std::vector<Result> results;
+    std::unordered_map<std::string, size_t> by_smiles;
+    while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), later);
+        List& l = lists[heap.back()];
+        const size_t p = l.pos++;
+        auto found = by_smiles.find(l.smiles[p]);
+        if (found != by_smiles.end()) {
+            results[found->second].ids += ";:;";
+            results[found->second].ids += l.ids[p];
         } else {
-            smiles_to_ids[smiles] = r.id;
+            by_smiles.emplace(l.smiles[p], results.size());
+            results.push_back({l.scores[p], l.smiles[p], l.ids[p]});
         }
-        if (smiles_to_ids.size() >= static_cast<size_t>(results_requested)) break;
+        if (results.size() >= static_cast<size_t>(results_requested)) break;
+        if (l.pos < l.scores.size()) std::push_heap(heap.begin(), heap.end(), later);
+        else heap.pop_back();
     }
-    int written = 0;
-    std::set<std::string> smiles_written;
-    for (const auto& r : sortable) {
-        if (written >= results_requested) break;
-        const std::string smiles(r.smiles);
-        if (smiles_written.count(smiles) > 0) continue;
-        smiles_written.insert(smiles);
+    for (const auto& r : results) {
         results_scores.push_back(r.score);
         results_smiles.push_back(r.smiles);
-        results_ids.push_back(strdup(smiles_to_ids[smiles].c_str()));
-        ++written;
+        results_ids.push_back(strdup(r.ids.c_str())); // the receiver frees them (:369-370)
     }
 }
 
@@ -242,7 +315,10 @@ std::vector<unsigned char> GPUSimServer::handleRequest(const std::vector<unsigne
     std::vector<float> results_scores;
     const auto t0 = std::chrono::steady_clock::now();
     unsigned long approximate_result_count = 0;
-    searchDatabases(query, results_requested, similarity_cutoff, dbname_to_key, results_smiles, results_ids,
+    // (a count <= 0 from the socket -- the reference would cast it to a huge unsigned -- gets an empty reply; counts
+    // above the table sizes are clamped inside FingerprintDB::search)
+    if (results_requested > 0)
+        searchDatabases(query, results_requested, similarity_cutoff, dbname_to_key, results_smiles, results_ids,
                     results_scores, approximate_result_count);
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(stderr, "Search completed, time elapsed: %g\n", el);
@@ -261,13 +337,14 @@ std::vector<unsigned char> GPUSimServer::handleRequest(const std::vector<unsigne
 
 namespace
 {
-// A request is complete when it parses: i32 ndb, ndb x (cstr, cstr), i32, i32, f64, QByteArray.
-bool request_complete(const std::vector<unsigned char>& buf)
+// Length of the first complete request in buf (i32 ndb, ndb x (cstr, cstr), i32, i32, f64, QByteArray),
+// 0 when more bytes are needed, -1 for garbage.
+long request_length(const std::vector<unsigned char>& buf)
 {
     try {
         QdsReader r(buf);
         const int ndb = r.i32();
-        if (ndb < 0 || ndb > 4096) return true; // garbage: let the handler fail and drop the client
+        if (ndb < 0 || ndb > 4096) return -1;
         for (int i = 0; i < ndb; i++) {
             r.cstr();
             r.cstr();
@@ -276,11 +353,13 @@ bool request_complete(const std::vector<unsigned char>& buf)
         r.i32();
         r.f64();
         r.bytearray();
-        return true;
+        return static_cast<long>(r.consumed());
     } catch (const std::exception&) {
-        return false;
+        return 0;
     }
 }
+
+constexpr size_t kMaxRequestBytes = size_t(4) << 20; // names + keys + one fingerprint: kilobytes in practice
 
 bool write_all(int fd, const unsigned char* p, size_t n)
 {
@@ -300,6 +379,11 @@ bool write_all(int fd, const unsigned char* p, size_t n)
 int GPUSimServer::exec()
 {
     if (m_listen_fd < 0) return 1;
+    auto len_error = [](int& fd, const char* what) {
+        std::fprintf(stderr, "request failed: %s\n", what);
+        close(fd);
+        fd = -1;
+    };
     struct Client {
         int fd;
         std::vector<unsigned char> buf;
@@ -330,21 +414,32 @@ int GPUSimServer::exec()
                 continue;
             }
             c.buf.insert(c.buf.end(), tmp, tmp + n);
-            // the reference assumes a whole request per readyRead (gpusim.cpp:381); here
-            // partial frames are buffered until they parse
-            if (!request_complete(c.buf)) continue;
-            try {
-                const std::vector<unsigned char> reply = handleRequest(c.buf);
-                if (!write_all(c.fd, reply.data(), reply.size())) {
-                    close(c.fd);
-                    c.fd = -1;
+            // the reference assumes a whole request per readyRead (gpusim.cpp:381); here partial frames are
+            // buffered until they parse and several requests in one read are answered one after the other
+            for (;;) {
+                const long len = request_length(c.buf);
+                if (len == 0) {
+                    if (c.buf.size() > kMaxRequestBytes) len_error(c.fd, "request larger than 4 MB");
+                    break;
                 }
-            } catch (const std::exception& e) {
-                std::fprintf(stderr, "request failed: %s\n", e.what());
-                close(c.fd);
-                c.fd = -1;
+                if (len < 0) {
+                    len_error(c.fd, "malformed request");
+                    break;
+                }
+                try {
+                    const std::vector<unsigned char> frame(c.buf.begin(), c.buf.begin() + len);
+                    const std::vector<unsigned char> reply = handleRequest(frame);
+                    c.buf.erase(c.buf.begin(), c.buf.begin() + len);
+                    if (!write_all(c.fd, reply.data(), reply.size())) {
+                        close(c.fd);
+                        c.fd = -1;
+                        break;
+                    }
+                } catch (const std::exception& e) {
+                    len_error(c.fd, e.what());
+                    break;
+                }
             }
-            c.buf.clear();
         }
         clients.erase(std::remove_if(clients.begin(), clients.end(), [](const Client& c) { return c.fd < 0; }),
                       clients.end());

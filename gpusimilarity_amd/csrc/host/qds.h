@@ -20,11 +20,12 @@ namespace gpusim
 class QdsReader
 {
   public:
-    QdsReader(const unsigned char* data, size_t size) : m_p(data), m_end(data + size) {}
+    QdsReader(const unsigned char* data, size_t size) : m_begin(data), m_p(data), m_end(data + size) {}
     explicit QdsReader(const std::vector<unsigned char>& v) : QdsReader(v.data(), v.size()) {}
 
     bool atEnd() const { return m_p >= m_end; }
     size_t remaining() const { return static_cast<size_t>(m_end - m_p); }
+    size_t consumed() const { return static_cast<size_t>(m_p - m_begin); }
 
     uint32_t u32()
     {
@@ -81,6 +82,7 @@ class QdsReader
     {
         if (static_cast<size_t>(m_end - m_p) < n) throw std::runtime_error("QDataStream: truncated input");
     }
+    const unsigned char* m_begin;
     const unsigned char* m_p;
     const unsigned char* m_end;
 };

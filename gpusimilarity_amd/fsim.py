@@ -139,8 +139,11 @@ def _cstr(b: bytes) -> bytes:
     return struct.pack(">I", len(b) + 1) + b + b"\0"
 
 
-def write_fsim(path: str, dbkey: str, fp_bitcount: int, fp_blocks, smiles, ids) -> None:
-    """Minimal writer (tests / benchmarks): one SMILES block, one ID block."""
+def write_fsim(path: str, dbkey: str, fp_bitcount: int, fp_blocks, smiles, ids, smiles_blocks: int = 1,
+               id_blocks: int = 1) -> None:
+    """Writer for tests and benchmark fixtures: one FP block per entry of ``fp_blocks`` (each becomes a
+    storage in the server, like the ~1 GiB blocks gpusim_createdb.py:56-69 rolls over), the SMILES / ID
+    strings split into ``smiles_blocks`` / ``id_blocks`` blocks of about equal length."""
     fp_blocks = [np.ascontiguousarray(b, dtype="<u4") for b in fp_blocks]
     fp_count = sum(b.shape[0] for b in fp_blocks)
     out = [struct.pack(">i", DATABASE_VERSION), _cstr(dbkey.encode("utf-8")),
@@ -153,8 +156,13 @@ def write_fsim(path: str, dbkey: str, fp_bitcount: int, fp_blocks, smiles, ids) 
             parts.append(struct.pack(">I", len(blob)) + blob)
         return b"".join(parts)
 
+    def split(strings, nblocks):
+        strings = list(strings)
+        per = (len(strings) + nblocks - 1) // max(1, nblocks)
+        return [b"".join(_cstr(s) for s in strings[i * per:(i + 1) * per]) for i in range(max(1, nblocks))]
+
     out.append(qba_list([b.tobytes() for b in fp_blocks]))
-    out.append(qba_list([b"".join(_cstr(s) for s in smiles)]))
-    out.append(qba_list([b"".join(_cstr(s) for s in ids)]))
+    out.append(qba_list(split(smiles, smiles_blocks)))
+    out.append(qba_list(split(ids, id_blocks)))
     with open(path, "wb") as f:
         f.write(b"".join(out))
