@@ -188,25 +188,29 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
     nq = (warmup + steps) * qps
     distinct = min(nq, 64)  # distinct queries, cycled
     queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(distinct)]
-    bufs = table.make_search_buffers(1, k)
+    bufs = table.make_search_buffers(qps, k)
     ss = ShardedSearch(table, k, ctx["dev"], stream=ctx["stream"]) if sharded else None
+    steps_q = [np.ascontiguousarray(np.stack([queries[(s_ * qps + j) % distinct] for j in range(qps)])) for s_ in range(warmup + steps)]
 
-    def one_query(q):
+    def one_step(s_):
         if not sharded:
-            # the C ABI's synchronous entry point (FingerprintDB::search): the kernels write the hits
-            # into pinned host memory, the call returns when they are there
-            table.search_into(q, k, bufs)
+            # ONE call of the C ABI per step: gsim_db_search_each answers the step's queries strictly one after the
+            # other through the synchronous single-query path (FingerprintDB::search called qps times, as the
+            # reference's C++ server does) -- each query's kernel writes its hits into pinned host memory and the
+            # next one is launched when they are there; no Python between the queries
+            table.search_each_into(steps_q[s_], k, bufs)
             return
-        ss.enqueue(q)  # local top-k -> all-gather (k*12+16 B per GPU) -> rank merge -> D2H
-        ss.synchronize()  # the query is done when its k hits are in host memory
+        for j in range(qps):
+            ss.enqueue(steps_q[s_][j])  # local top-k -> all-gather (k*12+16 B per GPU) -> rank merge -> D2H
+            ss.synchronize()  # the query is done when its k hits are in host memory
 
-    for i in range(warmup * qps):
-        one_query(queries[i % distinct])
+    for s_ in range(warmup):
+        one_step(s_)
     if warmup:
         if sharded:
             hits, approx, _ = ss.result()
         else:
-            hits, approx = bufs[0][0, :bufs[1][0]], int(bufs[2][0])
+            hits, approx = bufs[0][qps - 1, :bufs[1][qps - 1]], int(bufs[2][qps - 1])
         want_row = query_row((warmup * qps - 1) % distinct, total_rows)
         assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
             "self hit missing: %r" % (hits[:3],)
@@ -216,8 +220,8 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
     if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
-    for i in range(warmup * qps, nq):
-        one_query(queries[i % distinct])
+    for s_ in range(warmup, warmup + steps):
+        one_step(s_)
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()

@@ -123,8 +123,12 @@ template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, v4i rb, v1
 // the operand work per MFMA is 5 / MT instructions; 2 W MT registers hold the queries.
 // NT = row tiles in flight per wave (accumulators: 16 MT NT registers; two independent MFMA chains
 // per wave are worth having, except when that leaves half of the waves without a row tile).
-template <int WORDS, int MT, int NT = (MT == 1 ? 2 : 1)>
-__global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
+// WV = waves per workgroup.  8 (two per SIMD: one wave's operand work overlaps the other's MFMAs) everywhere
+// except 2048-bit rows with MT = 2: two query tiles per wave need 256 registers for the expanded queries
+// alone, which only fits with ONE wave per SIMD (512 registers per lane) -- four waves x 64 queries; the
+// operand work per MFMA halves and a wave overlaps its own VALU with its own four MFMA chains.
+template <int WORDS, int MT, int NT = (MT == 1 ? 2 : 1), int WV = kMWaves>
+__global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
 {
     constexpr int QW = 32 * MT;         // queries per wave
     constexpr int KG = WORDS / 8;       // 256-bit groups per row
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     constexpr int RB = kMChunks / CPR;  // rows per LDS block
     constexpr int NTB = RB / 32;        // 32-row tiles per block
     static_assert(WORDS % 8 == 0 && CPR <= 16 && NTB >= 2 && NTB % 2 == 0, "unsupported row width");
-    static_assert(MT >= 1 && MT <= kMaxMT && 2 * WORDS * MT <= 128, "query operands must fit in registers");
+    static_assert(MT >= 1 && MT <= kMaxMT && 2 * WORDS * MT <= (WV == 4 ? 256 : 128), "query operands must fit in registers");
+    static_assert(WV == 4 || WV == kMWaves, "waves per workgroup");
+    constexpr int kWBlock = WV * 64;
     static_assert(NT >= 1 && NT <= 4 && NTB % NT == 0, "row tiles in flight");
     __shared__ MfmaShared sh;
 
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     // between them (tile = wave % p2, row group = wave / p2, p2 = query tiles rounded up to 2^n).
     const int ntiles = (nq + QW - 1) / QW;
     const int p2 = ntiles <= 1 ? 1 : (ntiles <= 2 ? 2 : (ntiles <= 4 ? 4 : 8));
-    const int tile = wq % p2, rgroup = wq / p2, ngroups = kMWaves / p2;
+    const int tile = wq % p2, rgroup = wq / p2, ngroups = WV / p2;
     const int q0t = tile * QW; // first query of this wave's tile(s)
     const bool wave_has_queries = q0t < nq && rgroup * NT < NTB;
     // The rare arguments once, into scalar registers; device pointers carry the global address
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     // A cutoff that keeps a sizeable fraction of the table (estimated by the sample pass, bit 3 of
     // the flags) would send that fraction of all pairs through the exact path: leave such batches
     // to the VALU pass (the host re-runs them when it sees the flag).
+    if (WV < kMWaves && lane == 0) rr.seg_count[w + WV] = 0; // the candidate segments of the waves that do not exist
     if (has_cutoff && (*((g_u32p) rr.flags) & 8u)) {
         if (lane == 0) rr.seg_count[w] = 0;
         return;
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     // c = (p % CPR') ^ swizzle of row p / CPR'; both the row offset inside a load group and c are the
     // same for every j, so a lane keeps two values and does 32-bit row arithmetic per load (rows per
     // device < 2^31).
-    constexpr int RPJ = kMBlock / CPR; // rows covered by one load of the whole workgroup
+    constexpr int RPJ = kWBlock / CPR; // rows covered by one load of the whole workgroup
     const int line0 = wq * 4 + (lane >> 4);
     const uint32_t rowl0 = static_cast<uint32_t>(line0 * RPLN + (lane & 15) / CPR);
     const uint32_t chunk0 = static_cast<uint32_t>(((lane & 15) % CPR) ^ (line0 % CPR));
@@ -260,11 +267,11 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     auto issue_block = [&](u64 blk, int buf) {
         const uint32_t first = static_cast<uint32_t>(blk) * RB + rowl0;
 #pragma unroll
-        for (int j = 0; j < kMChunks / kMBlock; j++) {
+        for (int j = 0; j < kMChunks / kWBlock; j++) {
             uint32_t grow = first + j * RPJ;
             grow = grow < last_row ? grow : last_row;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (dbc + static_cast<u64>(grow) * CPR),
-                                             (__attribute__((address_space(3))) void*) (&sh.rows[buf][(j * kMWaves + wq) * 64]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*) (&sh.rows[buf][(j * WV + wq) * 64]), 16, 0, 0);
         }
     };
 
@@ -775,7 +782,14 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
         const u64 nblocks = (a.nrows + (kMChunks / 16) - 1) / (kMChunks / 16);
         // (with one query tile only four of the eight row groups find a pair of row tiles; single
         // tiles for all eight waves -- NT = 1 -- were 20-50 % slower: one MFMA chain per wave)
-        hipLaunchKernelGGL((batch_mfma_kernel<64, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        static const int w64_env = std::getenv("GSIM_BATCH_MFMA_W64") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_W64")) : 0;
+        // Experiment kept for the record (GSIM_BATCH_MFMA_W64=2): four waves x two query tiles each halves the
+        // operand expansion per MFMA but leaves one wave per SIMD -- 30.0 ms per 256-query batch against 24.7 ms:
+        // the overlap of one wave's VALU work with the other wave's MFMAs is worth more than the saved work.
+        if (w64_env == 2)
+            hipLaunchKernelGGL((batch_mfma_kernel<64, 2, 1, 4>), dim3(num_cus), dim3(256), 0, s, a, nblocks);
+        else
+            hipLaunchKernelGGL((batch_mfma_kernel<64, 1>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
     } else if (a.W == 32) {
         const u64 nblocks = (a.nrows + (kMChunks / 8) - 1) / (kMChunks / 8);
         static const int mt_env = std::getenv("GSIM_BATCH_MFMA_MT") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_MT")) : 0;

@@ -29,6 +29,7 @@ namespace
 {
 
 thread_local std::string g_last_error;
+thread_local bool g_force_each = false; // gsim_db_search_each: queries one by one, never a shared table pass
 
 int fail(int code, const std::string& msg)
 {
@@ -395,6 +396,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
         if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
         f.dbg = s.d_dbg;
+        static const long long cached_bytes = std::getenv("GSIM_FUSED_CACHED_BYTES") ? std::atoll(std::getenv("GSIM_FUSED_CACHED_BYTES")) : 0;
+        f.cached_loads = static_cast<uint64_t>(s.nrows) * s.W * 4 <= static_cast<uint64_t>(cached_bytes) ? 1u : 0u;
         static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
         f.xflags = static_cast<uint32_t>(xflags);
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
@@ -557,8 +560,26 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         }
         stat(16, 1, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "elect-loaded", a, b, c);
+        stat(17, 1, &a, &b, &c);
+        std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "static-end(w0)", a, b, c);
         stat(12, 4, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n  end %.2f\n", "wave scan-end", a, b, c, (t[nwg * 24] - t0) / 100.0);
+        { // streaming end per workgroup class: blockIdx % 8 (the XCD a block lands on) and blockIdx / 32 (dispatch order)
+            double sx[8] = {}, sq[8] = {};
+            int nx[8] = {}, nqd[8] = {};
+            for (size_t g = 0; g < nwg; g++) {
+                const unsigned long long v = t[g * 24 + 3];
+                if (v < t0 || v - t0 > 100000000ull) continue;
+                sx[g % 8] += (v - t0) / 100.0, nx[g % 8]++;
+                const size_t oct = g * 8 / nwg;
+                sq[oct] += (v - t0) / 100.0, nqd[oct]++;
+            }
+            std::fprintf(stderr, "  arrived, mean by blockIdx %% 8:");
+            for (int i = 0; i < 8; i++) std::fprintf(stderr, " %7.1f", nx[i] ? sx[i] / nx[i] : 0.0);
+            std::fprintf(stderr, "\n  arrived, mean by blockIdx octile:");
+            for (int i = 0; i < 8; i++) std::fprintf(stderr, " %7.1f", nqd[i] ? sq[i] / nqd[i] : 0.0);
+            std::fprintf(stderr, "\n");
+        }
         (void) hipMemset(s.d_dbg, 0, t.size() * 8);
     }
     if (done && !(h->flags & 2u)) return GSIM_OK;
@@ -1304,8 +1325,8 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         if (metric != GSIM_METRIC_TANIMOTO) return fail(GSIM_ERR_INVALID, "folded tables support Tanimoto only");
         return search_folded(db, queries, nq, kout, cutoff, hits, counts, approx);
     }
-    const bool batched = nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 && gsim::batch_supported(db->W) &&
-                         env_int("GSIM_BATCH", 1) != 0;
+    const bool batched = !g_force_each && nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 &&
+                         gsim::batch_supported(db->W) && env_int("GSIM_BATCH", 1) != 0;
     if (batched) {
         // Multi-query path: kBQ queries share each pass over the table (VALU-bound).
         const size_t blk = gsim_result_block_bytes(k);
@@ -1387,6 +1408,15 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         if (rc != GSIM_OK) return rc;
     }
     return GSIM_OK;
+}
+
+int gsim_db_search_each(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+                        float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    g_force_each = true;
+    const int rc = gsim_db_search(db, queries, nq, k, cutoff, metric, alpha, beta, hits, counts, approx);
+    g_force_each = false;
+    return rc;
 }
 
 int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,

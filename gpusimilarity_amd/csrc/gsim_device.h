@@ -34,6 +34,7 @@ struct QueryState {
     uint32_t arrived;            // workgroups that have finished scanning and publishing (ticket)
     uint32_t sel_done;           // selector workgroups that have written their hits (ticket)
     uint32_t final_ready;        // small tables: the threshold of the end-of-scan checkpoint has been published
+    uint32_t pad1[2];
     // --- not reset per query: running totals for gsim_db_get_timing ---
     unsigned long long ncand_sum;
     unsigned long long nfinal_sum;
@@ -72,7 +73,7 @@ struct ScanArgs {
 // ---- single-launch path: scan + publish + select in ONE kernel (small and mid-size tables) ----
 constexpr uint32_t kFusedMaxK = 2048;       // largest k the single-launch path serves
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
-constexpr int kFusedSelectors = 128;        // last-arriving workgroups that run the select
+constexpr int kFusedSelectors = 256;        // last-arriving workgroups that run the select (all of them on a 256-CU grid)
 constexpr uint32_t kFusedPubCap = 1u << 16; // entries of the table-wide published-candidate list (16 B each)
 
 struct FusedArgs {
@@ -84,7 +85,8 @@ struct FusedArgs {
     uint32_t row_base;
     uint32_t* done_flag;  // NULL, or device-visible pinned host word that receives `epoch` when the block is complete
     uint32_t epoch;
-    uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 1 no polls, 2 no checkpoints, 4 no LDS histogram
+    uint32_t cached_loads;   // 1: default-policy table loads (tables that fit the Infinity Cache), 0: non-temporal
+    uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no checkpoints (no thresholds during the scan)
     unsigned long long* dbg; // NULL, or 8 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };
 

@@ -288,9 +288,11 @@ __device__ __forceinline__ void block_filter_flush(BlockFilter* sh, const ScanAr
     }
 }
 
-__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
+template <bool NTLOAD = true> __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
 {
-    return __builtin_nontemporal_load(p); // read once: keep it out of the caches' way
+    // read once: keep it out of the caches' way (+13 % on tables far larger than the caches); a table that fits
+    // the 256 MB Infinity Cache is better served by default-policy loads on repeated queries (NTLOAD = false)
+    return NTLOAD ? __builtin_nontemporal_load(p) : *p;
 }
 
 // LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads per lane per chunk.
@@ -353,7 +355,7 @@ __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q
 }
 
 // The streaming loop of one wavefront: chunks w, w + nwaves, ... of the table through filter f.
-template <int LPR, int U, typename Filter>
+template <int LPR, int U, typename Filter, bool NTLOAD = true>
 __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry& g, Filter& f, const u32x4& q, uint32_t w,
                                           int lane)
 {
@@ -371,7 +373,7 @@ __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry&
         {
             const u32x4* p = db + static_cast<u64>(w) * (CH * LPR) + lane;
 #pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
+            for (int j = 0; j < U; j++) nxt[j] = stream_load<NTLOAD>(p + j * 64);
         }
         for (u64 c = w;; c += g.nwaves) {
             u32x4 d[U];
@@ -381,7 +383,7 @@ __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry&
             const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last;
             const u32x4* p = db + cn * (CH * LPR) + lane;
 #pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
+            for (int j = 0; j < U; j++) nxt[j] = stream_load<NTLOAD>(p + j * 64);
             f.refresh(gt, lane);
             // The workgroup polls the table-wide threshold every 8th chunk while it moves fast
             // (first 64 chunks), then every 32nd, then every 128th; the waves take turns so that
@@ -407,7 +409,7 @@ __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry&
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const u64 row = row0 + static_cast<u64>(j * RPL + grp);
-            d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
+            d[j] = row < a.nrows ? stream_load<NTLOAD>(p + j * 64) : u32x4{0, 0, 0, 0};
         }
         f.refresh(f.load_gtau(), lane);
         reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
@@ -558,6 +560,11 @@ struct FusedSchedule {
     // AFTER the loop, over all rows, and the workgroups wait (bounded) for its threshold before
     // they publish: one more hop, ~1.7 k rows published instead of 10-20 k.
     __device__ __forceinline__ bool final_wait() const { return min_trips < 64; }
+    // (The XCDs do not stream at the same rate: their workgroups finish 5-10 % apart, which one is slow changes
+    // from run to run.  Handing out the table's last eighth dynamically -- units of workgroup-trips from a
+    // table-wide counter, fetched by the forwarder wave into an LDS ring -- was built and measured: the tail
+    // streamed at ~4.4 TB/s against 7.4 TB/s under the fixed assignment and the query got 5 % slower at 100 M rows,
+    // 15 % at 10 M, for every unit length / interleave / share tried.  DESIGN.md 7.)
 };
 
 // A streaming wave's view.  Its loop touches global memory only through the table loads: the
@@ -809,7 +816,7 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
         const uint32_t g = agent_load(&st->gtau);
         if (lane == 0 && g > __hip_atomic_load(&sh.tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.tau, g);
         if (final_wait && agent_load(&st->final_ready)) return;
-        // ~0.25 us naps for the first 30 us (a small table is over in 20), then ~1 us, later 16 of those per poll
+        // a poll every ~2 us at first, every ~5 us from the 64th on, every ~60 us from the 512th on
         const uint32_t naps = spins < 512u ? 1u : 16u;
         for (uint32_t i = 0; i < naps; i++) {
             if (!final_wait && __hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
@@ -823,13 +830,13 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
                     return;
                 }
             }
-            if (spins < 64u) __builtin_amdgcn_s_sleep(32);
-            else __builtin_amdgcn_s_sleep(127);
+            if (spins < 64u) __builtin_amdgcn_s_sleep(8); // (units of 64 clocks: ~0.2 us; a small table is over in 20-50 us)
+            else __builtin_amdgcn_s_sleep(127);                    // ~3.4 us
         }
     }
 }
 
-template <int LPR, int U>
+template <int LPR, int U, bool NTLOAD>
 __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeometry g, FusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
@@ -851,7 +858,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (tid < kFusedCheckpoints) sh.ck_cnt[tid] = 0;
     __syncthreads();
     FusedSchedule sched;
-    sched.init(static_cast<uint32_t>((a.nrows / (U * (64 / LPR))) / g.nwaves));
+    constexpr int CHR = U * (64 / LPR); // rows per chunk
+    const u64 nfull = a.nrows / CHR;    // full chunks
+    sched.init(static_cast<uint32_t>(nfull / g.nwaves));
     if (wv == kScanBlock / 64) {
         fused_forwarder(sh, st, fa, sched, lane);
         return;
@@ -883,7 +892,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.ck_j = 0;
     f.next_ck = f.M ? sched.trip(0) : 0xFFFFFFFFu;
     f.dbg = dbg;
-    scan_rows<LPR, U>(a, g, f, q, w, lane);
+    scan_rows<LPR, U, FusedFilter, NTLOAD>(a, g, f, q, w, lane);
     const bool final_wait = f.M != 0 && sched.final_wait();
     if (final_wait) { // the end-of-scan checkpoint: this wave's M-th best over all its rows
         f.write_summary(lane);
@@ -1063,6 +1072,14 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         hdr->count = redo ? 0u : (npub < a.k ? npub : a.k);
         hdr->flags = redo ? 2u : 0u;
         hdr->approx = a.cutoff > 0.0f ? __hip_atomic_load(&st->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nrows;
+        if (fa.done_flag) {
+            // the block is complete (every selector fenced its hits before its ticket): tell the host NOW, tidy up after
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(fa.done_flag, fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // re-zero the per-query state for the next launch (stream-ordered behind this one)
         st->ncand_sum += __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st->nfinal_sum += redo ? 0u : npub;
         st->queries += redo ? 0u : 1u;
@@ -1080,15 +1097,6 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         uint4* sm = reinterpret_cast<uint4*>(fa.summ);
         const uint32_t n16 = (g.nwaves + 3) / 4;
         for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0};
-    }
-    if (fa.done_flag) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(fa.done_flag, fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
     if (dbg && tid == 0) fa.dbg[static_cast<u64>(gridDim.x) * 24] = wall_clock64(); // the very end
 #undef GSIM_STAMP
@@ -1772,18 +1780,18 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int LPR, int U>
+template <int LPR, int U, bool NTLOAD>
 hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
 {
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
     static bool attr_done = false; // (the attribute is per function, not per device, on this runtime)
     if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel<LPR, U>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel<LPR, U, NTLOAD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(FusedShared)));
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((fused_kernel<LPR, U>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
+    hipLaunchKernelGGL((fused_kernel<LPR, U, NTLOAD>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
     return hipGetLastError();
 }
 
@@ -1808,8 +1816,9 @@ uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k)
 
 hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
 {
-#define GSIM_CASE(L) \
-    if (g.lanes_per_row == L && g.unroll == 8) return launch_fused_t<L, 8>(a, g, f, s);
+#define GSIM_CASE(L)                                                                          \
+    if (g.lanes_per_row == L && g.unroll == 8)                                                \
+        return f.cached_loads ? launch_fused_t<L, 8, false>(a, g, f, s) : launch_fused_t<L, 8, true>(a, g, f, s);
     GSIM_CASE(1)
     GSIM_CASE(2)
     GSIM_CASE(4)

@@ -164,6 +164,12 @@ int gsim_db_shard_count(const gsim_db* db);
 int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
                    float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
                    uint32_t* counts, uint64_t* approx);
+/* The same call with the queries answered strictly one after the other through the single-query path
+ * (FingerprintDB::search called nq times, as the reference's server does, gpusim.cpp:306-374): no table
+ * pass is shared.  For callers that measure or need per-query latency without crossing the ABI per query. */
+int gsim_db_search_each(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
+                        float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
+                        uint32_t* counts, uint64_t* approx);
 /* FingerprintDB::search_cpu      fingerprintdb_cuda.cpp:20-54: the reference's
  * explicit host path (TanimotoFunctorCPU on all host threads + the partial
  * bubble sort of :92-103).  Same outputs as gsim_db_search, but reference
