@@ -14,7 +14,7 @@ constexpr int kScanBins = 1024;
 // Largest finalist count the single-workgroup LDS select handles.
 constexpr int kSelectCap = 8192;
 constexpr int kScanBlock = 256; // 4 wavefronts
-constexpr int kFusedCheckpoints = 16; // single-launch path: threshold checkpoints (trip counts 1, 8, 64, ... and 3/4 of the trips)
+constexpr int kFusedCheckpoints = 16; // single-launch path: threshold checkpoints (trip counts 1, 4, 16, ... and 3/4 of the trips)
 
 // Device-resident per-query state, zeroed before every scan.
 // Device-resident per-query state.  Zero when a query starts: allocated zeroed,

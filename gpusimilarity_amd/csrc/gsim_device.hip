@@ -560,11 +560,13 @@ struct FusedSchedule {
     // AFTER the loop, over all rows, and the workgroups wait (bounded) for its threshold before
     // they publish: one more hop, ~1.7 k rows published instead of 10-20 k.
     __device__ __forceinline__ bool final_wait() const { return min_trips < 64; }
-    // (The XCDs do not stream at the same rate: their workgroups finish 5-10 % apart, which one is slow changes
-    // from run to run.  Handing out the table's last eighth dynamically -- units of workgroup-trips from a
-    // table-wide counter, fetched by the forwarder wave into an LDS ring -- was built and measured: the tail
-    // streamed at ~4.4 TB/s against 7.4 TB/s under the fixed assignment and the query got 5 % slower at 100 M rows,
-    // 15 % at 10 M, for every unit length / interleave / share tried.  DESIGN.md 7.)
+    // (The workgroups do not finish together: the classes blockIdx % 8 = {0,1,2,7} and {3,4,5,6} -- two halves of
+    // the chip -- end 3-4 % apart at 100 M rows, 10 % at 10 M, and WHICH half is the slow one changes from query to
+    // query: contention, not a property of an XCD.  Two remedies were built and measured, neither is kept:
+    // per-class shares of the table steered by the previous queries' times do not converge (the slow half flips);
+    // handing out the table's last eighth dynamically -- units of workgroup-trips from a table-wide counter, fetched
+    // by the forwarder wave into an LDS ring -- streamed that tail at ~4.4 TB/s against 7.4 TB/s under the fixed
+    // assignment and made the query 5 % slower at 100 M rows, 15 % at 10 M.  DESIGN.md 7.)
 };
 
 // A streaming wave's view.  Its loop touches global memory only through the table loads: the
