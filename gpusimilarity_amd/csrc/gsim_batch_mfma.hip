@@ -52,12 +52,13 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMWaves = 8;             // waves per workgroup = query tiles per pass
 constexpr int kMBlock = kMWaves * 64;  // threads
 constexpr int kMChunks = 4096;         // 16-byte chunks per LDS row block (64 KB, two buffers)
 constexpr int kMaxMT = 2;              // query tiles per wave (2 for 1024-bit rows: halves the operand work)
-constexpr int kMStage = 128;           // raw candidates staged per wave (processed in bulk above 64)
+constexpr int kMStage = 96;            // raw candidates staged per wave (processed in bulk above 32)
 
 // GSIM_MF_TIMING: per-phase cycle counters of wave 0 of every workgroup, summed into flags[2..]
 // (units of 64 cycles; printed by the host under GSIM_DEBUG_BATCH)
@@ -78,6 +79,7 @@ constexpr int kScaleM = 0x7E7E7E7E;  // 2^-1
 
 struct MfmaShared {
     u32x4 rows[2][kMChunks];
+    uint16_t rpop[2][kMChunks / 2]; // popc(row) of the block's rows, from the table's side array (2 chunks per row at least)
     // pre-filter constants in accumulator order: [query tile of the wave][lane half][acc register]
     float kap_a[kMWaves][kMaxMT][2][16];
     float kap_b[kMWaves][kMaxMT][2][16];
@@ -264,6 +266,8 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
     const uint32_t chunk0 = static_cast<uint32_t>(((lane & 15) % CPR) ^ (line0 % CPR));
     const u32x4* dbc = db + chunk0;
     const uint32_t last_row = static_cast<uint32_t>(a.nrows - 1);
+    const u32x4* rowpop16 = reinterpret_cast<const u32x4*>(a.rowpop);
+    const u64 last_pop_chunk = (a.nrows - 1) / 8;
     auto issue_block = [&](u64 blk, int buf) {
         const uint32_t first = static_cast<uint32_t>(blk) * RB + rowl0;
 #pragma unroll
@@ -272,6 +276,13 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
             grow = grow < last_row ? grow : last_row;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (dbc + static_cast<u64>(grow) * CPR),
                                              (__attribute__((address_space(3))) void*) (&sh.rows[buf][(j * WV + wq) * 64]), 16, 0, 0);
+        }
+        // the rows' popcounts: RB 16-bit counts = RB / 8 16-byte chunks, one per thread of the first waves
+        if (wq * 64 < RB / 8 && wq * 64 + lane < RB / 8) {
+            u64 pc = blk * (RB / 8) + static_cast<u64>(wq * 64 + lane);
+            pc = pc < last_pop_chunk ? pc : last_pop_chunk;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (rowpop16 + pc),
+                                             (__attribute__((address_space(3))) void*) (&sh.rpop[buf][wq * 64 * 8]), 16, 0, 0);
         }
     };
 
@@ -314,8 +325,8 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
                 for (int tt = 0; tt < NT; tt++) {
 #pragma unroll
                     for (int m = 0; m < MT; m++) acc[m][tt] = v16f{};
-                    pb[tt] = 0;
                     const int row = (t2 + tt) * 32 + i;
+                    pb[tt] = sh.rpop[buf][row];
                     const int line = row / RPLN;
                     lrow[tt] = &sh.rows[buf][line * 16 + (row % RPLN) * CPR];
                     xr[tt] = line % CPR;
@@ -326,10 +337,6 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
 #pragma unroll
                     for (int tt = 0; tt < NT; tt++) {
                         b[tt] = lrow[tt][(2 * g + h) ^ xr[tt]];
-                        pb[tt] = bcnt_acc(b[tt].x, pb[tt]);
-                        pb[tt] = bcnt_acc(b[tt].y, pb[tt]);
-                        pb[tt] = bcnt_acc(b[tt].z, pb[tt]);
-                        pb[tt] = bcnt_acc(b[tt].w, pb[tt]);
                     }
                     // the expanded row operand of a class is used by all MT query tiles
 #define GSIM_MFMA_CLASS(C)                                                                         \
@@ -363,7 +370,6 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
                 u64 rowi[NT];
 #pragma unroll
                 for (int tt = 0; tt < NT; tt++) {
-                    pb[tt] += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pb[tt]), 32, 64));
                     pbf[tt] = static_cast<float>(pb[tt]);
                     rowi[tt] = blk * RB + (t2 + tt) * 32 + i;
                     active[tt] = rowi[tt] < a.nrows;
@@ -383,11 +389,16 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
 #pragma unroll
                     for (int r4 = 0; r4 < 4; r4++) {
                         const f32x4 vu = kup[r4], vv = kvp[r4];
+                        // two pairs per instruction: v_pk_fma_f32 on the accumulator's register pairs, v_max3_f32
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 u2{vu[e], vu[e + 1]}, v2{vv[e], vv[e + 1]};
 #pragma unroll
-                            for (int tt = 0; tt < NT; tt++)
-                                mx[tt] = fmaxf(mx[tt], __builtin_fmaf(acc[m][tt][4 * r4 + e], vu[e], vv[e]));
+                            for (int tt = 0; tt < NT; tt++) {
+                                const f32x2 c2{acc[m][tt][4 * r4 + e], acc[m][tt][4 * r4 + e + 1]};
+                                const f32x2 t2v = __builtin_elementwise_fma(c2, u2, v2);
+                                mx[tt] = fmaxf(fmaxf(mx[tt], t2v.x), t2v.y);
+                            }
                         }
                     }
                     bool any = false;
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
                             stg_q[slot] = static_cast<uint32_t>(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h); // query of the wave
                         }
                         staged += static_cast<uint32_t>(__popcll(mp));
-                        if (staged > 64) {
+                        if (staged > kMStage - 64) {
                             MF_T(td0);
                             drain_stage();
                             MF_T(td1);
@@ -674,6 +685,29 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_sample_kernel(BatchArgs a,
 
 
 
+// popc(row) of every row as a 16-bit side array (2 bytes per row, computed once per table): the matrix-core pass
+// stages it with the rows instead of counting every row's bits again in each of its eight waves (one v_bcnt per
+// row word and wave: 1 of its ~9 vector instructions per MFMA).
+template <int CPR> __global__ __launch_bounds__(256) void row_popcount_kernel(const u32x4* __restrict__ rows, u64 nchunks, uint16_t* out)
+{
+    constexpr int UN = 4;
+    const u64 c0 = static_cast<u64>(blockIdx.x) * (256 * UN) + threadIdx.x;
+    u32x4 x[UN];
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+        const u64 c = c0 + j * 256;
+        x[j] = c < nchunks ? __builtin_nontemporal_load(rows + c) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < UN; j++) {
+        uint32_t p = bcnt_acc(x[j].x, bcnt_acc(x[j].y, bcnt_acc(x[j].z, bcnt_acc(x[j].w, 0u))));
+#pragma unroll
+        for (int d = 1; d < CPR; d <<= 1) p += static_cast<uint32_t>(__shfl_xor(static_cast<int>(p), d, 64));
+        const u64 c = c0 + j * 256;
+        if (c < nchunks && c % CPR == 0) out[c / CPR] = static_cast<uint16_t>(p);
+    }
+}
+
 // debug hook: the pre-filter constants as the device computes them, for qa = 0..max_qa and (no
 // cutoff) every threshold bin: out[(qa * nlev + lev) * 4 + {ka, kb, u, v}], nlev = 512 or 1
 __global__ __launch_bounds__(256) void prefilter_table_kernel(int tversky, float alpha, float beta, uint32_t max_qa, int has_cutoff,
@@ -717,6 +751,20 @@ void prefilter_table_host(int tversky, float alpha, float beta, uint32_t max_qa,
 namespace
 {
 } // namespace
+
+hipError_t launch_row_popcounts(const void* rows, uint64_t nrows, uint32_t W, uint16_t* d_out, hipStream_t s)
+{
+    if (!batch_mfma_supported(W)) return hipErrorInvalidValue;
+    const u64 nchunks = nrows * (W / 4);
+    if (nchunks == 0) return hipSuccess;
+    const dim3 grid(static_cast<uint32_t>((nchunks + 1023) / 1024)), block(256);
+    const u32x4* r = static_cast<const u32x4*>(rows);
+    if (W == 64) hipLaunchKernelGGL((row_popcount_kernel<16>), grid, block, 0, s, r, nchunks, d_out);
+    else if (W == 32) hipLaunchKernelGGL((row_popcount_kernel<8>), grid, block, 0, s, r, nchunks, d_out);
+    else if (W == 16) hipLaunchKernelGGL((row_popcount_kernel<4>), grid, block, 0, s, r, nchunks, d_out);
+    else hipLaunchKernelGGL((row_popcount_kernel<2>), grid, block, 0, s, r, nchunks, d_out);
+    return hipGetLastError();
+}
 
 bool batch_mfma_supported(uint32_t W)
 {

@@ -68,6 +68,8 @@ struct Shard {
     uint64_t nrows = 0;
     uint32_t W = 0;         // words per row ON THE DEVICE (table width / fold factor)
     void* d_rows = nullptr;
+    uint16_t* d_rowpop = nullptr; // popc(row) side array of the matrix-core batch pass (2 B per row, made on first use)
+    bool rowpop_valid = false;
     bool owns_rows = false;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr; // the stream in use (own or caller's)
@@ -169,6 +171,7 @@ int free_shard(Shard& s)
     (void) hipSetDevice(s.device);
     if (s.stream) (void) hipStreamSynchronize(s.stream);
     if (s.owns_rows && s.d_rows) (void) hipFree(s.d_rows);
+    if (s.d_rowpop) (void) hipFree(s.d_rowpop);
     if (s.d_query) (void) hipFree(s.d_query);
     if (s.d_state) (void) hipFree(s.d_state);
     if (s.d_cand) (void) hipFree(s.d_cand);
@@ -816,6 +819,14 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         (!(cutoff > 0.0f) || gsim::batch_mfma_sample_applies(s.W, s.nrows, nq, k, s.num_cus))) {
         a.q0 = 0;
         a.nq = nq;
+        // the rows' popcounts: once per table; borrowed rows (gsim_db_attach_device_rows) may have changed since the
+        // last call, so theirs are recounted every time (one more read of the table)
+        if (!s.d_rowpop) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_rowpop), gsim::row_popcount_bytes(s.nrows)));
+        if (!s.rowpop_valid || !s.owns_rows) {
+            GSIM_HIP(gsim::launch_row_popcounts(s.d_rows, s.nrows, s.W, s.d_rowpop, s.stream));
+            s.rowpop_valid = true;
+        }
+        a.rowpop = s.d_rowpop;
         GSIM_HIP(gsim::launch_batch_mfma_pass(a, s.bgeo, s.num_cus, sample, row_base, results,
                                               gsim_result_block_bytes(k), s.stream, bev ? bev[0] : nullptr,
                                               bev ? bev[1] : nullptr));

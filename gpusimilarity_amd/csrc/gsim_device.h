@@ -159,6 +159,7 @@ struct BatchArgs {
     const uint32_t* queries; // device, Q x W words
     const uint32_t* qpop;    // device, Q
     const BatchRare* rare;   // device copy of the rare arguments
+    const uint16_t* rowpop;  // matrix-core pass: popc(row) per row (launch_row_popcounts), padded to whole 16-byte chunks
     uint32_t W;
     uint32_t q0, nq;         // this pass: queries q0 .. q0+nq-1 (nq <= kBQ, matrix-core pass: kMfmaQueries)
     uint32_t k;
@@ -175,6 +176,9 @@ hipError_t launch_batch_pass(const BatchArgs& a, const BatchRare& rare_host, con
 // Matrix-core variant of the scan (gsim_batch_mfma.hip): up to kMfmaQueries queries per table pass.
 constexpr int kMfmaQueries = 256;
 bool batch_mfma_supported(uint32_t W);
+// the side array of row popcounts the matrix-core pass reads: nrows 16-bit counts (allocate row_popcount_bytes(nrows))
+hipError_t launch_row_popcounts(const void* rows, uint64_t nrows, uint32_t W, uint16_t* d_out, hipStream_t s);
+inline size_t row_popcount_bytes(uint64_t nrows) { return static_cast<size_t>((nrows + 7) / 8 + 1) * 16; }
 uint32_t batch_mfma_waves(int num_cus);
 hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s);
 bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err);

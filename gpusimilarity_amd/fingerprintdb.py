@@ -7,7 +7,6 @@ Strings (SMILES / IDs) live here, above the ABI; the ABI speaks row indices.
 """
 from __future__ import annotations
 
-import math
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -126,8 +125,3 @@ def top_results_bubble_sort(indices: List[int], scores: List[float], number_requ
             if scores[j] > scores[j - 1]:
                 indices[j], indices[j - 1] = indices[j - 1], indices[j]
                 scores[j], scores[j - 1] = scores[j - 1], scores[j]
-
-
-def result_candidates_for_fold(max_return_count: int, fold_factor: int) -> int:
-    """fingerprintdb_cuda.cu:284-287 (kept for the 'next' folding row)."""
-    return max_return_count * fold_factor * int(math.log2(2 * fold_factor))

@@ -587,6 +587,37 @@ def test_matrix_core_pass_matches_oracle(W, kind, n, nq):
     t.close()
 
 
+def test_matrix_core_pass_borrowed_rows_changed_between_batches():
+    """The matrix-core pass reads popc(row) from a side array made once per table; for rows the caller owns
+    (gsim_db_attach_device_rows) it is recounted on every call: rewrite the tensor in place between two batches
+    and both answers equal the oracle on the rows as they were at that call."""
+    import torch
+    n, W = 60_001, 32
+    db1 = O.synth_rows(0xB0220, 0, 0, n, W)
+    db2 = O.synth_rows(0xB0221, 1, 0, n, W)
+    ten = torch.from_numpy(db1.view(np.int32).copy()).to("cuda:0")
+    t = capi.Table(32 * W)
+    t.attach_device_rows(ten.data_ptr(), n, 0)
+    batch_check(t, db1, _mixed_queries(db1, 0, 96, W), 50, 0.0, ctx="borrowed, first")
+    ten.copy_(torch.from_numpy(db2.view(np.int32).copy()))
+    torch.cuda.synchronize()
+    batch_check(t, db2, _mixed_queries(db2, 1, 96, W), 50, 0.0, ctx="borrowed, rewritten")
+    t.close()
+
+
+@pytest.mark.parametrize("W,n,nq", [(8, 300_007, 256), (16, 120_001, 130), (8, 2_049, 64)])
+def test_matrix_core_pass_narrow_rows(W, n, nq):
+    """256- and 512-bit rows on the matrix cores (2048 and 1024 rows per LDS block: the popcount side array's
+    largest staging), ragged sizes."""
+    db = O.synth_rows(0x3FA5 + W + n, 0, 0, n, W)
+    t = make_table(db)
+    qs = _mixed_queries(db, 0, nq, W)
+    batch_check(t, db, qs, 100, 0.0, ctx="mfma narrow W=%d n=%d nq=%d" % (W, n, nq))
+    batch_check(t, db, qs[:64], 20, 0.0, ctx="mfma narrow tversky W=%d" % W, metric=capi.METRIC_TVERSKY,
+                alpha=np.float32(0.3), beta=np.float32(0.7))
+    t.close()
+
+
 def test_matrix_core_pass_tversky_weight_corners():
     """Weights for which the linear pre-filter is switched off or ill-conditioned (alpha = beta = 0,
     alpha + beta << 1) and asymmetric ones: the exact path decides, results equal the oracle."""
