@@ -1125,32 +1125,10 @@ struct SampleFilter {
     }
 };
 
-template <int LPR, int U>
-__global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t nsample, u64 stride_chunks)
+// The end of a sample kernel: the workgroup's histogram into the table-wide one; the last workgroup turns that into
+// tau0 and clears it.
+__device__ __forceinline__ void sample_publish(const ScanArgs& a, uint32_t* s_hist, uint32_t& s_last, int lane)
 {
-    __shared__ uint32_t s_hist[kScanBins];
-    __shared__ uint32_t s_last;
-    if (a.gate && *a.gate == 0) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
-    __syncthreads();
-    constexpr int CH = U * (64 / LPR);
-    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
-    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
-    SampleFilter f;
-    f.hist = s_hist;
-    f.cutoff = a.cutoff;
-    f.has_cutoff = a.cutoff > 0.0f;
-    const uint32_t nw = gridDim.x * (kScanBlock / 64);
-    for (uint32_t i = w; i < nsample; i += nw) {
-        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
-        const u32x4* p = db + c * (CH * LPR) + lane;
-        u32x4 d[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) d[j] = p[j * 64]; // plain loads: the scan re-reads these lines
-        reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
-    }
     __syncthreads();
     for (int i = threadIdx.x; i < kScanBins; i += kScanBlock)
         if (s_hist[i]) atomicAdd(&a.state->ghist[i], s_hist[i]);
@@ -1181,37 +1159,174 @@ __global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t
     for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) a.state->ghist[i] = 0;
 }
 
-// Any fingerprint width (W words, not a power-of-two number of 16-byte lanes):
-// one row per lane, word loop.  Correct for every W; not the tuned path.
-__global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, ScanGeometry g)
+template <int LPR, int U>
+__global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t nsample, u64 stride_chunks)
 {
-    __shared__ BlockFilter s_filter;
+    __shared__ uint32_t s_hist[kScanBins];
+    __shared__ uint32_t s_last;
     if (a.gate && *a.gate == 0) return;
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    block_filter_init(&s_filter, a.k, a.state->gtau);
-    const uint32_t* __restrict__ db = reinterpret_cast<const uint32_t*>(a.rows);
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
+    __syncthreads();
+    constexpr int CH = U * (64 / LPR);
+    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    SampleFilter f;
+    f.hist = s_hist;
+    f.cutoff = a.cutoff;
+    f.has_cutoff = a.cutoff > 0.0f;
+    const uint32_t nw = gridDim.x * (kScanBlock / 64);
+    for (uint32_t i = w; i < nsample; i += nw) {
+        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
+        const u32x4* p = db + c * (CH * LPR) + lane;
+        u32x4 d[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) d[j] = p[j * 64]; // plain loads: the scan re-reads these lines
+        reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
+    }
+    sample_publish(a, s_hist, s_last, lane);
+}
+
+// Any fingerprint width (W words, not a power-of-two number of 16-byte lanes).  The R rows of a wave's chunk
+// (ScanGeometry::chunk_rows: 64, fewer for very wide rows) are R W consecutive words, a multiple of 16 bytes at a
+// 16-byte boundary: the wave copies them verbatim into its LDS region with 16-byte global_load_lds (no registers, one
+// address computation per 16 bytes), then every lane reads back ITS row -- 16 bytes per read when the rows are
+// 16-byte multiples.  (One row per lane straight from global memory -- the reference's access pattern,
+// fingerprintdb_cuda.cu:98 -- touches 64 different 128-byte lines per load instruction: 0.18-0.32 of the HBM peak.)
+constexpr uint32_t kGenericLdsBytes = 96 * 1024; // dynamic LDS: the query + four wave regions
+
+__host__ __device__ inline uint32_t generic_query_words(uint32_t W) { return (W + 3u) & ~3u; }
+__host__ __device__ inline uint32_t generic_lds_bytes(uint32_t W, uint32_t R) { return (generic_query_words(W) + (kScanBlock / 64) * R * W) * 4u; }
+
+struct GenericChunk {
+    const uint32_t* db;
+    uint32_t* srow;       // this wave's LDS region: R x W words
+    const uint32_t* sq;   // the query in LDS
+    uint32_t W, R;
+    u64 total_words;
+
+    __device__ __forceinline__ void init(const ScanArgs& a, uint32_t R_, uint32_t* s_words, uint32_t wv)
+    {
+        db = reinterpret_cast<const uint32_t*>(a.rows);
+        W = a.W, R = R_;
+        sq = s_words;
+        srow = s_words + generic_query_words(W) + wv * R * W;
+        total_words = a.nrows * W;
+        for (uint32_t i = threadIdx.x; i < W; i += kScanBlock) s_words[i] = a.query[i]; // (a workgroup barrier follows in the caller)
+    }
+    // chunk c -> LDS; returns when it is there
+    __device__ __forceinline__ void load(u64 c, int lane) const
+    {
+        const uint32_t units = R * W / 4u; // 16-byte units per chunk
+        const u64 base = c * (static_cast<u64>(R) * W);
+        for (uint32_t u0 = 0; u0 < units; u0 += 64u) {
+            const uint32_t u = u0 + static_cast<uint32_t>(lane);
+            const u64 gi = base + 4ull * u;
+            if (u < units && gi + 4u <= total_words) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (db + gi),
+                                                 (__attribute__((address_space(3))) void*) (srow + 4u * u0), 16, 0, 0);
+            } else if (u < units) { // the table's last words (and what lies behind them in the last chunk)
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) srow[4u * u + t] = gi + t < total_words ? db[gi + t] : 0u;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the words are in LDS
+        __builtin_amdgcn_wave_barrier();
+    }
+    // popc(row & query), popc(row) of this lane's row of the chunk in LDS
+    __device__ __forceinline__ void count(int lane, uint32_t& cc, uint32_t& bb) const
+    {
+        const uint32_t* mine = srow + (static_cast<uint32_t>(lane) < R ? static_cast<uint32_t>(lane) : 0u) * W;
+        cc = 0, bb = 0;
+        if (W % 4u == 0) { // rows are 16-byte multiples: ds_read_b128
+            const u32x4* m4 = reinterpret_cast<const u32x4*>(mine);
+            const u32x4* q4 = reinterpret_cast<const u32x4*>(sq);
+            for (uint32_t j = 0; j < W / 4u; j++) {
+                const u32x4 x = m4[j], q = q4[j];
+                cc = bcnt_acc(x.x & q.x, bcnt_acc(x.y & q.y, bcnt_acc(x.z & q.z, bcnt_acc(x.w & q.w, cc))));
+                bb = bcnt_acc(x.x, bcnt_acc(x.y, bcnt_acc(x.z, bcnt_acc(x.w, bb))));
+            }
+        } else {
+            uint32_t j = 0;
+            for (; j + 4 <= W; j += 4) {
+                uint32_t xr[4], qr[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    xr[u] = mine[j + u];
+                    qr[u] = sq[j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    cc = bcnt_acc(xr[u] & qr[u], cc);
+                    bb = bcnt_acc(xr[u], bb);
+                }
+            }
+            for (; j < W; j++) {
+                const uint32_t xr = mine[j];
+                cc = bcnt_acc(xr & sq[j], cc);
+                bb = bcnt_acc(xr, bb);
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); // the next chunk's words overwrite the region
+    }
+};
+
+__global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, ScanGeometry g)
+{
+    __shared__ BlockFilter s_filter;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[]; // [query, padded to 4 words][4 waves x R rows x W words]
+    if (a.gate && *a.gate == 0) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t w = blockIdx.x * (kScanBlock / 64) + wv;
+    GenericChunk ch;
+    ch.init(a, g.chunk_rows, s_words, wv);
+    block_filter_init(&s_filter, a.k, a.state->gtau); // (ends with a workgroup barrier: the query is in place)
     WaveFilter f;
     f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
            a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
     for (u64 c = w; c < g.nchunks; c += g.nwaves) {
-        const u64 row = c * 64 + lane;
-        const bool active = row < a.nrows;
-        uint32_t cc = 0, bb = 0;
-        if (active) {
-            const uint32_t* r = db + row * a.W;
-            for (uint32_t i = 0; i < a.W; i++) {
-                const uint32_t x = r[i];
-                cc += __popc(x & a.query[i]);
-                bb += __popc(x);
-            }
-        }
+        ch.load(c, lane);
+        uint32_t cc, bb;
+        ch.count(lane, cc, bb);
+        const u64 row = c * ch.R + lane;
+        const bool active = static_cast<uint32_t>(lane) < ch.R && row < a.nrows;
         f.refresh((c / g.nwaves) % 8 == 0 ? f.load_gtau() : 0u, lane);
         const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc);
         f.offer(active, static_cast<uint32_t>(row), s, (cc << 16) + bb, lane);
     }
     f.finish(w, a, lane);
     block_filter_flush(&s_filter, a);
+}
+
+// K0 for the generic widths: as sample_kernel, chunks through GenericChunk
+__global__ __launch_bounds__(kScanBlock) void sample_generic_kernel(ScanArgs a, uint32_t R, uint32_t nsample, u64 stride_chunks)
+{
+    __shared__ uint32_t s_hist[kScanBins];
+    __shared__ uint32_t s_last;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];
+    if (a.gate && *a.gate == 0) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t w = blockIdx.x * (kScanBlock / 64) + wv;
+    GenericChunk ch;
+    ch.init(a, R, s_words, wv);
+    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
+    __syncthreads();
+    SampleFilter f;
+    f.hist = s_hist;
+    f.cutoff = a.cutoff;
+    f.has_cutoff = a.cutoff > 0.0f;
+    const uint32_t nw = gridDim.x * (kScanBlock / 64);
+    for (uint32_t i = w; i < nsample; i += nw) {
+        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
+        ch.load(c, lane);
+        uint32_t cc, bb;
+        ch.count(lane, cc, bb);
+        f.offer(static_cast<uint32_t>(lane) < R, 0u, score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc), 0u, lane);
+    }
+    sample_publish(a, s_hist, s_last, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1708,8 +1823,14 @@ ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_pe
         g.unroll = static_cast<uint32_t>(unroll);
         g.chunk_rows = g.unroll * (64 / lpr);
     } else {
+        // generic widths: the four waves' chunks live in LDS (scan_generic_kernel), fewer rows per chunk when they are wide
         g.unroll = 1;
         g.chunk_rows = 64;
+        while (g.chunk_rows > 4 && generic_lds_bytes(W, g.chunk_rows) > kGenericLdsBytes) g.chunk_rows /= 2;
+        // a wave has one chunk in flight and computes between loads: as many workgroups per CU as the LDS holds (up to four)
+        const uint32_t lds = generic_lds_bytes(W, g.chunk_rows) + static_cast<uint32_t>(sizeof(BlockFilter));
+        const int per_cu = std::max(1, std::min(4, static_cast<int>(150u * 1024u / lds)));
+        waves_per_cu = std::max(waves_per_cu, per_cu * (kScanBlock / 64));
     }
     g.nchunks = (nrows + g.chunk_rows - 1) / g.chunk_rows;
     uint64_t nw = static_cast<uint64_t>(num_cus) * static_cast<uint64_t>(waves_per_cu);
@@ -1730,10 +1851,10 @@ hipError_t launch_sample_t(const ScanArgs& a, uint32_t nsample, uint64_t stride,
     return hipGetLastError();
 }
 
-// Starting threshold from a strided sample (specialised widths, large tables only).
+// Starting threshold from a strided sample (large tables only).
 hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s)
 {
-    if (g.lanes_per_row == 0 || a.k == 0 || chunks_per_wave == 0) return hipSuccess;
+    if (a.k == 0 || chunks_per_wave == 0) return hipSuccess;
     const uint64_t nfull = a.nrows / g.chunk_rows;
     // never sample more than 1/8 of the table; under one chunk per wave the scan's own warm-up is cheaper
     const uint64_t fit = nfull / (8ull * g.nwaves);
@@ -1743,6 +1864,19 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     const uint64_t stride = nfull / want;
     const uint32_t nsample = static_cast<uint32_t>(want);
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    if (g.lanes_per_row == 0) {
+        const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
+        static bool attr_done = false;
+        if (!attr_done) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_generic_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGenericLdsBytes));
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(sample_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g.chunk_rows, nsample, stride);
+        return hipGetLastError();
+    }
 #define GSIM_CASE(L, UU) \
     if (g.lanes_per_row == L && g.unroll == UU) return launch_sample_t<L, UU>(a, nsample, stride, nblocks, s);
     GSIM_CASE(8, 8)
@@ -1778,7 +1912,16 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
 #undef GSIM_CASE
     if (g.lanes_per_row != 0) return hipErrorInvalidValue;
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    hipLaunchKernelGGL(scan_generic_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    static bool attr_done = false;
+    if (!attr_done) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_generic_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGenericLdsBytes));
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
+    if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scan_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g);
     return hipGetLastError();
 }
 

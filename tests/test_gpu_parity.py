@@ -207,6 +207,22 @@ def test_seeded_tables_match_oracle(n, W, kind):
     t.close()
 
 
+@pytest.mark.parametrize("n,W", [(300_001, 28), (200_003, 6), (150_000, 48), (100_001, 12), (64, 3), (65, 7),
+                                 (40_000, 100), (9_001, 200), (3_000, 511), (1_000, 1023), (500_000, 2)])
+def test_generic_widths_match_oracle(n, W):
+    """Widths that are not a power-of-two number of 16-byte lanes take scan_generic_kernel (coalesced loads, rows
+    transposed through LDS): even and odd row strides, rows wider than a 64-row LDS region holds (32 ... 4 rows per
+    chunk), ragged last chunks, the Tversky metric."""
+    db = O.synth_rows(0x6E6E + W, n % 2, 0, n, W)
+    t = make_table(db)
+    q = db[O.query_row(1, n)]
+    for k, cutoff in ((1000, 0.0), (7, 0.0), (50, 0.2)):
+        check_against_oracle(t, db, q, k, cutoff, ctx="generic n=%d W=%d k=%d c=%g" % (n, W, k, cutoff))
+    check_against_oracle(t, db, O.synth_rows(0x5EED0003, 0, 5, 1, W)[0], 100, 0.0, ctx="generic tversky W=%d" % W,
+                         metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    t.close()
+
+
 def test_ragged_and_edge_sizes():
     W = 32
     for n in (1, 7, 63, 64, 65, 511, 513, 4095, 4097):
