@@ -399,8 +399,6 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
         if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
         f.dbg = s.d_dbg;
-        static const long long cached_bytes = std::getenv("GSIM_FUSED_CACHED_BYTES") ? std::atoll(std::getenv("GSIM_FUSED_CACHED_BYTES")) : 0;
-        f.cached_loads = static_cast<uint64_t>(s.nrows) * s.W * 4 <= static_cast<uint64_t>(cached_bytes) ? 1u : 0u;
         static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
         f.xflags = static_cast<uint32_t>(xflags);
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));

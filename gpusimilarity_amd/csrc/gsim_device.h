@@ -85,7 +85,6 @@ struct FusedArgs {
     uint32_t row_base;
     uint32_t* done_flag;  // NULL, or device-visible pinned host word that receives `epoch` when the block is complete
     uint32_t epoch;
-    uint32_t cached_loads;   // 1: default-policy table loads (tables that fit the Infinity Cache), 0: non-temporal
     uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no checkpoints (no thresholds during the scan)
     unsigned long long* dbg; // NULL, or 8 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };

@@ -288,11 +288,11 @@ __device__ __forceinline__ void block_filter_flush(BlockFilter* sh, const ScanAr
     }
 }
 
-template <bool NTLOAD = true> __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
 {
-    // read once: keep it out of the caches' way (+13 % on tables far larger than the caches); a table that fits
-    // the 256 MB Infinity Cache is better served by default-policy loads on repeated queries (NTLOAD = false)
-    return NTLOAD ? __builtin_nontemporal_load(p) : *p;
+    // read once: keep it out of the caches' way (+13 % on tables far larger than the caches; default-policy loads
+    // for tables that fit the 256 MB Infinity Cache were tried on repeated queries over 1 M rows: no gain)
+    return __builtin_nontemporal_load(p);
 }
 
 // LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads per lane per chunk.
@@ -355,7 +355,7 @@ __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q
 }
 
 // The streaming loop of one wavefront: chunks w, w + nwaves, ... of the table through filter f.
-template <int LPR, int U, typename Filter, bool NTLOAD = true>
+template <int LPR, int U, typename Filter>
 __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry& g, Filter& f, const u32x4& q, uint32_t w,
                                           int lane)
 {
@@ -373,7 +373,7 @@ __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry&
         {
             const u32x4* p = db + static_cast<u64>(w) * (CH * LPR) + lane;
 #pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = stream_load<NTLOAD>(p + j * 64);
+            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
         }
         for (u64 c = w;; c += g.nwaves) {
             u32x4 d[U];
@@ -383,7 +383,7 @@ __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry&
             const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last;
             const u32x4* p = db + cn * (CH * LPR) + lane;
 #pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = stream_load<NTLOAD>(p + j * 64);
+            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
             f.refresh(gt, lane);
             // The workgroup polls the table-wide threshold every 8th chunk while it moves fast
             // (first 64 chunks), then every 32nd, then every 128th; the waves take turns so that
@@ -409,7 +409,7 @@ __device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry&
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const u64 row = row0 + static_cast<u64>(j * RPL + grp);
-            d[j] = row < a.nrows ? stream_load<NTLOAD>(p + j * 64) : u32x4{0, 0, 0, 0};
+            d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
         }
         f.refresh(f.load_gtau(), lane);
         reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
@@ -838,7 +838,7 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
     }
 }
 
-template <int LPR, int U, bool NTLOAD>
+template <int LPR, int U>
 __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeometry g, FusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.ck_j = 0;
     f.next_ck = f.M ? sched.trip(0) : 0xFFFFFFFFu;
     f.dbg = dbg;
-    scan_rows<LPR, U, FusedFilter, NTLOAD>(a, g, f, q, w, lane);
+    scan_rows<LPR, U>(a, g, f, q, w, lane);
     const bool final_wait = f.M != 0 && sched.final_wait();
     if (final_wait) { // the end-of-scan checkpoint: this wave's M-th best over all its rows
         f.write_summary(lane);
@@ -1925,18 +1925,18 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
     return hipGetLastError();
 }
 
-template <int LPR, int U, bool NTLOAD>
+template <int LPR, int U>
 hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
 {
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
     static bool attr_done = false; // (the attribute is per function, not per device, on this runtime)
     if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel<LPR, U, NTLOAD>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel<LPR, U>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(FusedShared)));
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((fused_kernel<LPR, U, NTLOAD>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
+    hipLaunchKernelGGL((fused_kernel<LPR, U>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
     return hipGetLastError();
 }
 
@@ -1961,9 +1961,9 @@ uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k)
 
 hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
 {
-#define GSIM_CASE(L)                                                                          \
-    if (g.lanes_per_row == L && g.unroll == 8)                                                \
-        return f.cached_loads ? launch_fused_t<L, 8, false>(a, g, f, s) : launch_fused_t<L, 8, true>(a, g, f, s);
+#define GSIM_CASE(L) \
+    if (g.lanes_per_row == L && g.unroll == 8) \
+        return launch_fused_t<L, 8>(a, g, f, s);
     GSIM_CASE(1)
     GSIM_CASE(2)
     GSIM_CASE(4)
