@@ -91,6 +91,9 @@ struct Shard {
     uint32_t* h_done = nullptr; // single-launch path: pinned word the kernel stores the query's epoch into
     uint32_t epoch = 0;
     bool last_fused = false;    // the last synchronous enqueue went through the single-launch path
+    // Tables whose scores tie heavily (narrow or very sparse fingerprints) make the single-launch path hand every
+    // query back, i.e. scan twice: after consecutive hand-backs the synchronous path skips it for 2, 4, ... 64 queries.
+    uint32_t redo_streak = 0, fused_skip = 0;
     unsigned long long* d_dbg = nullptr; // GSIM_FUSED_DEBUG: per-workgroup phase timestamps
     void* d_result = nullptr;
     size_t result_bytes = 0;
@@ -336,7 +339,11 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
         s.state_dirty = false;
     }
-    const bool fused = mode == kAuto && fused_applies(s, k);
+    bool fused = mode == kAuto && fused_applies(s, k);
+    if (fused && caller_syncs && s.fused_skip) {
+        s.fused_skip--;
+        fused = false;
+    }
     const bool classic = !fused || !caller_syncs;
     if (classic) {
         const int rc = ensure_classic_scratch(s);
@@ -583,7 +590,14 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         }
         (void) hipMemset(s.d_dbg, 0, t.size() * 8);
     }
-    if (done && !(h->flags & 2u)) return GSIM_OK;
+    if (done && !(h->flags & 2u)) {
+        s.redo_streak = 0;
+        return GSIM_OK;
+    }
+    if (done) {
+        s.redo_streak = s.redo_streak < 6 ? s.redo_streak + 1 : 6;
+        if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
+    }
     if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
     int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic);

@@ -97,6 +97,24 @@ def test_queries_the_path_cannot_hold_are_handed_back_and_stay_exact():
     t.close()
 
 
+def test_repeated_hand_backs_switch_the_single_launch_off_for_a_while():
+    """A table that ties on every query (duplicates of four fingerprints) would be scanned twice per query: after two
+    consecutive hand-backs the synchronous path goes straight to the four-kernel pipeline for 4, 8, ... 64 queries
+    and probes again afterwards.  Results stay exact throughout; a query the path can hold resets the streak."""
+    W = 32
+    base = O.synth_rows(0x71E9, 0, 0, 4, W)
+    tied = np.ascontiguousarray(base[np.random.default_rng(12).integers(0, 4, size=300_000)])
+    t = make_table(tied)
+    t.enable_timing(True)
+    for i in range(12):
+        check(t, tied, base[i % 4], 100, 0.0, "ties, query %d" % i)
+    tm = t.timing()
+    # queries 0, 1 handed back; 2..5 skipped (4); 6 probes and is handed back; 7..11 skipped (8 pending)
+    assert tm["handed_back"] == 3, tm
+    assert tm["queries"] == 12 + 3, tm
+    t.close()
+
+
 def test_enqueue_only_path_falls_back_on_the_device():
     """gsim_db_search_device cannot look at the result on the host: the four classic kernels are enqueued
     behind the single launch, gated on its hand-back flag.  Ties -> they run; random rows -> they return
