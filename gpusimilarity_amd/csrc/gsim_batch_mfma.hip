@@ -29,9 +29,12 @@
 // of the other scans (per-query histogram + threshold, monotone updates), kept in global
 // memory here because emissions are rare after the sample pass.
 //
-// Measured: 125 M x 2048-bit x 256 queries in 24 ms on one MI355X, MFMA
-// pipe 55 % busy; what limits it is the VALU work in the MFMA shadow (about 9 instructions per
-// MFMA, of which ~4 overlap), not HBM (1.3 TB/s) and not LDS (no bank conflicts).
+// popc(row) comes from a 2 B/row side array (row_popcount_kernel) staged with the row block.
+//
+// Measured: 125 M x 2048-bit x 256 queries in 22 ms on one MI355X = 0.60 of
+// the dense FP4 peak, MFMA pipe ~60 % busy; what limits it is the VALU work in the MFMA shadow
+// (7.6 instructions per MFMA) and the stalls of the epilogue, not HBM (1.4 TB/s) and not LDS
+// (no bank conflicts); the kernel has no registers left (256, 2048-bit rows) to restructure either.
 #include "gsim_device.h"
 
 #include <hip/hip_runtime.h>
