@@ -403,7 +403,8 @@ def main():
     collective = {"backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend), "world": dist.get_world_size() if dist.is_initialized() else 1,
                   "ranks": members, "launcher": "self-spawned" if os.environ.get("GSIM_BENCH_SPAWNED") else
                   ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "WORLD_SIZE" in os.environ else "single process"),
-                  "data_path_collective": "one all_gather_into_tensor of the per-rank result blocks per step" if world > 1 else None}
+                  "data_path_collective": ("one all_gather_into_tensor of the per-rank result blocks per query (batch mode: per batch), "
+                                           "%d B per rank" % capi.result_block_bytes(k)) if world > 1 else None}
     if share:
         collective["shared_gpu_test_mode"] = True
 
