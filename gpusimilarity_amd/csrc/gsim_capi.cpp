@@ -406,6 +406,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
         if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
         f.dbg = s.d_dbg;
+        // grid-wide waits give up after 2 ms + four scan times at 4 TB/s (only reached when the GPU is shared)
+        f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
         static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
         f.xflags = static_cast<uint32_t>(xflags);
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));

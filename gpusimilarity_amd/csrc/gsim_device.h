@@ -85,6 +85,7 @@ struct FusedArgs {
     uint32_t row_base;
     uint32_t* done_flag;  // NULL, or device-visible pinned host word that receives `epoch` when the block is complete
     uint32_t epoch;
+    uint32_t wait_ticks;     // bound of the grid-wide waits (100 MHz ticks): a few scan times, see fused_kernel
     uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no checkpoints (no thresholds during the scan)
     unsigned long long* dbg; // NULL, or 8 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };

@@ -911,7 +911,11 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     // ---- 3. publish this workgroup's survivors ----------------------------------------------
     if (final_wait) {
         if (wv == 0 && lane == 0) {
-            for (uint32_t spins = 0; agent_load(&st->final_ready) == 0 && spins < (1u << 16); spins++) __builtin_amdgcn_s_sleep(8);
+            const unsigned long long t_wait = wall_clock64(); // (bounded as the selectors' wait below)
+            for (uint32_t spins = 0; agent_load(&st->final_ready) == 0; spins++) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((spins & 63u) == 63u && wall_clock64() - t_wait > fa.wait_ticks) break;
+            }
         }
         __syncthreads(); // (released once the service waves have exited too)
     }
@@ -962,9 +966,14 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t r = ticket - (nwg - nsel);
     if (tid == 0) {
         uint32_t ok = 1;
+        // On a GPU this kernel has to itself the wait is the spread of the streaming end times.  When another queue
+        // holds part of the CUs, workgroups of this grid may not have started yet and will not while the waiters keep
+        // theirs: after fa.wait_ticks (a few scan times) without the last arrival the query goes to the classic
+        // kernels, which never wait.
+        const unsigned long long t_wait = wall_clock64();
         for (uint32_t spins = 0; agent_load(&st->arrived) < nwg; spins++) {
             __builtin_amdgcn_s_sleep(2);
-            if (spins > (1u << 24)) { // a workgroup never arrived (seconds): give the query to the classic kernels
+            if ((spins & 255u) == 255u && wall_clock64() - t_wait > fa.wait_ticks) {
                 ok = 0;
                 atomicOr(&st->redo, 1u);
                 break;
