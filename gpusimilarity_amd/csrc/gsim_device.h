@@ -71,7 +71,7 @@ struct ScanArgs {
 };
 
 // ---- single-launch path: scan + publish + select in ONE kernel (small and mid-size tables) ----
-constexpr uint32_t kFusedMaxK = 2048;       // largest k the single-launch path serves
+constexpr uint32_t kFusedMaxK = 4096;       // largest k the single-launch path serves
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
 constexpr int kFusedSelectors = 256;        // last-arriving workgroups that run the select (all of them on a 256-CU grid)
 constexpr uint32_t kFusedPubCap = 1u << 16; // entries of the table-wide published-candidate list (16 B each)

@@ -474,7 +474,7 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
 // Whatever the path cannot hold (a store that stays full after compaction, more published
 // rows than a selector's LDS takes: heavy ties, rows in ascending score order) sets
 // QueryState::redo and header flag 2; the four-kernel pipeline then runs the query.
-constexpr int kFusedPubLds = 8192;   // published rows a selector ranks (LDS)
+constexpr int kFusedPubLds = 16384;  // published rows a selector ranks (LDS)
 constexpr int kFusedMineCap = 2048;  // ... of which it owns at most this many
 constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder/elector, poller)
 

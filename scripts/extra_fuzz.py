@@ -25,4 +25,12 @@ for seed in range(100, 130):
         print("FUZZ FAIL seed", seed, str(e)[:300])
     if time.time() - t0 > 1000:
         print("stopped at seed", seed); break
+for seed in range(100, 130):
+    try:
+        F.test_fuzz_generic_widths_against_oracle(seed)
+    except AssertionError as e:
+        bad += 1
+        print("GENERIC FAIL seed", seed, str(e)[:300])
+    if time.time() - t0 > 1500:
+        print("stopped at seed", seed); break
 print("extra fuzz done, failures:", bad, "elapsed", round(time.time() - t0))

@@ -36,7 +36,7 @@ def test_single_launch_path_is_taken_and_exact(n, W):
     nq = 0
     for qi in range(3):
         q = db[O.query_row(qi, n)]
-        for k in (1, 10, 1000, 2048):
+        for k in (1, 10, 1000, 2048, 4096):
             check(t, db, q, k, 0.0, "n=%d W=%d k=%d" % (n, W, k))
             nq += 1
         check(t, db, q, 100, 0.05, "cutoff")
@@ -49,7 +49,7 @@ def test_single_launch_path_is_taken_and_exact(n, W):
     nq += 2
     tm = t.timing()
     # the all-zero query scores 0 against every row: a table-wide tie, handed back unless the whole table fits a selector
-    expect_back = 1 if n > 8192 else 0
+    expect_back = 1 if n > 16384 else 0
     if W >= 32:
         assert tm["handed_back"] == expect_back, tm
     # (sparse 128/256-bit fingerprints have a dozen bits set: their scores are a handful of small fractions and

@@ -87,3 +87,36 @@ def test_fuzz_large_batches_against_oracle(seed):
             assert int(approx[i]) == wap, ctx
             assert hits_equal(hits[i], want), ctx
         t.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_generic_widths_against_oracle(seed):
+    """Widths that are not a power-of-two number of 16-byte lanes (scan_generic_kernel: rows transposed through LDS,
+    sample pass on large tables), single queries and small multi-query calls."""
+    rng = np.random.default_rng(0x6E2 + seed)
+    sizes = [1, 3, 63, 64, 65, 255, 257, 4095, 4097, 65537, 262144 + 7, 2_100_001]
+    for case in range(14):
+        W = int(rng.choice([2, 5, 6, 7, 9, 12, 20, 24, 28, 48, 100, 130]))
+        n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(1, 200_000))
+        if W >= 48:
+            n = min(n, 150_000)
+        style = str(rng.choice(["sparse", "dense", "ties"]))
+        db = random_table(rng, n, W, style)
+        t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
+        for _ in range(3):
+            k = int(rng.choice([0, 1, 7, 100, 1000, 3000, n, n + 3]))
+            cutoff = float(rng.choice([0.0, 0.0, -0.5, 0.05, 0.3, 1.0]))
+            metric = int(rng.choice([0, 0, 1]))
+            al, be = (np.float32(rng.choice([0.0, 0.3, 1.0])), np.float32(rng.choice([0.0, 0.7, 1.0])))
+            nq = int(rng.choice([1, 1, 2, 6]))
+            qs = np.stack([db[rng.integers(0, n)] if rng.random() < 0.7 else
+                           O.synth_rows(int(rng.integers(1, 2**31)), int(rng.integers(0, 2)), 0, 1, W)[0] for _ in range(nq)])
+            kw = dict(metric=metric, alpha=al, beta=be) if metric else {}
+            hits, approx = t.search(qs, k, np.float32(cutoff), **kw)
+            for i in range(nq):
+                want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=4, **kw)
+                ctx = "generic seed=%d case=%d W=%d n=%d style=%s k=%d cutoff=%g metric=%d nq=%d q=%d" % (
+                    seed, case, W, n, style, k, cutoff, metric, nq, i)
+                assert int(approx[i]) == wap, ctx
+                assert hits_equal(hits[i], want), ctx
+        t.close()
