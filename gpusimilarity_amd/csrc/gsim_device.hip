@@ -450,26 +450,30 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
 //      threshold in its own LDS store (kFusedWaveCap slots; compacted in place when the
 //      threshold has risen).  The threshold is an exact 32-bit score key (order_key), 0 at
 //      the start: until the first one arrives every row is stored -- LDS writes only;
-//   2. checkpoints (after 1, 4, 16, ... trips and after 3/4 of them): every wave writes the
-//      M best score keys it holds to its slot of a small table-wide array (plain
-//      write-through stores, no waiting); the last wave of a workgroup takes a ticket, the
-//      last workgroup reads all nwaves x M keys and publishes the k-th largest as the new
-//      threshold.  Valid because every key is a distinct row really scanned: at least k rows
-//      score at or above it, so no top-k row is below it -- and a slot read early or stale
-//      only holds smaller keys, which only lowers the threshold;
+//   2. checkpoints (after 1, 4, 16, ... trips and after 3/4 of them; small tables: one more after
+//      the loop, which the workgroups wait for, bounded, before they publish): every streaming wave
+//      leaves ONE score key in LDS, its M-th best (M ~ 2k / #waves); the workgroup's forwarder wave
+//      copies the four keys to a table-wide array (plain write-through stores) and takes a two-level
+//      ticket; the last arriver's poller wave elects the r-th largest report, r = ceil(k / M), and
+//      publishes it as the new threshold (atomicMax).  Valid because each of the r largest reports
+//      stands for M distinct rows really scanned at or above it: at least k rows score at or above
+//      the threshold, so no top-k row is below it -- and a slot read early or stale only holds a
+//      smaller key, which only lowers the threshold.  The streaming waves never touch global memory
+//      for any of this (one in-order vmcnt: a store or atomic would drain their prefetch);
 //   3. a workgroup that has finished filters its stores against the freshest threshold,
 //      appends the survivors to the table-wide published list (one reservation atomic,
 //      16-byte write-through stores) and takes an arrival ticket.  All but the last
-//      kFusedSelectors arrivers exit at once;
-//   4. the last kFusedSelectors arrivers wait (bounded spin; they are the only waiters, so the
-//      grid needs no co-residency guarantee) until every workgroup has arrived, load the
-//      published list (a few thousand rows) into LDS and each ranks the rows it owns (hash of
-//      the row) by counting larger keys -- the output slot of a hit is its rank, keys are
-//      unique -- writing the hits of rank < k straight into the result block;
-//   5. the last selector writes the header, re-zeroes the per-query state and, for the
-//      synchronous API, stores the query's epoch into a pinned host word the caller polls: the
-//      hits (in pinned host memory) are complete when it changes, without waiting for the
-//      kernel's end-of-launch bookkeeping.
+//      kFusedSelectors arrivers exit at once (on a 256-CU grid all of them are selectors);
+//   4. the selectors wait until every workgroup has arrived (bounded by a few scan times of wall
+//      clock: on a GPU shared with another queue part of the grid may not have started while the
+//      waiters hold their CUs -- the query then goes to the four-kernel pipeline, which never
+//      waits), load the published list (a few thousand rows) into LDS and each ranks the rows it
+//      owns (hash of the row) by counting larger keys -- the output slot of a hit is its rank, keys
+//      are unique -- writing the hits of rank < k straight into the result block;
+//   5. the last selector writes the header and, for the synchronous API, stores the query's epoch
+//      into a pinned host word the caller polls -- the hits (in pinned host memory) are complete
+//      when it changes, without waiting for the kernel's end-of-launch bookkeeping -- and then
+//      re-zeroes the per-query state.
 //
 // Whatever the path cannot hold (a store that stays full after compaction, more published
 // rows than a selector's LDS takes: heavy ties, rows in ascending score order) sets
