@@ -959,15 +959,24 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries are out
     __syncthreads();
-    if (tid == 0) sh.ticket = atomicAdd(&st->arrived, 1u);
-    __syncthreads();
-    GSIM_STAMP(3);
-    const uint32_t ticket = sh.ticket;
     const uint32_t nsel = nwg < static_cast<uint32_t>(kFusedSelectors) ? nwg : static_cast<uint32_t>(kFusedSelectors);
-    if (ticket + nsel < nwg) return; // not one of the last arrivers
+    uint32_t r; // this workgroup's selector number
+    if (nsel == nwg) {
+        // every workgroup selects (any grid of up to kFusedSelectors workgroups, i.e. always on 256 CUs): the
+        // arrival needs no ticket, only the count -- an atomic nobody waits for
+        if (tid == 0) __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r = blockIdx.x;
+        GSIM_STAMP(3);
+    } else {
+        if (tid == 0) sh.ticket = atomicAdd(&st->arrived, 1u);
+        __syncthreads();
+        GSIM_STAMP(3);
+        const uint32_t ticket = sh.ticket;
+        if (ticket + nsel < nwg) return; // not one of the last arrivers
+        r = ticket - (nwg - nsel);
+    }
 
     // ---- 4. select (the last nsel arrivers) -------------------------------------------------
-    const uint32_t r = ticket - (nwg - nsel);
     if (tid == 0) {
         uint32_t ok = 1;
         // On a GPU this kernel has to itself the wait is the spread of the streaming end times.  When another queue
