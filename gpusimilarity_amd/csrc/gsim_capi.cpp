@@ -60,6 +60,7 @@ constexpr int kTimingRing = 1024;
 // single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart)
 constexpr size_t kSummBytes = 4096 * 4 + static_cast<size_t>(gsim::kFusedCheckpoints) * 9 * 128;
 constexpr int kQueryRing = 16;
+constexpr int kPipe = 8; // single queries of one gsim_db_search_each call enqueued ahead of the one being waited for (< kQueryRing)
 
 struct Shard {
     int device = 0;
@@ -88,9 +89,12 @@ struct Shard {
     bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)
     void* d_pub = nullptr;      // single-launch path: table-wide published-candidate list (1 MB)
     uint32_t* d_summ = nullptr; // single-launch path: per-wave checkpoint summaries (16 KB, zero between queries)
-    uint32_t* h_done = nullptr; // single-launch path: pinned word the kernel stores the query's epoch into
+    uint32_t* h_done = nullptr; // single-launch path: pinned words (one per pipeline slot) the kernel stores the query's epoch into
     uint32_t epoch = 0;
-    bool last_fused = false;    // the last synchronous enqueue went through the single-launch path
+    bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
+    uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
+    char* h_pipe = nullptr;          // kPipe pinned result blocks (gsim_db_search_each)
+    size_t h_pipe_block = 0;
     // Tables whose scores tie heavily (narrow or very sparse fingerprints) make the single-launch path hand every
     // query back, i.e. scan twice: after consecutive hand-backs the synchronous path skips it for 2, 4, ... 64 queries.
     uint32_t redo_streak = 0, fused_skip = 0;
@@ -187,6 +191,7 @@ int free_shard(Shard& s)
     if (s.d_summ) (void) hipFree(s.d_summ);
     if (s.d_dbg) (void) hipFree(s.d_dbg);
     if (s.h_done) (void) hipHostFree(s.h_done);
+    if (s.h_pipe) (void) hipHostFree(s.h_pipe);
     if (s.h_query) (void) hipHostFree(s.h_query);
     if (s.h_result) (void) hipHostFree(s.h_result);
     if (s.h_state) (void) hipHostFree(s.h_state);
@@ -331,7 +336,7 @@ bool fused_applies(const Shard& s, uint32_t k)
 // from a pinned ring slot (no upload op) and the last kernel re-zeroes the per-query state (no
 // memset op).  Nothing here synchronises with the host unless k > kSelectCap.
 int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                       float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode)
+                       float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode, uint32_t pipe_slot)
 {
     GSIM_HIP(hipSetDevice(s.device));
     if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
@@ -391,7 +396,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         }
         ev = &s.ev[3 * s.ev_used];
     }
-    s.last_fused = false;
+    if (caller_syncs) s.slot_fused[pipe_slot] = false;
     if (fused) {
         gsim::FusedArgs f{};
         f.pub = s.d_pub;
@@ -400,7 +405,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.tickets = s.d_summ + 4096;
         f.result = out;
         f.row_base = row_base;
-        f.done_flag = caller_syncs ? s.h_done : nullptr;
+        f.done_flag = caller_syncs ? s.h_done + pipe_slot : nullptr;
         f.epoch = ++s.epoch;
         if (s.epoch == 0) f.epoch = ++s.epoch; // 0 is the flag's initial value
         static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
@@ -414,7 +419,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
         if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
         if (caller_syncs) {
-            s.last_fused = true;
+            s.slot_fused[pipe_slot] = true;
+            s.slot_epoch[pipe_slot] = f.epoch;
             if (ev) {
                 GSIM_HIP(hipEventRecord(ev[2], s.stream));
                 s.ev_used++;
@@ -456,9 +462,9 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
 }
 
 int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                  float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode = kAuto)
+                  float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode = kAuto, uint32_t pipe_slot = 0)
 {
-    const int rc = enqueue_query_impl(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, caller_syncs, mode);
+    const int rc = enqueue_query_impl(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, caller_syncs, mode, pipe_slot);
     if (rc != GSIM_OK) s.state_dirty = true;
     return rc;
 }
@@ -518,12 +524,12 @@ int wait_stream(hipStream_t st)
 // is complete when it changes, a few microseconds before the stream reports the kernel retired;
 // a query it handed back (header flag 2) is re-run by the classic kernels here.
 int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
-                      float beta, uint32_t row_base, void* out)
+                      float beta, uint32_t row_base, void* out, uint32_t pipe_slot = 0)
 {
-    if (!s.last_fused) return wait_stream(s.stream);
-    s.last_fused = false;
-    volatile uint32_t* flag = s.h_done;
-    const uint32_t want = s.epoch;
+    if (!s.slot_fused[pipe_slot]) return wait_stream(s.stream);
+    s.slot_fused[pipe_slot] = false;
+    volatile uint32_t* flag = s.h_done + pipe_slot;
+    const uint32_t want = s.slot_epoch[pipe_slot];
     bool done = false;
     for (uint64_t spins = 0;; spins++) {
         if (*flag == want) {
@@ -602,7 +608,7 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
     }
     if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
-    int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic);
+    int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
     if (rc != GSIM_OK) return rc;
     return wait_stream(s.stream);
 }
@@ -902,6 +908,42 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
         *count = n;
     }
     if (approx) *approx = ap;
+    return GSIM_OK;
+}
+
+// gsim_db_search_each on a single-shard handle: the queries still run strictly one after the other on the GPU (one
+// stream, one per-query state), but up to kPipe of them are enqueued ahead of the one the host is waiting for, each with
+// its own pinned result block and completion word -- the next kernel starts when the previous one retires instead of
+// after a host round trip (flag seen, hits copied, next launch: ~8 us per query).
+int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff,
+                          int metric, float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    GSIM_HIP(hipSetDevice(s.device));
+    const size_t blk = gsim_result_block_bytes(k);
+    if (blk > s.h_pipe_block) {
+        if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
+        s.h_pipe = nullptr;
+        s.h_pipe_block = 0;
+        GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, hipHostMallocDefault));
+        s.h_pipe_block = blk;
+    }
+    const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
+    uint32_t issued = 0;
+    for (uint32_t done = 0; done < nq; done++) {
+        for (; issued < nq && issued - done < static_cast<uint32_t>(kPipe); issued++) {
+            const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta, row_base,
+                                         s.h_pipe + (issued % kPipe) * s.h_pipe_block, true, kAuto, issued % kPipe);
+            if (rc != GSIM_OK) return rc;
+        }
+        void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
+        const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta, row_base,
+                                         out, done % kPipe);
+        if (rc != GSIM_OK) return rc;
+        const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
+        std::memcpy(hits + static_cast<size_t>(done) * kout, h + 1, sizeof(gsim_hit) * h->count);
+        counts[done] = h->count;
+        if (approx) approx[done] = h->approx;
+    }
     return GSIM_OK;
 }
 
@@ -1426,6 +1468,10 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         }
         return GSIM_OK;
     }
+    static const int pipelined = env_int("GSIM_EACH_PIPELINE", 1);
+    if (g_force_each && pipelined && nsh == 1 && nq > 1 && k > 0 && db->shards[0].nrows > 0 && !db->shards[0].d_dbg &&
+        !std::getenv("GSIM_FUSED_DEBUG"))
+        return search_each_pipelined(db, db->shards[0], queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
         rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout, &counts[q],

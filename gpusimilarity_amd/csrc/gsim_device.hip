@@ -1115,6 +1115,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         __hip_atomic_store(&st->npub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // synchronous callers read the hand-back from the header (no gated kernels behind this launch): the next
+        // launch, possibly already enqueued, starts clean
+        if (fa.done_flag) __hip_atomic_store(&st->redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
     { // the summaries: zero again for the next query (16-byte stores)

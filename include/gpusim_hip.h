@@ -166,7 +166,9 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                    uint32_t* counts, uint64_t* approx);
 /* The same call with the queries answered strictly one after the other through the single-query path
  * (FingerprintDB::search called nq times, as the reference's server does, gpusim.cpp:306-374): no table
- * pass is shared.  For callers that measure or need per-query latency without crossing the ABI per query. */
+ * pass is shared.  On a single-shard handle up to eight queries are enqueued ahead of the one being waited for
+ * (each with its own pinned result block): they still run one at a time on the GPU, but the next one starts when
+ * the previous kernel retires, not after a host round trip. */
 int gsim_db_search_each(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
                         float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
                         uint32_t* counts, uint64_t* approx);

@@ -115,6 +115,38 @@ def test_repeated_hand_backs_switch_the_single_launch_off_for_a_while():
     t.close()
 
 
+def _each_against_oracle(t, db, qs, k, cutoff, ctx, **kw):
+    bufs = t.make_search_buffers(len(qs), k)
+    t.search_each_into(np.ascontiguousarray(qs), k, bufs, cutoff, **kw)
+    okw = dict(metric=kw["metric"], alpha=kw["alpha"], beta=kw["beta"]) if "metric" in kw else {}
+    for i, q in enumerate(qs):
+        want, wap = O.search(q, db, k, cutoff, nthreads=8, **okw)
+        assert int(bufs[2][i]) == wap, "%s query %d" % (ctx, i)
+        assert_hits_equal(bufs[0][i, :bufs[1][i]], want, "%s query %d" % (ctx, i))
+
+
+def test_search_each_keeps_queries_in_flight_and_stays_exact():
+    """gsim_db_search_each enqueues up to eight single queries ahead of the one it waits for (own result block and
+    completion word each).  More queries than slots, a cutoff, Tversky, k above the single launch's limit (classic
+    path inside the pipeline), and a table where every query is handed back while later ones are already enqueued."""
+    W = 32
+    db = O.synth_rows(0xEAC4, 0, 0, 700_001, W)
+    t = make_table(db)
+    qs = np.stack([db[O.query_row(i, len(db))] for i in range(19)] + [O.synth_rows(0xEAC5, 0, 3, 1, W)[0], np.zeros(W, dtype=np.uint32)])
+    _each_against_oracle(t, db, qs, 100, 0.0, "each")
+    _each_against_oracle(t, db, qs[:9], 1000, 0.12, "each, cutoff")
+    _each_against_oracle(t, db, qs[:5], 37, 0.0, "each, tversky", metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    _each_against_oracle(t, db, qs[:3], 5000, 0.0, "each, k = 5000")
+    t.close()
+    base = O.synth_rows(0x71EA, 0, 0, 4, W)
+    tied = np.ascontiguousarray(base[np.random.default_rng(13).integers(0, 4, size=200_000)])
+    t = make_table(tied)
+    t.enable_timing(True)
+    _each_against_oracle(t, tied, np.stack([base[i % 4] for i in range(11)]), 50, 0.0, "each, ties")
+    assert t.timing()["handed_back"] >= 2
+    t.close()
+
+
 def test_enqueue_only_path_falls_back_on_the_device():
     """gsim_db_search_device cannot look at the result on the host: the four classic kernels are enqueued
     behind the single launch, gated on its hand-back flag.  Ties -> they run; random rows -> they return
