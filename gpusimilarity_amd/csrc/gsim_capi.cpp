@@ -577,7 +577,7 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         stat(16, 1, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "elect-loaded", a, b, c);
         stat(17, 1, &a, &b, &c);
-        std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "static-end(w0)", a, b, c);
+        std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "3/4-ckpt(w0)", a, b, c);
         stat(12, 4, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n  end %.2f\n", "wave scan-end", a, b, c, (t[nwg * 24] - t0) / 100.0);
         { // streaming end per workgroup class: blockIdx % 8 (the XCD a block lands on) and blockIdx / 32 (dispatch order)
@@ -589,6 +589,19 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
                 sx[g % 8] += (v - t0) / 100.0, nx[g % 8]++;
                 const size_t oct = g * 8 / nwg;
                 sq[oct] += (v - t0) / 100.0, nqd[oct]++;
+            }
+            for (int slot : {18, 19, 20, 21, 22, 17, 1}) { // checkpoints after 4 ... 1024 trips, the 3/4 checkpoint, the end of streaming
+                double s8[8] = {};
+                int n8[8] = {};
+                for (size_t g = 0; g < nwg; g++) {
+                    const unsigned long long v = t[g * 24 + slot];
+                    if (v < t0 || v - t0 > 100000000ull) continue;
+                    s8[g % 8] += (v - t0) / 100.0, n8[g % 8]++;
+                }
+                static const char* const what[] = {"4 trips", "16 trips", "64 trips", "256 trips", "1024 trips"};
+                std::fprintf(stderr, "  %-14s mean by blockIdx %% 8:", slot == 17 ? "3/4 checkpoint" : slot == 1 ? "scan end" : what[slot - 18]);
+                for (int i = 0; i < 8; i++) std::fprintf(stderr, " %7.1f", n8[i] ? s8[i] / n8[i] : 0.0);
+                std::fprintf(stderr, "\n");
             }
             std::fprintf(stderr, "  arrived, mean by blockIdx %% 8:");
             for (int i = 0; i < 8; i++) std::fprintf(stderr, " %7.1f", nx[i] ? sx[i] / nx[i] : 0.0);

@@ -641,6 +641,10 @@ struct FusedFilter {
         write_summary(lane);
         if (lane == 0) atomicAdd(&sh->ck_cnt[ck_j], 1u); // (LDS, after the summary: a wave's LDS operations execute in order)
         if (dbg && lane == 0 && wv == 0 && ck_j == 0) dbg[9] = wall_clock64();
+        if (dbg && lane == 0 && wv == 0) {
+            if (ck_j + 1 == sched.count()) dbg[17] = wall_clock64(); // the last in-loop checkpoint (3/4 of the trips)
+            else if (ck_j >= 1 && ck_j <= 6) dbg[17 + ck_j] = wall_clock64(); // after 4, 16, 64, 256, 1024, 4096 trips
+        }
         ck_j++;
         next_ck = M ? sched.trip(ck_j) : 0xFFFFFFFFu;
     }
@@ -793,7 +797,10 @@ __device__ __forceinline__ void fused_forwarder(FusedShared& sh, QueryState* st,
                 continue;
             }
             if (spins > (1u << 24)) break;
-            __builtin_amdgcn_s_sleep(1);
+            // (the early checkpoints are a few microseconds apart; from the fourth on this wave naps ~1.7 us at a time:
+            // a wave that polls LDS every 64 clocks takes issue slots from the streaming wave on its SIMD)
+            if (j >= 3) __builtin_amdgcn_s_sleep(64);
+            else __builtin_amdgcn_s_sleep(1);
             continue;
         }
         if (lane < kScanBlock / 64)
