@@ -794,6 +794,16 @@ def test_matrix_core_sample_pass_thresholds_are_safe(W, n):
             want, wap = O.search(qs[i], db, 1000, 0.0, nthreads=ORACLE_THREADS, **kw)
             assert wap == n
             assert_hits_equal(hits[i], want, "oracle W=%d q=%d %r" % (W, i, sorted(kw)))
+    # the single-query path with a cutoff on the same table: `approx` counts every row at or above it -- any chunk of
+    # the table scanned twice or not at all would show
+    t = capi.Table(W * 32)
+    t.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
+    for i, (k, cutoff) in ((3, (1000, 0.06)), (75, (50, 0.11))):
+        got, ap = t.search(qs[i], k, cutoff)
+        want, wap = O.search(qs[i], db, k, cutoff, nthreads=ORACLE_THREADS)
+        assert int(ap[0]) == wap, "approx W=%d q=%d cutoff=%g" % (W, i, cutoff)
+        assert_hits_equal(got[0], want, "oracle, cutoff W=%d q=%d" % (W, i))
+    t.close()
 
 
 @pytest.mark.parametrize("W,n,nq,k", [(32, 50_000, 70, 8192), (64, 30_000, 130, 8192), (64, 300, 256, 300),
