@@ -459,6 +459,10 @@ def main():
                              "per-GPU top-k + RCCL all-gather + merge")),
             "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "metric": "tanimoto",
             "parallelism": "row shards, 1 process/GPU" + (", RCCL all_gather of top-k blocks" if world > 1 else ""),
+            "query_execution": ("one query at a time on the GPU; gsim_db_search_each keeps up to 8 of the step's queries "
+                                "enqueued ahead (own result block each), no query shares a table pass with another"
+                                if not sharded else
+                                "one query at a time: local search, all-gather, merge, D2H, then the next"),
         },
         "whole_path_hbm_frac": res["whole_path_hbm_frac"],
         "roofline": res["roofline"],
