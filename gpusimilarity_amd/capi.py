@@ -21,6 +21,7 @@ METRIC_TANIMOTO = 0
 METRIC_TVERSKY = 1
 SYNTH_SPARSE = 0
 SYNTH_DENSE = 1
+SYNTH_MORGAN = 2
 SELECT_CAP = 8192
 
 HIT_DTYPE = np.dtype([("row", "<u4"), ("score", "<f4"), ("common", "<u2"), ("popc_db", "<u2")])
@@ -44,7 +45,7 @@ _lib = None
 EXPORTS = [
     "gsim_device_count", "gsim_device_free_bytes", "gsim_available_device_bytes", "gsim_next_device",
     "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor",
-    "gsim_fold_fingerprint", "gsim_db_generate", "gsim_db_attach_device_rows",
+    "gsim_fold_fingerprint", "gsim_db_generate", "gsim_synth_row", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
     "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
@@ -83,6 +84,7 @@ def load():
         "gsim_db_fold_factor": (C.c_uint32, [vp]),
         "gsim_fold_fingerprint": (C.c_int, [u32p, C.c_uint32, C.c_uint32, u32p]),
         "gsim_db_generate": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
+        "gsim_synth_row": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, u32p]),
         "gsim_db_attach_device_rows": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
         "gsim_db_destroy": (C.c_int, [vp]),
         "gsim_db_count": (C.c_uint64, [vp]),
@@ -148,6 +150,13 @@ def next_device(required_bytes: int) -> int:
     d = C.c_int(-1)
     check(load().gsim_next_device(required_bytes, C.byref(d)))
     return d.value
+
+
+def synth_row(seed: int, kind: int, row: int, fp_bits: int) -> np.ndarray:
+    """Row `row` of the synthetic table gsim_db_generate makes (host twin of the device generator)."""
+    out = np.empty(fp_bits // 32, dtype=np.uint32)
+    check(load().gsim_synth_row(seed, kind, row, fp_bits, _u32(out)))
+    return out
 
 
 def result_block_bytes(k: int) -> int:

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "gsim_device.h"
+#include "gsim_synth.h"
 
 namespace
 {
@@ -54,6 +55,27 @@ int env_int(const char* name, int dflt)
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
     return std::atoi(v);
+}
+
+// Test hook (no production use): GSIM_TEST_ALIAS_DEVICES=N makes the library present N logical devices that all
+// live on physical device 0, so that the in-process multi-device code -- gsim_db_finalize(db, dev, n > 1), the shard
+// fan-out and host merge of search_one / the batch path / folded tables, gsim_next_device's round robin,
+// gpusimserver --gpus N -- runs on a one-GPU box exactly as it would on N GPUs (own stream, state and scratch per
+// shard; only the physical device index differs).
+int alias_devices()
+{
+    static const int n = env_int("GSIM_TEST_ALIAS_DEVICES", 0);
+    return n > 0 ? n : 0;
+}
+
+int phys_device(int logical)
+{
+    return alias_devices() ? 0 : logical;
+}
+
+hipError_t set_device(int logical)
+{
+    return hipSetDevice(phys_device(logical));
 }
 
 constexpr int kTimingRing = 1024;
@@ -175,7 +197,7 @@ namespace
 
 int free_shard(Shard& s)
 {
-    (void) hipSetDevice(s.device);
+    (void) set_device(s.device);
     if (s.stream) (void) hipStreamSynchronize(s.stream);
     if (s.owns_rows && s.d_rows) (void) hipFree(s.d_rows);
     if (s.d_rowpop) (void) hipFree(s.d_rowpop);
@@ -231,9 +253,9 @@ int setup_shard(gsim_db* db, Shard& s)
 {
     if (s.nrows > 0x7FFFFFFFull) // candidate / finalist slots are 32-bit indexed, capacity a power of two <= 2^31
         return fail(GSIM_ERR_INVALID, "more than 2^31-1 rows on one device: shard the table over more devices");
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     hipDeviceProp_t prop;
-    GSIM_HIP(hipGetDeviceProperties(&prop, s.device));
+    GSIM_HIP(hipGetDeviceProperties(&prop, phys_device(s.device)));
     s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     GSIM_HIP(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
     s.stream = s.own_stream;
@@ -273,7 +295,7 @@ int setup_shard(gsim_db* db, Shard& s)
 int ensure_classic_scratch(Shard& s)
 {
     if (s.classic_ready) return GSIM_OK;
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
     GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
     GSIM_HIP(hipMalloc(&s.d_cand_cb, static_cast<size_t>(slots) * 4));
@@ -289,7 +311,7 @@ int ensure_result_capacity(Shard& s, uint32_t k)
 {
     const size_t need = gsim_result_block_bytes(k);
     if (need > s.result_bytes) {
-        GSIM_HIP(hipSetDevice(s.device));
+        GSIM_HIP(set_device(s.device));
         if (s.d_result) GSIM_HIP(hipFree(s.d_result));
         s.d_result = nullptr;
         GSIM_HIP(hipMalloc(&s.d_result, need));
@@ -338,7 +360,7 @@ bool fused_applies(const Shard& s, uint32_t k)
 int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
                        float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode, uint32_t pipe_slot)
 {
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
         GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, ncand_sum), s.stream));
         GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
@@ -473,7 +495,7 @@ int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, floa
 int drain_timing(gsim_db* db, Shard& s)
 {
     if (s.ev_used == 0 && s.bev_used == 0) return GSIM_OK;
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     GSIM_HIP(hipStreamSynchronize(s.stream));
     for (uint32_t i = 0; i < s.bev_used; i++) {
         float ms = 0.f;
@@ -497,7 +519,7 @@ int drain_timing(gsim_db* db, Shard& s)
 // Running candidate / finalist totals kept on the device by the select kernel.
 int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal, unsigned long long* nredo = nullptr)
 {
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     GSIM_HIP(hipMemcpyAsync(s.h_state, s.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost, s.stream));
     GSIM_HIP(hipStreamSynchronize(s.stream));
     *ncand = s.h_state->ncand_sum;
@@ -729,7 +751,7 @@ constexpr uint32_t kBatchMaxQ = 256; // queries per batch call on a shard (large
 // Buffers of the multi-query path, sized for kBatchMaxQ queries and result blocks of k hits.
 int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
 {
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     if (s.bq_cap == 0) {
         const int wpc = env_int("GSIM_BATCH_WAVES_PER_CU", 12);
         s.bgeo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, 8);
@@ -794,7 +816,7 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     // 12 KB written by the select kernel straight over PCIe cost ~5 ms per batch)
     const bool to_host = results == nullptr;
     if (to_host) results = s.d_bresult; // (allocated or grown just above)
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     const size_t qbytes = static_cast<size_t>(nq) * s.W * 4;
     std::memcpy(s.h_bqueries, queries, qbytes);
     uint32_t* hp = s.h_bqueries + static_cast<size_t>(nq) * s.W;
@@ -899,7 +921,7 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
     uint64_t ap = 0;
     merged.clear();
     for (auto& s : db->shards) {
-        GSIM_HIP(hipSetDevice(s.device));
+        GSIM_HIP(set_device(s.device));
         int rc = finish_query_sync(db, s, query, k, cutoff, metric, alpha, beta,
                                    db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
         if (rc != GSIM_OK) return rc;
@@ -931,7 +953,7 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
 int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff,
                           int metric, float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
 {
-    GSIM_HIP(hipSetDevice(s.device));
+    GSIM_HIP(set_device(s.device));
     const size_t blk = gsim_result_block_bytes(k);
     if (blk > s.h_pipe_block) {
         if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
@@ -993,7 +1015,7 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
         merged.clear();
         for (size_t i = 0; i < db->shards.size(); i++) {
             Shard& s = db->shards[i];
-            GSIM_HIP(hipSetDevice(s.device));
+            GSIM_HIP(set_device(s.device));
             int rc = finish_query_sync(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result);
             if (rc != GSIM_OK) return rc;
             const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
@@ -1071,6 +1093,7 @@ int gsim_device_count(int* count)
         (void) hipGetLastError();
         n = 0;
     }
+    if (n > 0 && alias_devices()) n = alias_devices(); // test hook, see alias_devices()
     *count = n;
     return GSIM_OK;
 }
@@ -1081,7 +1104,7 @@ int gsim_device_free_bytes(int device, size_t* free_bytes)
     int n = 0;
     gsim_device_count(&n);
     if (device < 0 || device >= n) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
-    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(set_device(device));
     size_t fr = 0, tot = 0;
     GSIM_HIP(hipMemGetInfo(&fr, &tot));
     *free_bytes = fr;
@@ -1219,7 +1242,7 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
             }
             folded.resize(static_cast<size_t>(s.nrows) * Wf);
             fold_rows_mt(db->host_rows.data() + s.first_row * db->W, s.nrows, db->W, db->fold, folded.data());
-            GSIM_HIP(hipSetDevice(s.device));
+            GSIM_HIP(set_device(s.device));
             GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
             s.owns_rows = true;
             if (bytes) GSIM_HIP(hipMemcpy(s.d_rows, folded.data(), bytes, hipMemcpyHostToDevice));
@@ -1244,7 +1267,7 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
         s.device = device + i;
         s.first_row = std::min<uint64_t>(per * i, db->nrows);
         s.nrows = std::min<uint64_t>(per, db->nrows - s.first_row);
-        GSIM_HIP(hipSetDevice(s.device));
+        GSIM_HIP(set_device(s.device));
         const size_t bytes = static_cast<size_t>(s.nrows) * row_bytes;
         GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
         s.owns_rows = true;
@@ -1263,7 +1286,9 @@ int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row, u
 {
     if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
     if (db->finalized || db->nrows) return fail(GSIM_ERR_STATE, "table already holds rows");
-    if (kind != GSIM_SYNTH_SPARSE && kind != GSIM_SYNTH_DENSE) return fail(GSIM_ERR_INVALID, "unknown synthetic kind");
+    if (kind != GSIM_SYNTH_SPARSE && kind != GSIM_SYNTH_DENSE && kind != GSIM_SYNTH_MORGAN)
+        return fail(GSIM_ERR_INVALID, "unknown synthetic kind");
+    if (kind == GSIM_SYNTH_MORGAN && db->W > 12288) return fail(GSIM_ERR_INVALID, "Morgan-shaped rows: fp_bits too large");
     if (nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
     int ndev = 0;
     gsim_device_count(&ndev);
@@ -1275,7 +1300,7 @@ int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row, u
     s.device = device;
     s.first_row = 0;
     s.nrows = nrows;
-    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(set_device(device));
     const size_t bytes = static_cast<size_t>(nrows) * db->W * 4;
     GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
     s.owns_rows = true;
@@ -1284,6 +1309,21 @@ int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row, u
     GSIM_HIP(gsim::launch_generate(s.d_rows, seed, kind, first_row, nrows, db->W, s.stream));
     GSIM_HIP(hipStreamSynchronize(s.stream));
     db->finalized = true;
+    return GSIM_OK;
+}
+
+int gsim_synth_row(uint64_t seed, int kind, uint64_t row, uint32_t fp_bits, uint32_t* out_words)
+{
+    if (!out_words) return fail(GSIM_ERR_INVALID, "out_words is NULL");
+    if (fp_bits == 0 || fp_bits % 32 != 0 || fp_bits > 32768) return fail(GSIM_ERR_INVALID, "fp_bits must be a positive multiple of 32, <= 32768");
+    const uint32_t W = fp_bits / 32;
+    if (kind == GSIM_SYNTH_MORGAN) {
+        gsim::synth_row_morgan(out_words, seed, row, W);
+    } else if (kind == GSIM_SYNTH_SPARSE || kind == GSIM_SYNTH_DENSE) {
+        for (uint32_t j = 0; j < W; j++) out_words[j] = gsim::synth_word_iid(seed, kind == GSIM_SYNTH_DENSE, row * W + j);
+    } else {
+        return fail(GSIM_ERR_INVALID, "unknown synthetic kind");
+    }
     return GSIM_OK;
 }
 
@@ -1347,7 +1387,7 @@ int gsim_db_row(const gsim_db* db, uint64_t row, uint32_t* out_words)
     }
     for (const auto& s : db->shards) {
         if (row >= s.first_row && row < s.first_row + s.nrows) {
-            GSIM_HIP(hipSetDevice(s.device));
+            GSIM_HIP(set_device(s.device));
             const unsigned char* src = static_cast<const unsigned char*>(s.d_rows) +
                                        static_cast<size_t>(row - s.first_row) * db->W * 4;
             GSIM_HIP(hipMemcpy(out_words, src, static_cast<size_t>(db->W) * 4, hipMemcpyDeviceToHost));
@@ -1423,7 +1463,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             bool overflow = false, dense_cutoff = false;
             for (auto& s : db->shards) {
                 if (s.nrows == 0) continue;
-                GSIM_HIP(hipSetDevice(s.device));
+                GSIM_HIP(set_device(s.device));
                 rc = wait_stream(s.stream);
                 if (rc != GSIM_OK) return rc;
                 if (s.h_bflags[0] & 8u) dense_cutoff = true;
@@ -1438,7 +1478,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             }
             for (auto& s : db->shards) {
                 if (s.nrows == 0) continue;
-                GSIM_HIP(hipSetDevice(s.device));
+                GSIM_HIP(set_device(s.device));
                 rc = wait_stream(s.stream);
                 if (rc != GSIM_OK) return rc;
                 if (s.h_bflags[0] & 1u) overflow = true;
@@ -1539,7 +1579,7 @@ int gsim_db_search_batch_device(gsim_db* db, const uint32_t* queries, uint32_t n
             if (rc != GSIM_OK) return rc;
             // the one host synchronisation of a batch: did a query overflow its candidate segment or
             // collect too many ties for the multi-query select (bit 2, set by batch_select_kernel)?
-            GSIM_HIP(hipSetDevice(s.device));
+            GSIM_HIP(set_device(s.device));
             rc = wait_stream(s.stream);
             if (rc != GSIM_OK) return rc;
             if (s.h_bflags[0] & 8u) { // the cutoff keeps too many rows for the matrix-core pass: VALU pass
@@ -1566,7 +1606,7 @@ int gsim_merge_device(int device, void* hip_stream, const void* d_blocks, uint32
 {
     if (!d_blocks || !d_result || nblocks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
     if (block_bytes < gsim_result_block_bytes(k)) return fail(GSIM_ERR_INVALID, "block_bytes too small for k");
-    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(set_device(device));
     GSIM_HIP(gsim::launch_merge_batch(d_blocks, nblocks, 1, block_bytes, k, d_result,
                                       static_cast<hipStream_t>(hip_stream)));
     return GSIM_OK;
@@ -1578,7 +1618,7 @@ int gsim_merge_device_batch(int device, void* hip_stream, const void* d_blocks, 
     if (!d_blocks || !d_results || nranks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
     if (block_bytes < gsim_result_block_bytes(k)) return fail(GSIM_ERR_INVALID, "block_bytes too small for k");
     if (nq == 0) return GSIM_OK;
-    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(set_device(device));
     GSIM_HIP(gsim::launch_merge_batch(d_blocks, nranks, nq, block_bytes, k, d_results,
                                       static_cast<hipStream_t>(hip_stream)));
     return GSIM_OK;
@@ -1730,7 +1770,7 @@ int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint
     int ndev = 0;
     gsim_device_count(&ndev);
     if (device < 0 || device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
-    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(set_device(device));
     const size_t n = static_cast<size_t>(max_b + 1) * (max_c + 1);
     float* d = nullptr;
     GSIM_HIP(hipMalloc(&d, n * sizeof(float)));
@@ -1754,7 +1794,7 @@ int gsim_debug_prefilter_constants(int device, int metric, float alpha, float be
     int ndev = 0;
     gsim_device_count(&ndev);
     if (device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
-    GSIM_HIP(hipSetDevice(device));
+    GSIM_HIP(set_device(device));
     const size_t n = static_cast<size_t>(max_qa + 1) * (has_cutoff ? 1 : gsim::kBBins) * 4;
     float* d = nullptr;
     GSIM_HIP(hipMalloc(&d, n * sizeof(float)));

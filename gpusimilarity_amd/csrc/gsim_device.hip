@@ -36,8 +36,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
+#include "gsim_synth.h"
 
 namespace gsim
 {
@@ -1786,34 +1790,29 @@ __global__ __launch_bounds__(256) void merge_kernel(const void* all_blocks, uint
 // synthetic table generator (twin of oracle gso_synth_word)
 // ---------------------------------------------------------------------------
 
-__device__ __forceinline__ u64 splitmix64(u64 x)
-{
-    u64 z = x + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-__device__ __forceinline__ u64 stream_at(u64 seed, u64 n)
-{
-    return splitmix64(seed + n * 0x9E3779B97F4A7C15ull);
-}
-
 __global__ __launch_bounds__(256) void generate_kernel(uint32_t* rows, u64 seed, int kind, u64 first_row,
                                                        u64 nwords, uint32_t W)
 {
     const u64 stride = static_cast<u64>(gridDim.x) * blockDim.x;
-    for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < nwords; i += stride) {
-        const u64 ctr = first_row * W + i;
-        uint32_t word;
-        if (kind == GSIM_SYNTH_DENSE) {
-            word = static_cast<uint32_t>(stream_at(seed, ctr));
-        } else {
-            const u64 h0 = stream_at(seed, 2 * ctr), h1 = stream_at(seed, 2 * ctr + 1);
-            word = static_cast<uint32_t>(h0) & static_cast<uint32_t>(h0 >> 32) & static_cast<uint32_t>(h1) &
-                   static_cast<uint32_t>(h1 >> 32);
-        }
-        rows[i] = word;
+    for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < nwords; i += stride)
+        rows[i] = synth_word_iid(seed, kind == GSIM_SYNTH_DENSE, first_row * W + i);
+}
+
+// GSIM_SYNTH_MORGAN (gsim_synth.h): a row is made whole, by one thread, in LDS; the workgroup's rows
+// then leave with coalesced stores.  R rows per workgroup (host: kMorganLdsWords / W, at most 256).
+constexpr uint32_t kMorganLdsWords = 12288;
+
+__global__ __launch_bounds__(256) void generate_morgan_kernel(uint32_t* rows, u64 seed, u64 first_row, u64 nrows,
+                                                              uint32_t W, uint32_t R)
+{
+    __shared__ uint32_t s_rows[kMorganLdsWords];
+    for (u64 r0 = static_cast<u64>(blockIdx.x) * R; r0 < nrows; r0 += static_cast<u64>(gridDim.x) * R) {
+        const uint32_t n = static_cast<uint32_t>(nrows - r0 < R ? nrows - r0 : R);
+        if (threadIdx.x < n) synth_row_morgan(s_rows + threadIdx.x * W, seed, first_row + r0 + threadIdx.x, W);
+        __syncthreads();
+        uint32_t* dst = rows + r0 * W;
+        for (uint32_t i = threadIdx.x; i < n * W; i += 256) dst[i] = s_rows[i];
+        __syncthreads();
     }
 }
 
@@ -1839,6 +1838,23 @@ template <int LPR, int U> hipError_t launch_scan_t(const ScanArgs& a, const Scan
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per device and kernel (whether the runtime keeps the attribute
+// per function or per device is its business; a multi-device handle launches the same kernel on several devices).
+struct DynLdsOnce {
+    std::atomic<bool> done[64] = {};
+    hipError_t ensure(const void* fn, size_t bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+        return hipSuccess;
+    }
+};
 
 static bool is_pow2(uint32_t x)
 {
@@ -1898,13 +1914,9 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
     if (g.lanes_per_row == 0) {
         const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
-        static bool attr_done = false;
-        if (!attr_done) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_generic_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGenericLdsBytes));
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        static DynLdsOnce once;
+        const hipError_t e = once.ensure(reinterpret_cast<const void*>(sample_generic_kernel), kGenericLdsBytes);
+        if (e != hipSuccess) return e;
         if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
         hipLaunchKernelGGL(sample_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g.chunk_rows, nsample, stride);
         return hipGetLastError();
@@ -1944,13 +1956,9 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
 #undef GSIM_CASE
     if (g.lanes_per_row != 0) return hipErrorInvalidValue;
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    static bool attr_done = false;
-    if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_generic_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kGenericLdsBytes));
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;
+    const hipError_t e = once.ensure(reinterpret_cast<const void*>(scan_generic_kernel), kGenericLdsBytes);
+    if (e != hipSuccess) return e;
     const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
     if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
     hipLaunchKernelGGL(scan_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g);
@@ -1961,13 +1969,9 @@ template <int LPR, int U>
 hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
 {
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    static bool attr_done = false; // (the attribute is per function, not per device, on this runtime)
-    if (!attr_done) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_kernel<LPR, U>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(sizeof(FusedShared)));
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;
+    const hipError_t e = once.ensure(reinterpret_cast<const void*>(fused_kernel<LPR, U>), sizeof(FusedShared));
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((fused_kernel<LPR, U>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
     return hipGetLastError();
 }
@@ -2019,17 +2023,9 @@ hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned lon
 hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, const uint32_t* finalists_cb,
                          uint32_t finalists_cap, uint32_t row_base, void* d_result, hipStream_t s)
 {
-    // per-device function attribute, set once per device
-    static bool attr_done[64] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static DynLdsOnce once;
+    const hipError_t e = once.ensure(reinterpret_cast<const void*>(select_kernel), kSelectLds);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kSelectLds));
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_done[dev] = true;
-    }
     hipLaunchKernelGGL(select_kernel, dim3(kSelectBlocks), dim3(kSelectThreads), kSelectLds, s, a, finalists,
                        finalists_cb, finalists_cap, row_base, d_result);
     return hipGetLastError();
@@ -2086,6 +2082,15 @@ hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_r
 {
     const uint64_t nwords = nrows * W;
     if (nwords == 0) return hipSuccess;
+    if (kind == GSIM_SYNTH_MORGAN) {
+        if (W > kMorganLdsWords) return hipErrorInvalidValue;
+        const uint32_t R = std::min<uint32_t>(256u, kMorganLdsWords / W);
+        uint64_t nb = (nrows + R - 1) / R;
+        if (nb > 65536) nb = 65536;
+        hipLaunchKernelGGL(generate_morgan_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s,
+                           reinterpret_cast<uint32_t*>(rows), seed, first_row, nrows, W, R);
+        return hipGetLastError();
+    }
     uint64_t nb = (nwords + 255) / 256;
     if (nb > 65536) nb = 65536;
     hipLaunchKernelGGL(generate_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s,

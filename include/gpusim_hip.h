@@ -43,6 +43,9 @@ extern "C" {
 
 #define GSIM_SYNTH_SPARSE 0 /* bit density 1/16 (Morgan-like) */
 #define GSIM_SYNTH_DENSE 1  /* bit density 1/2                */
+#define GSIM_SYNTH_MORGAN 2 /* Morgan-shaped rows: popcount 20..53 of 1024, a dozen very frequent bits, series of
+                               analogs, table-wide scaffolds, ~3 % exact duplicates (csrc/gsim_synth.h) -- coarse,
+                               tie-heavy scores like the reference's ChEMBL / Zinc / Enamine tables */
 
 typedef struct gsim_db gsim_db;
 
@@ -129,6 +132,9 @@ int gsim_fold_fingerprint(const uint32_t* fingerprint, uint32_t words, uint32_t 
  * Replaces add_rows+finalize for benchmark tables that exceed host memory. */
 int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row,
                      uint64_t nrows, int device);
+/* Row `row` of that synthetic table, computed on the host by the generator's own code (benchmark
+ * queries are rows of the table; no device, no handle needed). */
+int gsim_synth_row(uint64_t seed, int kind, uint64_t row, uint32_t fp_bits, uint32_t* out_words);
 /* Borrow rows that already live in device memory (e.g. a torch tensor); the
  * caller keeps ownership and must keep them alive.  16-byte aligned. */
 int gsim_db_attach_device_rows(gsim_db* db, const void* d_rows, uint64_t nrows,

@@ -32,6 +32,12 @@ static inline uint64_t stream_at(uint64_t seed, uint64_t n)
 uint32_t gso_synth_word(uint64_t seed, int kind, uint64_t row, uint32_t W, uint32_t j)
 {
     const uint64_t ctr = row * (uint64_t) W + j;
+    if (kind == GSO_KIND_MORGAN) { /* rows of this kind are made whole (gso_synth_row_morgan) */
+        uint32_t tmp[1024];
+        if (W > 1024 || j >= W) return 0;
+        gso_synth_row_morgan(tmp, seed, row, W);
+        return tmp[j];
+    }
     if (kind == GSO_KIND_DENSE) {
         return (uint32_t) stream_at(seed, ctr);
     }
@@ -40,9 +46,87 @@ uint32_t gso_synth_word(uint64_t seed, int kind, uint64_t row, uint32_t W, uint3
     return (uint32_t) h0 & (uint32_t) (h0 >> 32) & (uint32_t) h1 & (uint32_t) (h1 >> 32);
 }
 
+/* Morgan-shaped rows (GSO_KIND_MORGAN).  What the reference's numbers are quoted on is 1024-bit
+ * Morgan r=2 fingerprints (python/gpusim_utils.py:21,55-66); its fixture test/small.fsim has popcounts
+ * 20..53 (mean 34.5), a dozen bits set in more than half of the rows and a long tail, mean pairwise
+ * Tanimoto 0.155.  The generator reproduces that shape and what real libraries add: rows come in
+ * scaffold clusters (contiguous series of 16..1024 analogs, table-wide scaffolds, singletons) and a
+ * few per cent are exact duplicates.  A row is: 16 "common" bits drawn per scaffold with the
+ * fixture's frequencies + 10..26 scaffold bits (minus up to two dropped per member) + 2..13 member
+ * bits.  Counter-based, integer-only: row r depends on (seed, r, fp width) alone.
+ * The device twin is generate_morgan_kernel (gsim_device.hip), the product-side host twin
+ * gsim_synth_row (gsim_capi.cpp). */
+static inline uint64_t mh2(uint64_t seed, uint64_t tag, uint64_t a, uint64_t b)
+{
+    return gso_splitmix64(gso_splitmix64(seed + tag * 0xD1B54A32D192ED03ULL + a * 0x9E3779B97F4A7C15ULL) +
+                          b * 0x9E3779B97F4A7C15ULL);
+}
+
+static const uint8_t k_morgan_common[16] = {253, 253, 236, 220, 200, 174, 166, 161, 161, 141, 133, 131, 90, 84, 74, 74};
+
+static inline uint32_t morgan_pos(uint64_t x, uint32_t W)
+{
+    /* product of two uniforms: density ~ -ln(u), then the (word, bit) transposition spreads the
+     * frequent low positions over the words */
+    const uint32_t u = (uint32_t) (((x & 0xFFFFu) * ((x >> 16) & 0xFFFFu)) >> 16);
+    const uint32_t pos = (uint32_t) (((uint64_t) u * (W * 32u)) >> 16);
+    return (pos & 31u) * W + (pos >> 5);
+}
+
+void gso_synth_row_morgan(uint32_t* out, uint64_t seed, uint64_t row, uint32_t W)
+{
+    const uint32_t nbits = W * 32u;
+    for (uint32_t j = 0; j < W; j++) out[j] = 0;
+    const uint64_t rh = mh2(seed, 1, row, 0);
+    const uint64_t sh = mh2(seed, 2, row >> 10, 0);
+    uint64_t sid, mspace;
+    switch (rh & 3u) {
+    case 0: /* table-wide scaffold */
+        sid = (1ULL << 62) | ((rh >> 8) & 0xFFFFu);
+        mspace = 1u << 14;
+        break;
+    case 1: /* singleton */
+        sid = (2ULL << 62) | row;
+        mspace = 1;
+        break;
+    default: { /* a contiguous series of S = 16, 64, 256 or 1024 rows */
+        const uint32_t lg = 4u + 2u * (uint32_t) (sh & 3u);
+        sid = (row >> lg) | ((uint64_t) lg << 56);
+        mspace = 4ULL << lg;
+    }
+    }
+    const uint64_t m = (rh >> 24) % mspace;
+    const uint64_t kh = mh2(seed, 3, sid, 0);
+    const uint64_t mh = mh2(seed, 6, sid, m);
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint64_t c = mh2(seed, 4, sid, i >> 3);
+        if (((c >> (8 * (i & 7u))) & 0xFFu) < k_morgan_common[i]) {
+            const uint32_t p = (i * 67u + 5u) % nbits;
+            out[p >> 5] |= 1u << (p & 31u);
+        }
+    }
+    const uint32_t ps = 10u + (uint32_t) (kh % 17u);
+    const uint32_t ndrop = (uint32_t) (mh % 3u);
+    const uint32_t d0 = (uint32_t) ((mh >> 8) & 0xFFu) % ps, d1 = (uint32_t) ((mh >> 16) & 0xFFu) % ps;
+    for (uint32_t j = 0; j < ps; j++) {
+        if ((ndrop >= 1 && j == d0) || (ndrop >= 2 && j == d1)) continue;
+        const uint32_t p = morgan_pos(mh2(seed, 5, sid, j), W);
+        out[p >> 5] |= 1u << (p & 31u);
+    }
+    const uint32_t na = 2u + (uint32_t) ((mh >> 32) % 12u);
+    for (uint32_t j = 0; j < na; j++) {
+        const uint32_t p = morgan_pos(gso_splitmix64(mh + (j + 1) * 0x9E3779B97F4A7C15ULL), W);
+        out[p >> 5] |= 1u << (p & 31u);
+    }
+}
+
 void gso_synth_rows(uint32_t* out, uint64_t seed, int kind, uint64_t first_row,
                     uint64_t nrows, uint32_t W)
 {
+    if (kind == GSO_KIND_MORGAN) {
+        for (uint64_t r = 0; r < nrows; r++) gso_synth_row_morgan(out + r * W, seed, first_row + r, W);
+        return;
+    }
     for (uint64_t r = 0; r < nrows; r++) {
         for (uint32_t j = 0; j < W; j++) {
             out[r * W + j] = gso_synth_word(seed, kind, first_row + r, W, j);

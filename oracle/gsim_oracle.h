@@ -33,6 +33,7 @@ extern "C" {
 
 #define GSO_KIND_SPARSE 0 /* bit density 1/16, Morgan-like */
 #define GSO_KIND_DENSE 1  /* bit density 1/2 */
+#define GSO_KIND_MORGAN 2 /* Morgan-shaped: popcount 20..53, scaffold clusters, duplicates */
 
 typedef struct {
     uint32_t row;     /* row index in the scanned table               */
@@ -47,6 +48,8 @@ uint64_t gso_splitmix64(uint64_t x);
 uint32_t gso_synth_word(uint64_t seed, int kind, uint64_t row, uint32_t W, uint32_t j);
 void gso_synth_rows(uint32_t* out, uint64_t seed, int kind, uint64_t first_row,
                     uint64_t nrows, uint32_t W);
+/* one row of the GSO_KIND_MORGAN table (gso_synth_word serves the other kinds word by word) */
+void gso_synth_row_morgan(uint32_t* out, uint64_t seed, uint64_t row, uint32_t W);
 /* row index used for query number q of an N-row table. */
 uint64_t gso_query_row(uint64_t q, uint64_t nrows);
 
