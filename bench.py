@@ -8,7 +8,7 @@
 rendezvous); under torch.distributed.run the ranks are taken from the environment.
 
 A "step" is one pass of the hot path over one batch of synthetic input: --queries-per-step
-(default 16) single queries, one after the other -- for each, the packed table resident in HBM
+(default 128: 20 steps keep the GPU busy for ~5 s at 100 M rows) single queries, one after the other -- for each, the packed table resident in HBM
 is scanned once, the exact top-k is selected, (N > 1: the per-GPU top-k blocks are all-gathered
 over RCCL/xGMI and merged), and the k hits land in host memory.  Weak scaling: every rank holds
 --rows-per-gpu rows (default 100 M at N = 1 = BASELINE.json configs[2], the HBM-bound roofline
@@ -19,7 +19,8 @@ Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel's algorithmic 
 fingerprint per pass) over its HIP-event duration on the stream it runs on.  At N = 1 the line
 also carries `configs`: every single-GPU BASELINE config measured in this run (configs[1]: 1 M
 rows; configs[2]: the headline; configs[4]'s per-GPU shape: 125 M x 2048-bit, Tversky, 256-query
-batches), and `cpu_baseline`: the reference's host functor path + top-k on this box's cores
+batches) plus the 1 M / 100 M-row tables again with MORGAN-SHAPED rows (clustered, tie-heavy: what the
+reference's own numbers are quoted on), and `cpu_baseline`: the reference's host functor path + top-k on this box's cores
 (oracle/_ref when present, else the oracle port) on bounded samples.
 """
 import argparse
@@ -40,7 +41,7 @@ MFMA_FP4_PEAK_TFLOPS = 10000.0  # dense MX-FP4, MI355X_MICROARCH.md (measured 90
 DB_SEED = 0x5EED0001
 GOLDEN = 0x9E3779B97F4A7C15
 M64 = (1 << 64) - 1
-SYNTH_SPARSE, SYNTH_DENSE = 0, 1
+SYNTH_SPARSE, SYNTH_DENSE, SYNTH_MORGAN = 0, 1, 2
 
 
 def _splitmix64(x):
@@ -51,18 +52,10 @@ def _splitmix64(x):
 
 
 def synth_row(seed, kind, row, W):
-    """Host twin of the device generator for one row -- used to make the
-    query fingerprints (queries are rows of the table: guaranteed score-1.0 self hit)."""
-    out = np.zeros(W, dtype=np.uint32)
-    for j in range(W):
-        ctr = row * W + j
-        if kind == SYNTH_DENSE:
-            out[j] = _splitmix64((seed + ctr * GOLDEN) & M64) & 0xFFFFFFFF
-        else:
-            h0 = _splitmix64((seed + (2 * ctr) * GOLDEN) & M64)
-            h1 = _splitmix64((seed + (2 * ctr + 1) * GOLDEN) & M64)
-            out[j] = (h0 & 0xFFFFFFFF) & (h0 >> 32) & (h1 & 0xFFFFFFFF) & (h1 >> 32)
-    return out
+    """One row of the synthetic table, from the generator's own host twin in the product library
+    (gsim_synth_row) -- the query fingerprints are rows of the table: guaranteed score-1.0 self hit."""
+    from gpusimilarity_amd import capi
+    return capi.synth_row(seed, kind, row, W * 32)
 
 
 def query_row(q, nrows):
@@ -212,7 +205,8 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
         else:
             hits, approx = bufs[0][qps - 1, :bufs[1][qps - 1]], int(bufs[2][qps - 1])
         want_row = query_row((warmup * qps - 1) % distinct, total_rows)
-        assert len(hits) == min(k, total_rows) and int(hits["row"][0]) == want_row and hits["score"][0] == 1.0, \
+        # (Morgan-shaped tables hold exact duplicates: the query's own row is one of the rows scoring 1.0)
+        assert len(hits) == min(k, total_rows) and hits["score"][0] == 1.0 and want_row in hits["row"][hits["score"] == 1.0], \
             "self hit missing: %r" % (hits[:3],)
         assert approx == total_rows
     table.enable_timing(True)
@@ -330,12 +324,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--queries-per-step", type=int, default=16,
+    ap.add_argument("--queries-per-step", type=int, default=128,
                     help="single queries per step (a step is one pass of the hot path over one batch of input)")
     ap.add_argument("--rows-per-gpu", type=int, default=0)
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--fp-bits", type=int, default=1024)
-    ap.add_argument("--kind", choices=["sparse", "dense"], default="sparse")
+    ap.add_argument("--kind", choices=["sparse", "dense", "morgan"], default="sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configs (N = 1 only)")
     ap.add_argument("--batch-queries", type=int, default=0,
@@ -383,11 +377,11 @@ def main():
 
     R = args.rows_per_gpu or (100_000_000 if world == 1 else 125_000_000)
     total_rows = R * world
-    kind = capi.SYNTH_SPARSE if args.kind == "sparse" else capi.SYNTH_DENSE
+    kind = {"sparse": capi.SYNTH_SPARSE, "dense": capi.SYNTH_DENSE, "morgan": capi.SYNTH_MORGAN}[args.kind]
     k = args.k
     sharded = world > 1 or args.force_sharded_path
 
-    def make_table(rows, bits, first_row):
+    def make_table(rows, bits, first_row, kind=kind):
         t = capi.Table(bits)
         t.generate(DB_SEED, kind, first_row, rows, device_index)  # this rank's contiguous shard, made in HBM
         t.set_row_base(first_row)
@@ -442,11 +436,11 @@ def main():
         "ms_per_step": res["ms_per_query"] * qps, "value": res["fingerprints_per_s"], "unit": "fingerprints/s",
         "timed_region_s": res["seconds"], "whole_path_hbm_frac": res["whole_path_hbm_frac"], "roofline": res["roofline"]}
     out = {
+        "timed_region_s": res["seconds"],
         "metric": "fingerprints scanned/sec (1024-bit Tanimoto top-1000)",
         "value": res["fingerprints_per_s"], "unit": "fingerprints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_query"] * qps, "queries_per_step": qps, "ms_per_query": res["ms_per_query"],
-        "timed_region_s": res["seconds"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {
@@ -462,7 +456,9 @@ def main():
             "query_execution": ("one query at a time on the GPU; gsim_db_search_each keeps up to 8 of the step's queries "
                                 "enqueued ahead (own result block each), no query shares a table pass with another"
                                 if not sharded else
-                                "one query at a time: local search, all-gather, merge, D2H, then the next"),
+                                "one query at a time, NOT pipelined: local search, all-gather, merge, D2H, host waits, then the "
+                                "next (the N = 1 line keeps 8 queries enqueued and holds 100 M rows per GPU, this one %d M: "
+                                "compare per-GPU rates, not ms/query)" % (R // 1_000_000)),
         },
         "whole_path_hbm_frac": res["whole_path_hbm_frac"],
         "roofline": res["roofline"],
@@ -471,16 +467,32 @@ def main():
     if world == 1 and not args.no_configs and not sharded:
         # the other single-GPU BASELINE configs, measured in this run, each with its own dominant-kernel roofline
         cfgs = []
-        t1 = make_table(1_000_000, 1024, 0)
-        r1, _ = time_queries(ctx, t1, 1_000_000, 1_000_000, 1024, kind, 1000, max(args.steps, 20), args.warmup, 64, False)
-        t1.close()
-        cfgs.append({"name": "BASELINE configs[1]: 1M x 1024-bit, Tanimoto top-1000, 1 MI355X", "rows_per_gpu": 1_000_000,
-                     "fp_bits": 1024, "k": 1000, "ms_per_query": r1["ms_per_query"], "ms_per_step": r1["ms_per_query"],
-                     "value": r1["fingerprints_per_s"], "unit": "fingerprints/s", "timed_region_s": r1["seconds"],
-                     "whole_path_hbm_frac": r1["whole_path_hbm_frac"], "roofline": r1["roofline"],
-                     "note": "latency-bound: the 128 MB table streams in 16 us at 8 TB/s; the rest is launch, the threshold "
-                             "exchange and the select inside the single launch"})
+
+        def single_cfg(name, rows, kind_, qps_, note=None):
+            t = make_table(rows, 1024, 0, kind_)
+            r, _ = time_queries(ctx, t, rows, rows, 1024, kind_, 1000, max(args.steps, 20), args.warmup, qps_, False)
+            t.close()
+            c = {"name": name, "rows_per_gpu": rows, "fp_bits": 1024, "k": 1000, "ms_per_query": r["ms_per_query"],
+                 "ms_per_step": r["ms_per_query"] * qps_, "queries_per_step": qps_, "value": r["fingerprints_per_s"],
+                 "unit": "fingerprints/s", "timed_region_s": r["seconds"], "whole_path_hbm_frac": r["whole_path_hbm_frac"],
+                 "roofline": r["roofline"]}
+            if note:
+                c["note"] = note
+            return c
+
+        cfgs.append(single_cfg("BASELINE configs[1]: 1M x 1024-bit, Tanimoto top-1000, 1 MI355X", 1_000_000, kind, 512,
+                               "latency-bound: the 128 MB table streams in 16 us at 8 TB/s; the rest is launch, the threshold "
+                               "exchange and the select inside the single launch"))
         cfgs.append(headline_cfg)
+        # the same two tables with Morgan-shaped rows (GSIM_SYNTH_MORGAN: popcount 20..53, frequent bits, series of analogs,
+        # duplicates -- coarse, tie-heavy scores): what the reference's published numbers are quoted on
+        try:
+            cfgs.append(single_cfg("configs[1] shape, Morgan-like rows: 1M x 1024-bit, Tanimoto top-1000", 1_000_000,
+                                   capi.SYNTH_MORGAN, 512))
+            cfgs.append(single_cfg("configs[2] shape, Morgan-like rows: 100M x 1024-bit, Tanimoto top-1000", 100_000_000,
+                                   capi.SYNTH_MORGAN, 32))
+        except Exception as e:  # never lose the headline over it
+            cfgs.append({"name": "Morgan-like tables", "error": repr(e)})
         try:
             t4 = make_table(125_000_000, 2048, 0)
             r4 = time_batches(ctx, t4, 125_000_000, 125_000_000, 2048, kind, 1000, 256, 8, 2, False)

@@ -18,6 +18,7 @@ METRIC_TANIMOTO = 0
 METRIC_TVERSKY = 1
 KIND_SPARSE = 0
 KIND_DENSE = 1
+KIND_MORGAN = 2
 
 HIT_DTYPE = np.dtype([("row", "<u4"), ("score", "<f4"), ("common", "<u2"), ("popc_db", "<u2")])
 
