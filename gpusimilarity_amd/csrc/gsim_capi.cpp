@@ -79,8 +79,10 @@ hipError_t set_device(int logical)
 }
 
 constexpr int kTimingRing = 1024;
-// single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart)
-constexpr size_t kSummBytes = 4096 * 4 + static_cast<size_t>(gsim::kFusedCheckpoints) * 9 * 128;
+// single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart) + the
+// arrival counters (128 B apart)
+constexpr size_t kTicketWords = static_cast<size_t>(gsim::kFusedCheckpoints) * 9 * 32;
+constexpr size_t kSummBytes = 4096 * 4 + kTicketWords * 4 + static_cast<size_t>(gsim::kFusedArriveCounters) * 128;
 constexpr int kQueryRing = 16;
 constexpr int kPipe = 8; // single queries of one gsim_db_search_each call enqueued ahead of the one being waited for (< kQueryRing)
 
@@ -108,9 +110,25 @@ struct Shard {
     unsigned long long* d_final = nullptr;
     uint32_t* d_final_cb = nullptr;
     uint32_t final_cap = 0;
+    unsigned long long* d_large = nullptr; // k > kSelectCap: the gathered top-k keys (sorted in place), next_pow2(k) entries
+    uint32_t large_cap = 0;
+    gsim::LargeKState* d_lk = nullptr;
     bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)
-    void* d_pub = nullptr;      // single-launch path: table-wide published-candidate list (1 MB)
+    void* d_pub = nullptr;      // single-launch path: the workgroups' published-candidate regions (128 KB each)
+    void* d_hdr = nullptr;      // ... and their headers (64 B each)
     uint32_t* d_summ = nullptr; // single-launch path: per-wave checkpoint summaries (16 KB, zero between queries)
+    // Second lane of the single-launch path (small tables, gsim_db_search_each): its own stream, per-query state and
+    // publish buffers, so that consecutive queries alternate between two streams and the next kernel's workgroups
+    // move in while the previous kernel's closing tail (ticket, header, re-zeroing, end-of-launch bookkeeping) runs.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        gsim::QueryState* d_state = nullptr;
+        void* d_pub = nullptr;
+        void* d_hdr = nullptr;
+        uint32_t* d_summ = nullptr;
+        bool state_dirty = false;
+    } alt;
+    bool alt_ready = false, on_alt = false;
     uint32_t* h_done = nullptr; // single-launch path: pinned words (one per pipeline slot) the kernel stores the query's epoch into
     uint32_t epoch = 0;
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
@@ -209,8 +227,17 @@ int free_shard(Shard& s)
     if (s.d_seg_count) (void) hipFree(s.d_seg_count);
     if (s.d_final) (void) hipFree(s.d_final);
     if (s.d_result) (void) hipFree(s.d_result);
+    if (s.d_large) (void) hipFree(s.d_large);
+    if (s.d_lk) (void) hipFree(s.d_lk);
     if (s.d_pub) (void) hipFree(s.d_pub);
+    if (s.d_hdr) (void) hipFree(s.d_hdr);
     if (s.d_summ) (void) hipFree(s.d_summ);
+    if (s.alt.stream) (void) hipStreamSynchronize(s.alt.stream);
+    if (s.alt.d_state) (void) hipFree(s.alt.d_state);
+    if (s.alt.d_pub) (void) hipFree(s.alt.d_pub);
+    if (s.alt.d_hdr) (void) hipFree(s.alt.d_hdr);
+    if (s.alt.d_summ) (void) hipFree(s.alt.d_summ);
+    if (s.alt.stream) (void) hipStreamDestroy(s.alt.stream);
     if (s.d_dbg) (void) hipFree(s.d_dbg);
     if (s.h_done) (void) hipHostFree(s.h_done);
     if (s.h_pipe) (void) hipHostFree(s.h_pipe);
@@ -272,7 +299,8 @@ int setup_shard(gsim_db* db, Shard& s)
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(s.W) * 4));
     GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
     GSIM_HIP(hipMemset(s.d_state, 0, sizeof(gsim::QueryState))); // the kernels keep it zero between queries
-    GSIM_HIP(hipMalloc(&s.d_pub, static_cast<size_t>(gsim::kFusedPubCap) * 16));
+    GSIM_HIP(hipMalloc(&s.d_pub, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
+    GSIM_HIP(hipMalloc(&s.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
     GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_summ), kSummBytes));
     GSIM_HIP(hipMemset(s.d_summ, 0, kSummBytes));
     GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_done), 64, hipHostMallocDefault));
@@ -305,6 +333,35 @@ int ensure_classic_scratch(Shard& s)
     GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
     s.classic_ready = true;
     return GSIM_OK;
+}
+
+// The second lane's buffers (see Shard::Lane), made on first use.
+int ensure_alt_lane(Shard& s)
+{
+    if (s.alt_ready) return GSIM_OK;
+    GSIM_HIP(set_device(s.device));
+    GSIM_HIP(hipStreamCreateWithFlags(&s.alt.stream, hipStreamNonBlocking));
+    GSIM_HIP(hipMalloc(&s.alt.d_state, sizeof(gsim::QueryState)));
+    GSIM_HIP(hipMemset(s.alt.d_state, 0, sizeof(gsim::QueryState)));
+    GSIM_HIP(hipMalloc(&s.alt.d_pub, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
+    GSIM_HIP(hipMalloc(&s.alt.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
+    GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.alt.d_summ), kSummBytes));
+    GSIM_HIP(hipMemset(s.alt.d_summ, 0, kSummBytes));
+    s.alt_ready = true;
+    return GSIM_OK;
+}
+
+// Make lane `alt` (false: the shard's own) the one every enqueue / wait on the shard uses.
+void use_lane(Shard& s, bool alt)
+{
+    if (alt == s.on_alt) return;
+    std::swap(s.stream, s.alt.stream);
+    std::swap(s.d_state, s.alt.d_state);
+    std::swap(s.d_pub, s.alt.d_pub);
+    std::swap(s.d_hdr, s.alt.d_hdr);
+    std::swap(s.d_summ, s.alt.d_summ);
+    std::swap(s.state_dirty, s.alt.state_dirty);
+    s.on_alt = alt;
 }
 
 int ensure_result_capacity(Shard& s, uint32_t k)
@@ -356,7 +413,7 @@ bool fused_applies(const Shard& s, uint32_t k)
 //
 // Classic path: sample -> scan -> compact -> select.  The query is read by the kernels straight
 // from a pinned ring slot (no upload op) and the last kernel re-zeroes the per-query state (no
-// memset op).  Nothing here synchronises with the host unless k > kSelectCap.
+// memset op).  Nothing here synchronises with the host, whatever k.
 int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
                        float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode, uint32_t pipe_slot)
 {
@@ -422,6 +479,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
     if (fused) {
         gsim::FusedArgs f{};
         f.pub = s.d_pub;
+        f.hdr = s.d_hdr;
+        f.arrive = s.d_summ + 4096 + kTicketWords;
         f.summ = s.d_summ;
         f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k);
         f.tickets = s.d_summ + 4096;
@@ -464,17 +523,25 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
     if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
         GSIM_HIP(gsim::launch_select(a, s.d_final, s.d_final_cb, s.final_cap, row_base, out, s.stream));
     } else {
-        // large k: sort every finalist in global memory (the host reads the count)
-        uint32_t nfinal = 0;
-        GSIM_HIP(hipMemcpyAsync(&nfinal, &s.d_state->nfinal, 4, hipMemcpyDeviceToHost, s.stream));
-        GSIM_HIP(hipStreamSynchronize(s.stream));
-        if (nfinal > s.final_cap) nfinal = s.final_cap;
-        const uint32_t np2 = next_pow2_u32(nfinal ? nfinal : 1);
-        GSIM_HIP(gsim::launch_fill_zero_keys(s.d_final, nfinal, np2, s.stream));
-        GSIM_HIP(gsim::launch_bitonic_global(s.d_final, np2, s.stream));
-        const uint32_t nout = nfinal < k ? nfinal : k;
-        GSIM_HIP(gsim::launch_emit_hits(a, s.d_final, nout, row_base, s.nrows, 1u, out, s.stream));
-        GSIM_HIP(gsim::launch_reset_state(s.d_state, s.stream));
+        // large k: the k-th largest finalist key by a radix select on the device (the finalist count never reaches the
+        // host: nothing here waits), the keys at or above it gathered and sorted in global memory (sized by k)
+        const uint32_t np2 = next_pow2_u32(k);
+        if (np2 > s.large_cap) {
+            if (s.d_large) GSIM_HIP(hipFree(s.d_large));
+            s.d_large = nullptr;
+            s.large_cap = 0;
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_large), static_cast<size_t>(np2) * 8));
+            s.large_cap = np2;
+        }
+        if (!s.d_lk) {
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_lk), sizeof(gsim::LargeKState)));
+            GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
+        }
+        GSIM_HIP(hipMemsetAsync(s.d_large, 0, static_cast<size_t>(np2) * 8, s.stream));
+        GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, s.stream));
+        GSIM_HIP(gsim::launch_bitonic_global(s.d_large, np2, s.stream));
+        GSIM_HIP(gsim::launch_emit_hits(a, s.d_large, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
+        GSIM_HIP(gsim::launch_reset_state(s.d_state, s.d_lk, s.stream));
     }
     if (ev) {
         GSIM_HIP(hipEventRecord(ev[2], s.stream));
@@ -497,6 +564,7 @@ int drain_timing(gsim_db* db, Shard& s)
     if (s.ev_used == 0 && s.bev_used == 0) return GSIM_OK;
     GSIM_HIP(set_device(s.device));
     GSIM_HIP(hipStreamSynchronize(s.stream));
+    if (s.alt_ready) GSIM_HIP(hipStreamSynchronize(s.alt.stream));
     for (uint32_t i = 0; i < s.bev_used; i++) {
         float ms = 0.f;
         GSIM_HIP(hipEventElapsedTime(&ms, s.bev[2 * i], s.bev[2 * i + 1]));
@@ -525,6 +593,13 @@ int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal,
     *ncand = s.h_state->ncand_sum;
     *nfinal = s.h_state->nfinal_sum;
     if (nredo) *nredo = s.h_state->redo_sum;
+    if (s.alt_ready) { // the other lane keeps its own running totals
+        GSIM_HIP(hipStreamSynchronize(s.alt.stream));
+        GSIM_HIP(hipMemcpy(s.h_state, s.alt.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost));
+        *ncand += s.h_state->ncand_sum;
+        *nfinal += s.h_state->nfinal_sum;
+        if (nredo) *nredo += s.h_state->redo_sum;
+    }
     return GSIM_OK;
 }
 
@@ -590,7 +665,7 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         };
         double a, b, c;
         std::fprintf(stderr, "fused phases, us after the first workgroup started (min/avg/max over workgroups):\n");
-        const char* names[] = {"start", "scan-end(w0)", "compacted", "arrived", "sel:all-arrived", "sel:loaded", "sel:ranked", "sel:fenced",
+        const char* names[] = {"start", "scan-end(w0)", "compacted", "published", "sel:all-arrived", "sel:filtered", "sel:ranked", "sel:fenced",
                                "tau-first-seen", "ckpt0-done", "elect-start", "elect-end"};
         for (int i = 0; i < 12; i++) {
             stat(i, 1, &a, &b, &c);
@@ -600,6 +675,8 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "elect-loaded", a, b, c);
         stat(17, 1, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "3/4-ckpt(w0)", a, b, c);
+        stat(23, 1, &a, &b, &c);
+        std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "sel:elected", a, b, c);
         stat(12, 4, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n  end %.2f\n", "wave scan-end", a, b, c, (t[nwg * 24] - t0) / 100.0);
         { // streaming end per workgroup class: blockIdx % 8 (the XCD a block lands on) and blockIdx / 32 (dispatch order)
@@ -642,6 +719,7 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
     }
     if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
+    use_lane(s, false); // the four-kernel pipeline runs on the shard's own lane (one scratch per shard)
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
     int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
     if (rc != GSIM_OK) return rc;
@@ -963,14 +1041,37 @@ int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32
         s.h_pipe_block = blk;
     }
     const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
+    // Small tables: consecutive queries alternate between two lanes (streams with their own per-query state).  A
+    // kernel of the single-launch path holds a CU's LDS, so two never share a CU -- the next one's workgroups move in
+    // as the previous one's leave, and its launch, the previous one's close and the kernel boundary overlap
+    // (1 M rows: ~10 us per query).  From ~16 M rows on the boundary is below 2 % and two streaming kernels at once only
+    // disturb each other.  Not on a stream the caller supplied (its ordering contract is one stream).
+    static const int overlap_on = env_int("GSIM_OVERLAP", 1);
+    static const long long overlap_max = std::getenv("GSIM_OVERLAP_MAX_BYTES") ? std::atoll(std::getenv("GSIM_OVERLAP_MAX_BYTES")) : (2ll << 30);
+    const bool two_lanes = overlap_on && !s.on_alt && s.stream == s.own_stream && fused_applies(s, k) &&
+                           static_cast<long long>(s.nrows * s.W * 4ull) <= overlap_max;
+    if (two_lanes) {
+        const int rc = ensure_alt_lane(s);
+        if (rc != GSIM_OK) return rc;
+    }
+    struct LaneGuard { // whatever happens, the shard leaves on its own lane
+        Shard& s;
+        ~LaneGuard() { use_lane(s, false); }
+    } guard{s};
     uint32_t issued = 0;
+    bool slot_lane[kPipe] = {};
     for (uint32_t done = 0; done < nq; done++) {
         for (; issued < nq && issued - done < static_cast<uint32_t>(kPipe); issued++) {
+            // (the four-kernel pipeline's scratch exists once per shard: queries that take it -- a table whose queries
+            // keep being handed back -- all go through the shard's own lane, one after the other)
+            slot_lane[issued % kPipe] = two_lanes && (issued & 1u) && s.fused_skip == 0 && s.redo_streak == 0;
+            use_lane(s, slot_lane[issued % kPipe]);
             const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta, row_base,
                                          s.h_pipe + (issued % kPipe) * s.h_pipe_block, true, kAuto, issued % kPipe);
             if (rc != GSIM_OK) return rc;
         }
         void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
+        use_lane(s, slot_lane[done % kPipe]);
         const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta, row_base,
                                          out, done % kPipe);
         if (rc != GSIM_OK) return rc;
@@ -1040,12 +1141,25 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
                 cm[j] = static_cast<uint16_t>(common);
                 pc[j] = static_cast<uint16_t>(pd);
             }
-            // top_results_bubble_sort(indices, scores, k): stable, strict '>'
-            for (uint32_t a = 0; a < k && a < n; a++) {
-                for (uint32_t b = n - 1; b > a; b--) {
-                    if (sc[b] > sc[b - 1]) {
-                        std::swap(idx[b], idx[b - 1]);
-                        std::swap(sc[b], sc[b - 1]);
+            // top_results_bubble_sort(indices, scores, k) (fingerprintdb_cuda.cpp:92-103): k passes of a bubble sort with
+            // a strict '>' -- stable, so its first k entries are the first k of a stable descending sort.  That sort is
+            // what runs here (O(n log n) instead of O(k n): k = 1000, F = 8 means 32 k candidates x 1000 passes per
+            // storage and query); the literal bubble sort only when a NaN score (0/0: two empty fingerprints) is
+            // present, for which '>' is not an order and the two would differ.
+            bool has_nan = false;
+            for (uint32_t j = 0; j < n; j++) has_nan = has_nan || sc[j] != sc[j];
+            if (!has_nan) {
+                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return sc[x] > sc[y]; });
+                std::vector<float> sorted(n);
+                for (uint32_t j = 0; j < n; j++) sorted[j] = sc[idx[j]];
+                sc.swap(sorted);
+            } else {
+                for (uint32_t a = 0; a < k && a < n; a++) {
+                    for (uint32_t b = n - 1; b > a; b--) {
+                        if (sc[b] > sc[b - 1]) {
+                            std::swap(idx[b], idx[b - 1]);
+                            std::swap(sc[b], sc[b - 1]);
+                        }
                     }
                 }
             }

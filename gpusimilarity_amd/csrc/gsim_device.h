@@ -30,10 +30,10 @@ struct QueryState {
     uint32_t redo;               // single-launch path gave up (candidate overflow, heavy ties): the gated
                                  // classic kernels behind it run the query; their select kernel clears it
     // --- single-launch path (fused_kernel) ---
-    uint32_t npub;               // candidates published to the table-wide list by finished workgroups
-    uint32_t arrived;            // workgroups that have finished scanning and publishing (ticket)
+    uint32_t npub;               // (unused since round 3: workgroups publish into fixed regions)
+    uint32_t arrived;            // (unused since round 3: the arrival counters live next to the tickets)
     uint32_t sel_done;           // selector workgroups that have written their hits (ticket)
-    uint32_t final_ready;        // small tables: the threshold of the end-of-scan checkpoint has been published
+    uint32_t final_ready;        // (unused since round 3: every selector derives the final threshold itself)
     uint32_t pad1[2];
     // --- not reset per query: running totals for gsim_db_get_timing ---
     unsigned long long ncand_sum;
@@ -70,25 +70,33 @@ struct ScanArgs {
                               // (they are enqueued behind the single-launch path as its fallback)
 };
 
-// ---- single-launch path: scan + publish + select in ONE kernel (small and mid-size tables) ----
-constexpr uint32_t kFusedMaxK = 4096;       // largest k the single-launch path serves
+// ---- single-launch path: scan + publish + select in ONE kernel --------------------------------
+constexpr uint32_t kFusedMaxK = 8192;       // largest k the single-launch path serves
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
-constexpr int kFusedSelectors = 256;        // last-arriving workgroups that run the select (all of them on a 256-CU grid)
-constexpr uint32_t kFusedPubCap = 1u << 16; // entries of the table-wide published-candidate list (16 B each)
+constexpr int kFusedSelectors = 256;        // workgroups of the grid: every one of them ranks its share of the finalists
+constexpr uint32_t kFusedRegion = 4 * kFusedWaveCap; // published entries (16 B each) of one workgroup: its fixed region of the list
+constexpr uint32_t kFusedHeaderBytes = 64;  // per workgroup: {count, sorted flag, the four waves' end-of-scan summaries}
+constexpr uint32_t kFusedArriveCounters = 8; // arrival counters (workgroup b adds to counter b % 8), 128 B apart
 
 struct FusedArgs {
-    void* pub;            // device, kFusedPubCap x 16 B {key, cb, 0}
-    uint32_t* summ;       // device, nwaves score keys: the waves' checkpoint summaries (zero between queries)
+    void* pub;            // device, nwg regions of kFusedRegion x 16 B {key, cb, 0}: what each workgroup publishes
+    void* hdr;            // device, nwg headers of kFusedHeaderBytes
+    uint32_t* arrive;     // device, kFusedArriveCounters counters 128 B apart (zero between queries)
+    uint32_t* summ;       // device, nwaves score keys: the waves' in-loop checkpoint summaries (zero between queries)
     uint32_t summ_keys;   // M: every wave reports its M-th best key (fused_summary_keys), 0 = no checkpoints
     uint32_t* tickets;    // device, kFusedCheckpoints x 9 counters 128 B apart (8 per-group + 1 top), zero between queries
     void* result;         // result block: device memory or device-visible pinned host memory
     uint32_t row_base;
     uint32_t* done_flag;  // NULL, or device-visible pinned host word that receives `epoch` when the block is complete
     uint32_t epoch;
-    uint32_t wait_ticks;     // bound of the grid-wide waits (100 MHz ticks): a few scan times, see fused_kernel
-    uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no checkpoints (no thresholds during the scan)
-    unsigned long long* dbg; // NULL, or 8 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
+    uint32_t wait_ticks;     // bound of the grid-wide wait (100 MHz ticks): a few scan times, see fused_kernel
+    uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints
+    unsigned long long* dbg; // NULL, or 24 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };
+
+// bytes of the three device buffers of the single-launch path for a grid of nwg workgroups
+inline size_t fused_pub_bytes(uint32_t nwg) { return static_cast<size_t>(nwg) * kFusedRegion * 16; }
+inline size_t fused_hdr_bytes(uint32_t nwg) { return static_cast<size_t>(nwg) * kFusedHeaderBytes; }
 
 hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s);
 bool fused_supported(const ScanGeometry& g);
@@ -109,13 +117,24 @@ hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned lon
 // writes {gsim_result_header; gsim_hit[k]}.
 hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, const uint32_t* finalists_cb,
                          uint32_t finalists_cap, uint32_t row_base, void* d_result, hipStream_t s);
+// Large-k path (k > kSelectCap): device state of the radix select (zero between queries).
+struct LargeKState {
+    unsigned long long prefix; // leading bytes of the k-th largest finalist key found so far
+    uint32_t remaining;        // its rank among the finalists that share the prefix
+    uint32_t ticket;
+    uint32_t count;            // keys gathered
+    uint32_t all;              // fewer finalists than k: every finalist is taken
+    uint32_t hist[256];
+};
 // Re-zero the per-query part of the state (large-k path only; the select kernel does it otherwise).
-hipError_t launch_reset_state(QueryState* state, hipStream_t s);
+hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s);
+hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
+                                unsigned long long* out, uint32_t out_cap, hipStream_t s);
 
 // Large-k path (k > kSelectCap): global-memory bitonic sort of all finalists.
 hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s);
 hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s);
-hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, uint32_t nkeys,
+hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, const LargeKState* lk,
                             uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags,
                             void* d_result, hipStream_t s);
 

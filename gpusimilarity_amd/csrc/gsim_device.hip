@@ -4,11 +4,11 @@
 // (fingerprintdb_cuda.cu:228-339: sequence / transform(TanimotoFunctor) /
 // remove_if / sort_by_key over ALL rows).  Two routes, same results bit for bit:
 //
-// Single-launch path (fused_kernel; k <= kFusedMaxK, the usual case): ONE persistent
+// Single-launch path (fused_kernel; k <= kFusedMaxK = 8192, the usual case): ONE persistent
 //   launch streams the table, keeps candidates in LDS, exchanges per-wave top-M score
-//   summaries to raise a table-wide score threshold, publishes the survivors and lets
-//   the last-arriving workgroups rank them -- no grid barrier, no histogram, no scratch
-//   in global memory beyond a 1 MB list.  See the comment above fused_kernel.
+//   summaries to raise a table-wide score threshold, publishes the survivors into
+//   per-workgroup regions and lets every workgroup rank its share of them -- one grid-wide
+//   wait, no histogram, no per-row scratch in global memory.  See the comment above fused_kernel.
 //
 // Four-kernel pipeline (the general route: any k, any width, heavy ties, adversarial
 //   row orders; also what the single launch hands a query back to):
@@ -454,37 +454,41 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
 //      threshold in its own LDS store (kFusedWaveCap slots; compacted in place when the
 //      threshold has risen).  The threshold is an exact 32-bit score key (order_key), 0 at
 //      the start: until the first one arrives every row is stored -- LDS writes only;
-//   2. checkpoints (after 1, 4, 16, ... trips and after 3/4 of them; small tables: one more after
-//      the loop, which the workgroups wait for, bounded, before they publish): every streaming wave
-//      leaves ONE score key in LDS, its M-th best (M ~ 2k / #waves); the workgroup's forwarder wave
-//      copies the four keys to a table-wide array (plain write-through stores) and takes a two-level
-//      ticket; the last arriver's poller wave elects the r-th largest report, r = ceil(k / M), and
-//      publishes it as the new threshold (atomicMax).  Valid because each of the r largest reports
-//      stands for M distinct rows really scanned at or above it: at least k rows score at or above
-//      the threshold, so no top-k row is below it -- and a slot read early or stale only holds a
-//      smaller key, which only lowers the threshold.  The streaming waves never touch global memory
-//      for any of this (one in-order vmcnt: a store or atomic would drain their prefetch);
-//   3. a workgroup that has finished filters its stores against the freshest threshold,
-//      appends the survivors to the table-wide published list (one reservation atomic,
-//      16-byte write-through stores) and takes an arrival ticket.  All but the last
-//      kFusedSelectors arrivers exit at once (on a 256-CU grid all of them are selectors);
-//   4. the selectors wait until every workgroup has arrived (bounded by a few scan times of wall
-//      clock: on a GPU shared with another queue part of the grid may not have started while the
-//      waiters hold their CUs -- the query then goes to the four-kernel pipeline, which never
-//      waits), load the published list (a few thousand rows) into LDS and each ranks the rows it
-//      owns (hash of the row) by counting larger keys -- the output slot of a hit is its rank, keys
+//   2. in-loop checkpoints (after 1, 4, 16, ... trips and after 3/4 of them): every streaming wave leaves ONE
+//      score key in LDS, its M-th best (M ~ 2k / #waves); the workgroup's forwarder wave copies the four keys to a
+//      table-wide array (plain write-through stores) and takes a two-level ticket; the last arriver's poller wave
+//      elects the r-th largest report, r = ceil(k / M), and publishes it as the new threshold (atomicMax).  Valid
+//      because each of the r largest reports stands for M distinct rows really scanned at or above it: at least k
+//      rows score at or above the threshold, so no top-k row is below it -- and a slot read early or stale only
+//      holds a smaller key, which only lowers the threshold.  The streaming waves never touch global memory for any
+//      of this (one in-order vmcnt: a store or atomic would drain their prefetch);
+//   3. a workgroup that has finished streaming drops what lies below the freshest in-loop threshold and publishes
+//      the rest into ITS OWN fixed region of the list -- no reservation, no exchange before it; in canonical order
+//      when there are few rows (the usual case: a local rank count) -- together with a 64-byte header: the count
+//      and its four waves' END-OF-SCAN reports (each wave's M-th best 64-bit key over all its rows).  Write-through
+//      stores, one wait, one arrival atomic (eight counters) that nobody waits for;
+//   4. every workgroup then becomes a selector.  It waits until all have arrived -- the ONE grid-wide wait of the
+//      kernel (round 2 had two: an end-of-scan threshold exchange on small tables, then this one); bounded by a few
+//      scan times of wall clock: on a GPU shared with another queue part of the grid may not have started while the
+//      waiters hold their CUs, the query then goes to the four-kernel pipeline, which never waits -- and requests, in
+//      one round trip, every workgroup's header and the first 16 entries of every region.  From the 4 x #workgroups
+//      end-of-scan reports every selector derives the SAME final threshold (fused_final_threshold: the r-th largest
+//      report as a 64-bit key -- it carries the row index, so it also cuts through groups of equal scores), keeps the
+//      published rows at or above it in LDS (regions whose prefix is exhausted are read on: clustered rows, ties) and
+//      ranks the rows it owns (hash of the row) by counting larger keys -- the output slot of a hit is its rank, keys
 //      are unique -- writing the hits of rank < k straight into the result block;
-//   5. the last selector writes the header and, for the synchronous API, stores the query's epoch
-//      into a pinned host word the caller polls -- the hits (in pinned host memory) are complete
-//      when it changes, without waiting for the kernel's end-of-launch bookkeeping -- and then
-//      re-zeroes the per-query state.
+//   5. the last selector writes the header and, for the synchronous API, stores the query's epoch into a pinned host
+//      word the caller polls -- the hits (in pinned host memory) are complete when it changes, without waiting for
+//      the kernel's end-of-launch bookkeeping -- and then re-zeroes the per-query state.
 //
-// Whatever the path cannot hold (a store that stays full after compaction, more published
-// rows than a selector's LDS takes: heavy ties, rows in ascending score order) sets
-// QueryState::redo and header flag 2; the four-kernel pipeline then runs the query.
-constexpr int kFusedPubLds = 16384;  // published rows a selector ranks (LDS)
-constexpr int kFusedMineCap = 2048;  // ... of which it owns at most this many
-constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder/elector, poller)
+// Whatever the path cannot hold (a wave's store that stays full after compaction, more than 16 Ki finalists or 2 Ki
+// owned by one selector: extreme ties, rows in ascending score order) sets QueryState::redo and header flag 2; the
+// four-kernel pipeline then runs the query.
+constexpr int kFusedFinalLds = 16384;   // finalists a selector ranks (LDS)
+constexpr int kFusedMineCap = 2048;     // ... of which it owns at most this many
+constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder, poller/elector)
+constexpr uint32_t kFusedPrefix = 16;   // entries of every region a selector requests before it knows the region's count
+constexpr uint32_t kFusedSortCap = 256; // a workgroup with up to this many rows publishes them in canonical order
 
 struct FusedShared {
     union {
@@ -493,11 +497,20 @@ struct FusedShared {
             uint32_t cb[kScanBlock / 64][kFusedWaveCap];
         } store;
         struct { // selectors
-            u64 fkey[kFusedPubLds];
-            uint32_t mine_idx[kFusedMineCap];
-            uint32_t mine_cb[kFusedMineCap];
+            u64 fkey[kFusedFinalLds];
+            union {
+                struct {
+                    uint32_t idx[kFusedMineCap];
+                    uint32_t cb[kFusedMineCap];
+                } mine;
+                u64 rep[(kScanBlock / 64) * kFusedSelectors]; // the waves' end-of-scan reports, during the election only
+            } u;
         } sel;
     };
+    uint32_t hist[256];           // election: digit histogram
+    uint32_t rn[kFusedSelectors]; // per region: entries | sorted << 31
+    uint16_t cont[kFusedSelectors]; // regions with more finalists than the requested prefix holds
+    u64 wfin[kScanBlock / 64];    // the streaming waves' end-of-scan reports (M-th best 64-bit key)
     uint32_t tau;       // workgroup's copy of the score-key threshold (monotone; kept fresh by the service wave)
     uint32_t overflow;  // a wave's store overflowed
     uint32_t nemit;     // rows stored by the workgroup (statistics)
@@ -506,7 +519,8 @@ struct FusedShared {
     uint32_t ck_cnt[kFusedCheckpoints];             // streaming waves that have left their summary for checkpoint j
     uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
     uint32_t wcount[kScanBlock / 64];
-    uint32_t base, ticket, nmine, ok;
+    uint32_t nfin, nmine, ncont, ok, ticket;
+    uint32_t sel_digit, sel_rem, sel_pop;
 };
 
 __device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
@@ -562,19 +576,11 @@ struct FusedSchedule {
     {
         return last_ck + (trip(last_ck) != 0xFFFFFFFFu ? 1u : 0u);
     }
-    // Small tables: a threshold takes ~12 us from checkpoint to every workgroup (tickets, election,
-    // polls) and the table is over in 20-60: the last in-loop threshold is drawn from a small part
-    // of the rows and would publish far more than k of them.  Such tables get one more checkpoint
-    // AFTER the loop, over all rows, and the workgroups wait (bounded) for its threshold before
-    // they publish: one more hop, ~1.7 k rows published instead of 10-20 k.
-    __device__ __forceinline__ bool final_wait() const { return min_trips < 64; }
     // (The workgroups do not finish together: the classes blockIdx % 8 = {0,1,2,7} and {3,4,5,6} -- two halves of
     // the chip -- end 3-4 % apart at 100 M rows, 10 % at 10 M, and WHICH half is the slow one changes from query to
-    // query: contention, not a property of an XCD.  Two remedies were built and measured, neither is kept:
-    // per-class shares of the table steered by the previous queries' times do not converge (the slow half flips);
-    // handing out the table's last eighth dynamically -- units of workgroup-trips from a table-wide counter, fetched
-    // by the forwarder wave into an LDS ring -- streamed that tail at ~4.4 TB/s against 7.4 TB/s under the fixed
-    // assignment and made the query 5 % slower at 100 M rows, 15 % at 10 M.  DESIGN.md 7.)
+    // query: contention, not a property of an XCD.  Remedies that were built and measured, none kept: per-class
+    // shares of the table steered by the previous queries' times; handing out the table's tail dynamically; a shared
+    // last quarter.  DESIGN.md 7.)
 };
 
 // A streaming wave's view.  Its loop touches global memory only through the table loads: the
@@ -608,25 +614,27 @@ struct FusedFilter {
         }
     }
 
-    // The M-th best score key of this wave's store -> the workgroup's LDS summary: "this wave holds M
-    // distinct rows scoring at least this".  Every lane keeps the best four of the entries it visits,
-    // then M rounds of wave-wide max + pop (a lane that holds more than four of the wave's M best
-    // under-reports: a smaller key, for which the statement still holds).
-    __device__ __forceinline__ void write_summary(int lane)
+    // The M-th best 64-bit key of this wave's store: "this wave holds M distinct rows at or above this key in the
+    // canonical order" (0: fewer than M rows).  Every lane keeps the best four of the entries it visits, then M
+    // rounds of wave-wide max + pop (a lane that holds more than four of the wave's M best under-reports: a
+    // smaller key, for which the statement still holds).
+    __device__ __forceinline__ u64 mth_best(int lane) const
     {
-        uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         for (uint32_t i = lane; i < staged; i += 64) {
-            const uint32_t v = static_cast<uint32_t>(skey[i] >> 32);
+            const u64 v = skey[i];
             if (v > t3) {
                 t3 = v;
-                if (t3 > t2) { const uint32_t x = t2; t2 = t3; t3 = x; }
-                if (t2 > t1) { const uint32_t x = t1; t1 = t2; t2 = x; }
-                if (t1 > t0) { const uint32_t x = t0; t0 = t1; t1 = x; }
+                if (t3 > t2) { const u64 x = t2; t2 = t3; t3 = x; }
+                if (t2 > t1) { const u64 x = t1; t1 = t2; t2 = x; }
+                if (t1 > t0) { const u64 x = t0; t0 = t1; t1 = x; }
             }
         }
-        uint32_t mth = 0;
+        u64 mth = 0;
         for (uint32_t r = 0; r < M; r++) {
-            mth = wave_max_u32(t0);
+            const uint32_t hi = wave_max_u32(static_cast<uint32_t>(t0 >> 32));
+            const uint32_t lo = wave_max_u32(static_cast<uint32_t>(t0 >> 32) == hi ? static_cast<uint32_t>(t0) : 0u);
+            mth = (static_cast<u64>(hi) << 32) | lo;
             const u64 b = __ballot(t0 == mth);
             if (lane == __builtin_ctzll(b)) {
                 t0 = t1;
@@ -635,19 +643,22 @@ struct FusedFilter {
                 t3 = 0;
             }
         }
-        if (lane == 0) sh->wsum[wv] = mth; // 0: fewer than M rows so far
+        return mth;
     }
 
     // called once per trip of the streaming loop with the number of chunks this wave has finished
     __device__ __forceinline__ void checkpoint(uint32_t trips_done, int lane)
     {
         if (trips_done != next_ck) return;
-        write_summary(lane);
-        if (lane == 0) atomicAdd(&sh->ck_cnt[ck_j], 1u); // (LDS, after the summary: a wave's LDS operations execute in order)
+        const u64 mth = mth_best(lane);
+        if (lane == 0) {
+            sh->wsum[wv] = static_cast<uint32_t>(mth >> 32); // the score key: 0 = fewer than M rows so far
+            atomicAdd(&sh->ck_cnt[ck_j], 1u); // (LDS, after the summary: a wave's LDS operations execute in order)
+        }
         if (dbg && lane == 0 && wv == 0 && ck_j == 0) dbg[9] = wall_clock64();
         if (dbg && lane == 0 && wv == 0) {
             if (ck_j + 1 == sched.count()) dbg[17] = wall_clock64(); // the last in-loop checkpoint (3/4 of the trips)
-            else if (ck_j >= 1 && ck_j <= 6) dbg[17 + ck_j] = wall_clock64(); // after 4, 16, 64, 256, 1024, 4096 trips
+            else if (ck_j >= 1 && ck_j <= 5) dbg[17 + ck_j] = wall_clock64(); // after 4, 16, 64, 256, 1024 trips
         }
         ck_j++;
         next_ck = M ? sched.trip(ck_j) : 0xFFFFFFFFu;
@@ -706,7 +717,7 @@ struct FusedFilter {
     }
 };
 
-// The election: every wave reported its M-th best score key, so each of the r = ceil(k / M) largest
+// The in-loop election: every wave reported its M-th best score key, so each of the r = ceil(k / M) largest
 // reports stands for M distinct rows at or above it: at least k rows score at or above the r-th
 // largest report, which is published as the threshold (to 15 leading bits, rounded down).  One wave.
 __device__ __forceinline__ void fused_elect(FusedShared& sh, QueryState* st, uint32_t* summ, uint32_t nvals, uint32_t k,
@@ -772,35 +783,29 @@ __device__ __forceinline__ void fused_elect(FusedShared& sh, QueryState* st, uin
     if (dbg && lane == 0) dbg[11] = wall_clock64();
 }
 
-// The service waves: everything of the threshold protocol that touches global memory.
+// The service waves: everything of the in-loop threshold protocol that touches global memory.  Both leave when the
+// workgroup's streaming waves are done (scan_done), so neither can outlive the scan.
 //
 // Wave 4 (forwarder): when the four streaming waves have left their summaries for checkpoint j,
 // copies them (4 keys) to the table-wide array and takes the checkpoint's ticket -- two
 // levels, one counter per XCD-sized group of workgroups (b % 8) and one on top, 128 bytes apart:
-// 256 arrivals on one word serialise at ~12 ns each.  The last arriver runs the election.  The
+// 256 arrivals on one word serialise at ~12 ns each.  The last arriver hands the election to its poller.  The
 // stores are not waited for: a slot read before its store lands holds smaller keys (older or
 // zero), which only lowers the threshold.
-// Wave 5 (poller): keeps the workgroup's LDS copy of the table-wide threshold fresh; it polls
-// every microsecond at first (a small table is over in 20) and backs off to one poll per ~16 us.
-__device__ __forceinline__ void fused_forwarder(FusedShared& sh, QueryState* st, const FusedArgs& fa, const FusedSchedule& sched,
-                                                int lane)
+// Wave 5 (poller): keeps the workgroup's LDS copy of the table-wide threshold fresh -- it polls
+// every microsecond at first (a small table is over in 20) and backs off to one poll per ~60 us -- and runs the
+// elections its forwarder wins.
+__device__ __forceinline__ void fused_forwarder(FusedShared& sh, const FusedArgs& fa, const FusedSchedule& sched, int lane)
 {
-    const uint32_t M = fa.summ_keys;
-    if (M == 0) return;
-    const bool final_wait = sched.final_wait();
-    const uint32_t nloop = sched.count(), nck = nloop + (final_wait ? 1u : 0u);
+    if (fa.summ_keys == 0 || (fa.xflags & 2u)) return;
+    const uint32_t nck = sched.count();
     const uint32_t nwg = gridDim.x;
     const uint32_t x = blockIdx.x % 8u;
     const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
-    for (uint32_t j = 0, spins = 0; j < nck; spins++) {
+    for (uint32_t j = 0; j < nck;) {
         if (__hip_atomic_load(&sh.ck_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != kScanBlock / 64) {
-            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) {
-                // the streaming loop is over: in-loop checkpoints it did not reach no longer matter
-                if (!final_wait) break;
-                if (j < nloop) j = nloop;
-                continue;
-            }
-            if (spins > (1u << 24)) break;
+            // the streaming loop is over: checkpoints it did not reach no longer matter
+            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
             // (the early checkpoints are a few microseconds apart; from the fourth on this wave naps ~1.7 us at a time:
             // a wave that polls LDS every 64 clocks takes issue slots from the streaming wave on its SIMD)
             if (j >= 3) __builtin_amdgcn_s_sleep(64);
@@ -818,39 +823,83 @@ __device__ __forceinline__ void fused_forwarder(FusedShared& sh, QueryState* st,
             if (lane == 0) t = atomicAdd(&tk[8 * 32], 1u);
             t = __builtin_amdgcn_readfirstlane(t);
             if (t == ngroups - 1 && lane == 0) // the poller wave runs the election: this wave stays free for the next checkpoint
-                __hip_atomic_store(&sh.elect_req, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicMax(&sh.elect_req, j + 1);
         }
         j++;
     }
 }
 
-__device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, const FusedArgs& fa, const FusedSchedule& sched,
-                                             uint32_t nwaves, uint32_t k, int lane, u64* dbg)
+__device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, const FusedArgs& fa, uint32_t nwaves, uint32_t k,
+                                             int lane, u64* dbg)
 {
-    const bool final_wait = fa.summ_keys != 0 && sched.final_wait();
-    const uint32_t jfinal = sched.count() + 1; // elect_req value of the end-of-scan checkpoint
-    for (uint32_t spins = 0; spins < (1u << 24); spins++) {
+    for (uint32_t spins = 0;; spins++) {
         const uint32_t g = agent_load(&st->gtau);
         if (lane == 0 && g > __hip_atomic_load(&sh.tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.tau, g);
-        if (final_wait && agent_load(&st->final_ready)) return;
         // a poll every ~2 us at first, every ~5 us from the 64th on, every ~60 us from the 512th on
         const uint32_t naps = spins < 512u ? 1u : 16u;
         for (uint32_t i = 0; i < naps; i++) {
-            if (!final_wait && __hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
-            const uint32_t req = __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (req) {
-                if (lane == 0) __hip_atomic_store(&sh.elect_req, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
-                if (final_wait && req == jfinal) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the threshold is out before the flag
-                    if (lane == 0) __hip_atomic_store(&st->final_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-            }
+            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
+            uint32_t req = 0; // (consumed with an exchange: a request stored between a plain load and a plain clear would be lost)
+            if (lane == 0 && __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) req = atomicExch(&sh.elect_req, 0u);
+            req = __builtin_amdgcn_readfirstlane(req);
+            if (req && fa.summ_keys) fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
             if (spins < 64u) __builtin_amdgcn_s_sleep(8); // (units of 64 clocks: ~0.2 us; a small table is over in 20-50 us)
             else __builtin_amdgcn_s_sleep(127);                    // ~3.4 us
         }
     }
+}
+
+// The selectors' final threshold: the r-th largest of the nv end-of-scan reports in sh.sel.u.rep (each the M-th best
+// 64-bit key of one wave over ALL its rows), r = ceil(k / M), as a lower bound of at least 16 leading bits.  Valid as
+// the in-loop thresholds are (each of the r largest reports stands for M distinct rows at or above it in the canonical
+// order), and because the keys carry the row index it also cuts through ties: of a group of equal scores only the rows
+// that can still reach the top k stay above it.  Radix descent, 8 bits per pass, by the whole workgroup (256 threads:
+// an LDS digit histogram, wave 0 finds the digit); it stops early once at most eight reports share the prefix found so
+// far (no ties: two passes), and goes through all 64 bits only when many reports do -- heavy ties.  Every selector
+// computes the same value from the same reports.  Returns the threshold; all 256 threads must call.
+__device__ __forceinline__ u64 fused_final_threshold(FusedShared& sh, uint32_t nv, uint32_t r, int tid)
+{
+    u64 prefix = 0;
+    uint32_t remaining = r;
+    int pass = 0;
+#pragma unroll 1
+    for (; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        sh.hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < nv; i += kScanBlock) {
+            const u64 key = sh.sel.u.rep[i];
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t h[4];
+            uint32_t s4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                h[i] = sh.hist[tid * 4 + i];
+                s4 += h[i];
+            }
+            uint32_t bin, cnt;
+            threshold_from_counts<4>(h, s4, remaining, tid, bin, cnt);
+            if (tid == 0) {
+                const uint32_t pop = sh.hist[bin];
+                sh.sel_digit = bin;
+                sh.sel_pop = pop;
+                sh.sel_rem = remaining - (cnt - pop); // rank of the wanted report inside the digit's bin (>= 1)
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sh.sel_digit;
+        remaining = sh.sel_rem;
+        const uint32_t pop = sh.sel_pop;
+        if (pass == 0 && sh.sel_digit == 0) return 0ull; // fewer than r non-zero reports: no threshold
+        if (pass >= 1 && pop <= 8u) {
+            pass++;
+            break;
+        }
+    }
+    return pass >= 8 ? prefix : prefix << (64 - 8 * pass);
 }
 
 template <int LPR, int U>
@@ -879,14 +928,15 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const u64 nfull = a.nrows / CHR;    // full chunks
     sched.init(static_cast<uint32_t>(nfull / g.nwaves));
     if (wv == kScanBlock / 64) {
-        fused_forwarder(sh, st, fa, sched, lane);
+        fused_forwarder(sh, fa, sched, lane);
         return;
     }
     if (wv == kScanBlock / 64 + 1) {
-        fused_poller(sh, st, fa, sched, g.nwaves, a.k, lane, dbg);
+        fused_poller(sh, st, fa, g.nwaves, a.k, lane, dbg);
         return;
     }
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wv);
+    const uint32_t nwg = gridDim.x;
 
     const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
     FusedFilter f;
@@ -894,7 +944,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.st = st;
     f.skey = sh.store.key[wv];
     f.scb = sh.store.cb[wv];
-    f.M = (fa.xflags & 2u) ? 0u : fa.summ_keys;
+    f.M = fa.summ_keys;
     f.wv = static_cast<uint32_t>(wv);
     f.w = w;
     f.k = a.k;
@@ -907,15 +957,10 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.store_off = false;
     f.sched = sched;
     f.ck_j = 0;
-    f.next_ck = f.M ? sched.trip(0) : 0xFFFFFFFFu;
+    f.next_ck = (f.M && !(fa.xflags & 2u)) ? sched.trip(0) : 0xFFFFFFFFu;
     f.dbg = dbg;
     scan_rows<LPR, U>(a, g, f, q, w, lane);
-    const bool final_wait = f.M != 0 && sched.final_wait();
-    if (final_wait) { // the end-of-scan checkpoint: this wave's M-th best over all its rows
-        f.write_summary(lane);
-        if (lane == 0) atomicAdd(&sh.ck_cnt[sched.count()], 1u);
-    }
-    if (lane == 0) atomicAdd(&sh.scan_done, 1u);
+    if (lane == 0) atomicAdd(&sh.scan_done, 1u); // (the service waves leave)
     if (f.has_cutoff) {
         const uint32_t tot = wave_sum(f.kept);
         if (lane == 0 && tot) atomicAdd(&st->kept, static_cast<u64>(tot));
@@ -923,125 +968,189 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (dbg && lane == 0) dbg[12 + wv] = wall_clock64();
     if (dbg && lane == 0 && wv == 0) dbg[1] = wall_clock64();
 
-    // ---- 3. publish this workgroup's survivors ----------------------------------------------
-    if (final_wait) {
-        if (wv == 0 && lane == 0) {
-            const unsigned long long t_wait = wall_clock64(); // (bounded as the selectors' wait below)
-            for (uint32_t spins = 0; agent_load(&st->final_ready) == 0; spins++) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((spins & 63u) == 63u && wall_clock64() - t_wait > fa.wait_ticks) break;
-            }
-        }
-        __syncthreads(); // (released once the service waves have exited too)
-    }
+    // ---- 3. publish: this workgroup's survivors and its four end-of-scan reports ---------------
+    // No exchange precedes it: the rows at or above the freshest in-loop threshold go into the workgroup's own region
+    // of the list (no reservation), in canonical order when there are few, and the selectors derive the final
+    // threshold themselves from the reports of all workgroups.
     f.refresh(agent_load(&st->gtau), lane);
     if (!f.store_off) f.compact_store(lane);
-    if (lane == 0) {
-        sh.wcount[wv] = f.store_off ? 0u : f.staged;
-        if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
-    }
-    __syncthreads();
-    GSIM_STAMP(2);
-    const uint32_t nwg = gridDim.x;
-    if (tid == 0) {
-        uint32_t tot = 0;
-        for (int i = 0; i < kScanBlock / 64; i++) tot += sh.wcount[i];
-        uint32_t base = 0;
-        if (tot) base = atomicAdd(&st->npub, tot);
-        if (sh.overflow || base + tot > kFusedPubCap) {
-            atomicOr(&st->redo, 1u);
-            base = kFusedPubCap; // nothing is stored
-        }
-        sh.base = base;
-        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit));
-    }
-    __syncthreads();
     {
-        uint32_t off = sh.base;
-        for (int i = 0; i < wv; i++) off += sh.wcount[i];
-        if (sh.base < kFusedPubCap && !f.store_off) {
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, kFusedPubCap * 16u, 0x00020000);
-            for (uint32_t i = lane; i < f.staged; i += 64) {
-                const u64 key = f.skey[i];
-                const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
-                __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, (off + i) * 16u, 0, /*sc1: write-through*/ 16);
+        const u64 fin = (f.M && !f.store_off) ? f.mth_best(lane) : 0ull;
+        if (lane == 0) {
+            sh.wfin[wv] = fin;
+            sh.wcount[wv] = f.store_off ? 0u : f.staged;
+            if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
+        }
+    }
+    __syncthreads(); // (released once the service waves have exited too)
+    GSIM_STAMP(2);
+    const bool bad = __hip_atomic_load(&sh.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+    uint32_t ntot = 0, off = 0;
+#pragma unroll
+    for (int i = 0; i < kScanBlock / 64; i++) {
+        const uint32_t c = sh.wcount[i];
+        off += i < wv ? c : 0u;
+        ntot += c;
+    }
+    if (bad) ntot = 0;
+    const bool sorted = ntot <= kFusedSortCap;
+    {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            static_cast<unsigned char*>(fa.pub) + static_cast<size_t>(blockIdx.x) * (kFusedRegion * 16u), 0, kFusedRegion * 16u, 0x00020000);
+        const uint32_t mine_n = bad ? 0u : f.staged;
+        for (uint32_t i = lane; i < mine_n; i += 64) {
+            const u64 key = f.skey[i];
+            uint32_t pos = off + i;
+            if (sorted) { // canonical position inside the workgroup: the number of larger keys (keys are unique)
+                pos = 0;
+#pragma unroll 1
+                for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
+                    const uint32_t cnt = sh.wcount[w2];
+                    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.store.key[w2]);
+                    for (uint32_t j = 0; j < cnt; j += 2) {
+                        const ulonglong2 kk = k2[j >> 1];
+                        pos += kk.x > key ? 1u : 0u;
+                        pos += (j + 1 < cnt && kk.y > key) ? 1u : 0u;
+                    }
+                }
             }
+            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
+        }
+        if (tid < 3) { // the header: {entries, sorted, 0, 0}, {report 0, report 1}, {report 2, report 3}
+            const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
+            const u64 r0 = tid == 0 ? (static_cast<u64>(sorted ? 1u : 0u) << 32 | ntot) : sh.wfin[2 * tid - 2];
+            const u64 r1 = tid == 0 ? 0ull : sh.wfin[2 * tid - 1];
+            const u32x4 hv{static_cast<uint32_t>(r0), static_cast<uint32_t>(r0 >> 32), static_cast<uint32_t>(r1), static_cast<uint32_t>(r1 >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(hv, hrsrc, blockIdx.x * kFusedHeaderBytes + tid * 16u, 0, /*sc1*/ 16);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries are out
     __syncthreads();
-    const uint32_t nsel = nwg < static_cast<uint32_t>(kFusedSelectors) ? nwg : static_cast<uint32_t>(kFusedSelectors);
-    uint32_t r; // this workgroup's selector number
-    if (nsel == nwg) {
-        // every workgroup selects (any grid of up to kFusedSelectors workgroups, i.e. always on 256 CUs): the
-        // arrival needs no ticket, only the count -- an atomic nobody waits for
-        if (tid == 0) __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r = blockIdx.x;
-        GSIM_STAMP(3);
-    } else {
-        if (tid == 0) sh.ticket = atomicAdd(&st->arrived, 1u);
-        __syncthreads();
-        GSIM_STAMP(3);
-        const uint32_t ticket = sh.ticket;
-        if (ticket + nsel < nwg) return; // not one of the last arrivers
-        r = ticket - (nwg - nsel);
-    }
-
-    // ---- 4. select (the last nsel arrivers) -------------------------------------------------
     if (tid == 0) {
+        if (bad) atomicOr(&st->redo, 1u);
+        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit));
+        // the arrival: eight counters (b % 8), an atomic nobody waits for
+        __hip_atomic_fetch_add(&fa.arrive[(blockIdx.x % kFusedArriveCounters) * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    GSIM_STAMP(3);
+
+    // ---- 4. select: every workgroup of the grid (fused_supported: at most kFusedSelectors) ------
+    const uint32_t nsel = nwg, r = blockIdx.x;
+    if (wv == 0) {
         uint32_t ok = 1;
         // On a GPU this kernel has to itself the wait is the spread of the streaming end times.  When another queue
         // holds part of the CUs, workgroups of this grid may not have started yet and will not while the waiters keep
         // theirs: after fa.wait_ticks (a few scan times) without the last arrival the query goes to the classic
         // kernels, which never wait.
         const unsigned long long t_wait = wall_clock64();
-        for (uint32_t spins = 0; agent_load(&st->arrived) < nwg; spins++) {
+        for (uint32_t spins = 0;; spins++) {
+            uint32_t c = 0;
+            if (lane < static_cast<int>(kFusedArriveCounters)) c = agent_load(&fa.arrive[lane * 32]);
+            if (wave_sum_dpp(c) >= nwg) break;
             __builtin_amdgcn_s_sleep(2);
             if ((spins & 255u) == 255u && wall_clock64() - t_wait > fa.wait_ticks) {
                 ok = 0;
-                atomicOr(&st->redo, 1u);
+                if (lane == 0) atomicOr(&st->redo, 1u);
                 break;
             }
         }
-        sh.ok = ok;
-        sh.nmine = 0;
+        if (lane == 0) {
+            sh.ok = (ok && agent_load(&st->redo) == 0) ? 1u : 0u; // (one reader: the value is the same for the whole workgroup)
+            sh.nfin = 0;
+            sh.nmine = 0;
+            sh.ncont = 0;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     GSIM_STAMP(4);
-    // the first 2048 published rows are requested before their count is known (the list has room)
-    constexpr int PL = 8; // published entries in flight per thread
-    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, kFusedPubCap * 16u, 0x00020000);
-    u32x4 e[PL];
+    // ONE round trip: the header of region `tid` and the first kFusedPrefix entries of every region are requested
+    // together, before anything is known about them (regions hold last query's rows beyond their count).
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, nwg * (kFusedRegion * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
+    constexpr int PL = static_cast<int>(kFusedPrefix);
+    u32x4 e[PL], hd[3];
 #pragma unroll
-    for (int u = 0; u < PL; u++)
-        e[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (u * kScanBlock + tid) * 16u, 0, /*sc1*/ 16);
-    const uint32_t npub = agent_load(&st->npub);
-    bool good = sh.ok && agent_load(&st->redo) == 0 && npub <= static_cast<uint32_t>(kFusedPubLds);
-    if (good) {
-        for (uint32_t i0 = 0; i0 < npub; i0 += kScanBlock * PL) {
+    for (int u = 0; u < 3; u++) hd[u] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, tid * kFusedHeaderBytes + u * 16u, 0, /*sc1*/ 16);
 #pragma unroll
-            for (int u = 0; u < PL; u++) {
-                const uint32_t i = i0 + u * kScanBlock + tid;
-                if (i < npub) {
-                    sh.sel.fkey[i] = (static_cast<u64>(e[u].y) << 32) | e[u].x;
-                    const uint32_t row = ~e[u].x;
-                    if (((row * 2654435761u) >> 16) % nsel == r) { // this selector ranks it
-                        const uint32_t mp = atomicAdd(&sh.nmine, 1u);
-                        if (mp < static_cast<uint32_t>(kFusedMineCap)) {
-                            sh.sel.mine_idx[mp] = i;
-                            sh.sel.mine_cb[mp] = e[u].z;
-                        }
-                    }
+    for (int u = 0; u < PL; u++) { // entry (u * 256 + tid): region (.. / 16), index (.. % 16); regions past the grid read as zeros
+        const uint32_t ent = static_cast<uint32_t>(u * kScanBlock + tid);
+        e[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (ent / kFusedPrefix) * (kFusedRegion * 16u) + (ent % kFusedPrefix) * 16u, 0, /*sc1*/ 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sh.rn[tid] = static_cast<uint32_t>(tid) < nwg ? ((hd[0].x < kFusedRegion ? hd[0].x : kFusedRegion) | (hd[0].y ? 0x80000000u : 0u)) : 0u;
+    if (static_cast<uint32_t>(tid) < nwg) {
+        sh.sel.u.rep[4 * tid + 0] = (static_cast<u64>(hd[1].y) << 32) | hd[1].x;
+        sh.sel.u.rep[4 * tid + 1] = (static_cast<u64>(hd[1].w) << 32) | hd[1].z;
+        sh.sel.u.rep[4 * tid + 2] = (static_cast<u64>(hd[2].y) << 32) | hd[2].x;
+        sh.sel.u.rep[4 * tid + 3] = (static_cast<u64>(hd[2].w) << 32) | hd[2].z;
+    }
+    __syncthreads();
+    bool good = sh.ok != 0; // (not good: headers and regions may be stale -- nothing below is used, the query is handed back)
+    u64 tauf = ~0ull;
+    if (good) tauf = 0;
+    if (good && fa.summ_keys) tauf = fused_final_threshold(sh, nwg * (kScanBlock / 64), (a.k + fa.summ_keys - 1) / fa.summ_keys, tid);
+    if (dbg && tid == 0) dbg[23] = wall_clock64();
+    // finalists = the published rows at or above the final threshold -> LDS; the rows this selector owns (hash of the
+    // row) are noted with their popcounts
+    auto take = [&](bool in, const u32x4& ent) {
+        const u64 key = (static_cast<u64>(ent.y) << 32) | ent.x;
+        const bool pass = in && key >= tauf;
+        const u64 m = __ballot(pass);
+        if (m == 0) return false;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&sh.nfin, static_cast<uint32_t>(__popcll(m)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t slot = base + lane_rank(m);
+        if (pass && slot < static_cast<uint32_t>(kFusedFinalLds)) {
+            sh.sel.fkey[slot] = key;
+            const uint32_t row = ~ent.x;
+            if (((row * 2654435761u) >> 16) % nsel == r) { // this selector ranks it
+                const uint32_t mp = atomicAdd(&sh.nmine, 1u);
+                if (mp < static_cast<uint32_t>(kFusedMineCap)) {
+                    sh.sel.u.mine.idx[mp] = slot;
+                    sh.sel.u.mine.cb[mp] = ent.z;
                 }
             }
-            if (i0 + kScanBlock * PL < npub) { // (rare: more than 2048 published rows)
+        }
+        return pass;
+    };
 #pragma unroll
-                for (int u = 0; u < PL; u++)
-                    e[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (i0 + kScanBlock * PL + u * kScanBlock + tid) * 16u, 0, /*sc1*/ 16);
+    for (int u = 0; u < PL; u++) {
+        const uint32_t ent = static_cast<uint32_t>(u * kScanBlock + tid);
+        const uint32_t gi = ent / kFusedPrefix, idx = ent % kFusedPrefix;
+        const uint32_t rnv = sh.rn[gi % kFusedSelectors]; // (gi < 256 always: 16 x 256 entries)
+        const uint32_t n_g = rnv & 0x7FFFFFFFu;
+        const bool pass = take(idx < n_g, e[u]);
+        // more rows of this region may qualify: its list is longer than the prefix and either not in order or still
+        // above the threshold at the prefix's end
+        if (good && idx == kFusedPrefix - 1 && n_g > kFusedPrefix && (!(rnv >> 31) || pass)) {
+            const uint32_t c = atomicAdd(&sh.ncont, 1u);
+            sh.cont[c] = static_cast<uint16_t>(gi);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t nc = good ? sh.ncont : 0u;
+        for (uint32_t ci = 0; ci < nc; ci++) { // (clustered rows, ties, unsorted regions: rare)
+            const uint32_t gi = sh.cont[ci];
+            const uint32_t n_g = sh.rn[gi] & 0x7FFFFFFFu;
+            for (uint32_t i0 = kFusedPrefix; i0 < n_g; i0 += kScanBlock * 4) {
+                u32x4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    x[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, gi * (kFusedRegion * 16u) + (i0 + u * kScanBlock + tid) * 16u, 0, /*sc1*/ 16);
+#pragma unroll
+                for (int u = 0; u < 4; u++) take(i0 + u * kScanBlock + tid < n_g, x[u]);
             }
         }
-        if (tid == 0 && (npub & 1u)) sh.sel.fkey[npub] = 0ull; // pad to a pair for the b128 reads (npub < kFusedPubLds or even)
+    }
+    __syncthreads();
+    const uint32_t nfin = sh.nfin;
+    good = good && nfin <= static_cast<uint32_t>(kFusedFinalLds);
+    if (good) {
+        if (tid == 0 && (nfin & 1u)) sh.sel.fkey[nfin] = 0ull; // pad to a pair for the b128 reads (nfin < kFusedFinalLds or even)
         __syncthreads();
         GSIM_STAMP(5);
         const uint32_t nmine = sh.nmine;
@@ -1049,7 +1158,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         if (good) {
             gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
             gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
-            const uint32_t npair = (npub + 1u) >> 1;
+            const uint32_t npair = (nfin + 1u) >> 1;
             const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.sel.fkey);
             // RG lanes share one row: each counts the larger keys among every RG-th pair
             // (ds_read_b128, two keys per read, several reads in flight), then a shuffle sum
@@ -1058,7 +1167,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             for (uint32_t t0 = 0; t0 < nmine; t0 += kScanBlock / RG) {
                 const uint32_t t = t0 + static_cast<uint32_t>(tid / RG);
                 const bool have = t < nmine;
-                const u64 mine = have ? sh.sel.fkey[sh.sel.mine_idx[t]] : ~0ull;
+                const u64 mine = have ? sh.sel.fkey[sh.sel.u.mine.idx[t]] : ~0ull;
                 uint32_t rank = 0;
                 for (uint32_t j0 = sub; j0 < npair; j0 += RG * 8) { // eight reads in flight
                     ulonglong2 kk[8];
@@ -1077,7 +1186,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
 #pragma unroll
                 for (int d = RG / 2; d > 0; d >>= 1) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), d, 64));
                 if (have && sub == 0 && rank < a.k) {
-                    const uint32_t cb = sh.sel.mine_cb[t];
+                    const uint32_t cb = sh.sel.u.mine.cb[t];
                     gsim_hit h;
                     h.row = ~static_cast<uint32_t>(mine) + fa.row_base;
                     h.score = key_score(static_cast<uint32_t>(mine >> 32));
@@ -1104,7 +1213,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t redo = agent_load(&st->redo);
     if (tid == 0) {
         gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
-        hdr->count = redo ? 0u : (npub < a.k ? npub : a.k);
+        hdr->count = redo ? 0u : (nfin < a.k ? nfin : a.k);
         hdr->flags = redo ? 2u : 0u;
         hdr->approx = a.cutoff > 0.0f ? __hip_atomic_load(&st->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nrows;
         if (fa.done_flag) {
@@ -1116,22 +1225,20 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         }
         // re-zero the per-query state for the next launch (stream-ordered behind this one)
         st->ncand_sum += __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st->nfinal_sum += redo ? 0u : npub;
+        st->nfinal_sum += redo ? 0u : nfin;
         st->queries += redo ? 0u : 1u;
         st->redo_sum += redo ? 1u : 0u;
-        __hip_atomic_store(&st->final_ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->kept, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->ncand, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->gtau, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&st->npub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&st->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // synchronous callers read the hand-back from the header (no gated kernels behind this launch): the next
         // launch, possibly already enqueued, starts clean
         if (fa.done_flag) __hip_atomic_store(&st->redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
-    { // the summaries: zero again for the next query (16-byte stores)
+    if (tid < static_cast<int>(kFusedArriveCounters)) fa.arrive[tid * 32] = 0;
+    { // the in-loop summaries: zero again for the next query (16-byte stores)
         uint4* sm = reinterpret_cast<uint4*>(fa.summ);
         const uint32_t n16 = (g.nwaves + 3) / 4;
         for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0};
@@ -1669,8 +1776,15 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
     }
 }
 
-__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st)
+__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeKState* lk)
 {
+    if (threadIdx.x == 0 && lk) {
+        lk->prefix = 0;
+        lk->remaining = 0;
+        lk->ticket = 0;
+        lk->count = 0;
+        lk->all = 0;
+    }
     if (threadIdx.x == 0) {
         st->ncand_sum += st->ncand;
         st->nfinal_sum += st->nfinal;
@@ -1689,6 +1803,84 @@ __global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st)
 // large-k path (k > kSelectCap): bitonic sort of ALL finalists in global memory
 // (multi-launch), then emission of the first k.  Exact for any input.
 // ---------------------------------------------------------------------------
+
+// The k-th largest finalist key by an MSD radix descent, one launch per byte, the finalist count read ON THE DEVICE:
+// nothing of the large-k path is sized by the host from a value it would have to wait for.  Pass p histograms byte
+// (7 - p) of the keys that match the prefix found so far (LDS histogram per workgroup, one global atomic per non-empty
+// bin); the last workgroup (ticket) picks the digit that holds the wanted rank, extends the prefix and clears the
+// histogram.  Fewer finalists than k: `all` is set and every finalist is taken.
+__global__ __launch_bounds__(256) void largek_pass_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, int pass)
+{
+    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x;
+    uint32_t nfinal = a.state->nfinal;
+    if (nfinal > cap) nfinal = cap;
+    if (pass > 0 && lk->all) return;
+    const int shift = 56 - 8 * pass;
+    const u64 prefix = lk->prefix;
+    const uint32_t want = pass == 0 ? a.k : lk->remaining;
+    s_h[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256 + tid; i < nfinal; i += gridDim.x * 256) {
+        const u64 key = finalists[i];
+        if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_h[(key >> shift) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    if (s_h[tid]) atomicAdd(&lk->hist[tid], s_h[tid]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&lk->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid < 64) {
+        uint32_t h[4];
+        uint32_t s4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            h[i] = __hip_atomic_load(&lk->hist[tid * 4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s4 += h[i];
+        }
+        uint32_t bin, cnt;
+        threshold_from_counts<4>(h, s4, want, tid, bin, cnt);
+        if (tid == 0) {
+            if (cnt < want) { // (pass 0 only: fewer finalists than k)
+                lk->all = 1;
+                lk->prefix = 0;
+            } else {
+                const uint32_t pop = __hip_atomic_load(&lk->hist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lk->prefix = (prefix << 8) | bin;
+                lk->remaining = want - (cnt - pop);
+            }
+            lk->ticket = 0;
+        }
+    }
+    __syncthreads();
+    lk->hist[tid] = 0;
+}
+
+// the keys at or above the k-th largest (exactly min(k, #finalists) of them: keys are unique) -> out[0 ..)
+__global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, u64* out,
+                                                            uint32_t out_cap)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t nfinal = a.state->nfinal;
+    if (nfinal > cap) nfinal = cap;
+    const u64 kth = lk->all ? 0ull : lk->prefix;
+    const uint32_t n64 = (nfinal + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n64; i += gridDim.x * 256) {
+        const u64 key = i < nfinal ? finalists[i] : 0ull;
+        const bool take = i < nfinal && key >= kth;
+        const u64 m = __ballot(take);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&lk->count, static_cast<uint32_t>(__popcll(m)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t pos = base + lane_rank(m);
+        if (take && pos < out_cap) out[pos] = key;
+    }
+}
 
 __global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64 to)
 {
@@ -1710,12 +1902,13 @@ __global__ __launch_bounds__(256) void bitonic_step_kernel(u64* keys, uint32_t n
     }
 }
 
-__global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, uint32_t nkeys,
+__global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, const LargeKState* lk,
                                                         uint32_t row_base, u64 approx_if_no_cutoff, uint32_t flags,
                                                         void* d_result)
 {
     gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
     gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+    const uint32_t nkeys = lk->count < a.k ? lk->count : a.k;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nkeys) emit_hit(a, sorted_keys[i], row_base, hits + i);
     if (i == 0) {
@@ -1978,7 +2171,8 @@ hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedA
 
 bool fused_supported(const ScanGeometry& g)
 {
-    return g.lanes_per_row != 0 && g.unroll == 8;
+    // every workgroup of the grid is a selector and reads every workgroup's header with one thread
+    return g.lanes_per_row != 0 && g.unroll == 8 && g.nwaves <= static_cast<uint32_t>(kFusedSelectors) * (kScanBlock / 64);
 }
 
 // M of the checkpoint summaries ("my M-th best key"): about 2k / nwaves, so that the election's rank
@@ -1987,7 +2181,7 @@ bool fused_supported(const ScanGeometry& g)
 // electing wave's registers (64 x 64 keys).
 uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k)
 {
-    if (nwaves == 0 || nwaves > 4096) return 0;
+    if (nwaves == 0 || nwaves > static_cast<uint32_t>(kFusedSelectors) * (kScanBlock / 64)) return 0;
     uint32_t m = (2 * k + nwaves - 1) / nwaves;
     if (m < 1) m = 1;
     if (m > 16) m = 16;
@@ -2031,9 +2225,20 @@ hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists,
     return hipGetLastError();
 }
 
-hipError_t launch_reset_state(QueryState* state, hipStream_t s)
+hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s)
 {
-    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(256), 0, s, state);
+    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(256), 0, s, state, lk);
+    return hipGetLastError();
+}
+
+// k > kSelectCap: the k-th largest finalist key by eight radix passes, then the keys at or above it into `out`
+// (out_cap >= k entries; the caller zero-fills it and sorts it afterwards).  Nothing here is sized by the finalist count.
+hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
+                                unsigned long long* out, uint32_t out_cap, hipStream_t s)
+{
+    for (int pass = 0; pass < 8; pass++)
+        hipLaunchKernelGGL(largek_pass_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, pass);
+    hipLaunchKernelGGL(largek_gather_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, out, out_cap);
     return hipGetLastError();
 }
 
@@ -2057,12 +2262,12 @@ hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64
     return hipGetLastError();
 }
 
-hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, uint32_t nkeys,
+hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, const LargeKState* lk,
                             uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result,
                             hipStream_t s)
 {
-    const uint32_t nb = nkeys ? (nkeys + 255) / 256 : 1;
-    hipLaunchKernelGGL(emit_hits_kernel, dim3(nb), dim3(256), 0, s, a, sorted_keys, nkeys, row_base,
+    const uint32_t nb = a.k ? (a.k + 255) / 256 : 1; // (the kernel emits min(k, gathered) hits)
+    hipLaunchKernelGGL(emit_hits_kernel, dim3(nb), dim3(256), 0, s, a, sorted_keys, lk, row_base,
                        approx_if_no_cutoff, flags, d_result);
     return hipGetLastError();
 }

@@ -198,9 +198,9 @@ int gsim_db_set_row_base(gsim_db* db, uint32_t row_base);
 size_t gsim_result_block_bytes(uint32_t k);
 /* One query, single-shard handle: leaves {header; hits[k]} in device memory at
  * d_result (gsim_result_block_bytes(k) bytes), enqueued on the handle's stream,
- * no host synchronisation for k <= 8192 (larger k: the call waits once for the
- * stream, to size the global sort by the finalist count).  query is host memory
- * (fp_bits/32 words). */
+ * no host synchronisation for any k (k > 8192: a radix select on the device finds
+ * the k-th best key, nothing is sized by a count the host would have to read).
+ * query is host memory (fp_bits/32 words). */
 int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff,
                           int metric, float alpha, float beta, void* d_result);
 /* Merge nblocks result blocks (contiguous in device memory, block_bytes apart,

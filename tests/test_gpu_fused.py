@@ -24,6 +24,18 @@ def check(t, db, q, k, cutoff=0.0, ctx="", **kw):
     assert_hits_equal(hits[0], want, ctx)
 
 
+_overflowing = None
+
+
+def overflowing_table():
+    """2.2 M copies of ONE fingerprint: whatever the query, every row ties and every wave of the single launch meets
+    more rows at the threshold than its LDS store holds (2 048) -- the one thing the path still hands back."""
+    global _overflowing
+    if _overflowing is None:
+        _overflowing = np.ascontiguousarray(np.repeat(O.synth_rows(0x0F10, 0, 0, 1, 32), 2_200_000, axis=0))
+    return _overflowing
+
+
 @pytest.mark.parametrize("n,W", [(700, 32), (4_097, 32), (65_000, 32), (300_000, 32), (1_300_000, 32), (2_500_000, 8),
                                  (400_000, 64), (250_000, 4), (120_000, 128), (90_000, 256)])
 def test_single_launch_path_is_taken_and_exact(n, W):
@@ -36,7 +48,7 @@ def test_single_launch_path_is_taken_and_exact(n, W):
     nq = 0
     for qi in range(3):
         q = db[O.query_row(qi, n)]
-        for k in (1, 10, 1000, 2048, 4096):
+        for k in (1, 10, 1000, 2048, 4096, 8192):
             check(t, db, q, k, 0.0, "n=%d W=%d k=%d" % (n, W, k))
             nq += 1
         check(t, db, q, 100, 0.05, "cutoff")
@@ -48,10 +60,11 @@ def test_single_launch_path_is_taken_and_exact(n, W):
     check(t, db, np.zeros(W, dtype=np.uint32), 10, 0.0, "empty query (0/0 -> 0)")
     nq += 2
     tm = t.timing()
-    # the all-zero query scores 0 against every row: a table-wide tie, handed back unless the whole table fits a selector
-    expect_back = 1 if n > 16384 else 0
+    # the all-zero query scores 0 against every row: a table-wide tie.  The final threshold is a 64-bit key (score, row),
+    # so the tie is cut by row index and the query stays on the single launch -- unless a wave meets more tied rows
+    # than its LDS store holds (test_queries_the_path_cannot_hold_are_handed_back_and_stay_exact)
     if W >= 32:
-        assert tm["handed_back"] == expect_back, tm
+        assert tm["handed_back"] == 0, tm
     # (sparse 128/256-bit fingerprints have a dozen bits set: their scores are a handful of small fractions and
     # the k-th best ties with thousands of rows -- handed back by design, exact either way)
     assert tm["queries"] == nq + tm["handed_back"], tm  # (a handed-back query is timed twice)
@@ -59,17 +72,26 @@ def test_single_launch_path_is_taken_and_exact(n, W):
 
 
 def test_queries_the_path_cannot_hold_are_handed_back_and_stay_exact():
-    """Heavy ties (every row a duplicate of four fingerprints): the stores overflow, the four-kernel
-    pipeline (radix select over all ties) answers; rows in ascending score order: the threshold always
-    lags, the stores overflow as well.  Counted, and exact."""
+    """Heavy ties.  Every row a duplicate of four fingerprints (175 k rows tie at the top): since round 3 the final
+    threshold carries the row index and the single launch answers.  EVERY row the same fingerprint, 2.2 M of them:
+    each wave meets more tied rows than its store holds, the four-kernel pipeline (radix select over all ties)
+    answers; rows in ascending score order: the threshold always lags, the stores overflow as well.  Counted, exact."""
     W = 32
     base = O.synth_rows(0x71E8, 0, 0, 4, W)
     tied = np.ascontiguousarray(base[np.random.default_rng(11).integers(0, 4, size=700_000)])
     t = make_table(tied)
     t.enable_timing(True)
-    for k in (10, 1000):
+    for k in (10, 1000, 5000):
         check(t, tied, base[1], k, 0.0, "ties k=%d" % k)
-    assert t.timing()["handed_back"] == 2
+    assert t.timing()["handed_back"] == 0
+    t.close()
+    same = overflowing_table()
+    t = make_table(same)
+    t.enable_timing(True)
+    for k in (10, 1000):
+        check(t, same, base[1], k, 0.0, "all rows tie, k=%d" % k)
+        check(t, same, same[0], k, 0.0, "all rows score 1, k=%d" % k)
+    assert t.timing()["handed_back"] == 4
     t.close()
     # ascending scores along the table: row i shares i * 900 / n bits with the query
     n = 1_500_000
@@ -98,12 +120,13 @@ def test_queries_the_path_cannot_hold_are_handed_back_and_stay_exact():
 
 
 def test_repeated_hand_backs_switch_the_single_launch_off_for_a_while():
-    """A table that ties on every query (duplicates of four fingerprints) would be scanned twice per query: after two
-    consecutive hand-backs the synchronous path goes straight to the four-kernel pipeline for 4, 8, ... 64 queries
-    and probes again afterwards.  Results stay exact throughout; a query the path can hold resets the streak."""
+    """A table whose queries are all handed back (2.2 M copies of one fingerprint: every wave's store overflows) would
+    be scanned twice per query: after two consecutive hand-backs the synchronous path goes straight to the four-kernel
+    pipeline for 4, 8, ... 64 queries and probes again afterwards.  Results stay exact throughout; a query the path
+    can hold resets the streak."""
     W = 32
     base = O.synth_rows(0x71E9, 0, 0, 4, W)
-    tied = np.ascontiguousarray(base[np.random.default_rng(12).integers(0, 4, size=300_000)])
+    tied = overflowing_table()
     t = make_table(tied)
     t.enable_timing(True)
     for i in range(12):
@@ -137,12 +160,19 @@ def test_search_each_keeps_queries_in_flight_and_stays_exact():
     _each_against_oracle(t, db, qs[:9], 1000, 0.12, "each, cutoff")
     _each_against_oracle(t, db, qs[:5], 37, 0.0, "each, tversky", metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
     _each_against_oracle(t, db, qs[:3], 5000, 0.0, "each, k = 5000")
+    _each_against_oracle(t, db, qs[:3], 9000, 0.0, "each, k = 9000 (four-kernel pipeline inside the queue)")
     t.close()
     base = O.synth_rows(0x71EA, 0, 0, 4, W)
     tied = np.ascontiguousarray(base[np.random.default_rng(13).integers(0, 4, size=200_000)])
     t = make_table(tied)
     t.enable_timing(True)
     _each_against_oracle(t, tied, np.stack([base[i % 4] for i in range(11)]), 50, 0.0, "each, ties")
+    assert t.timing()["handed_back"] == 0  # (ties are cut by row index inside the single launch)
+    t.close()
+    same = overflowing_table()
+    t = make_table(same)
+    t.enable_timing(True)
+    _each_against_oracle(t, same, np.stack([base[i % 4] for i in range(11)]), 50, 0.0, "each, every query handed back")
     assert t.timing()["handed_back"] >= 2
     t.close()
 
@@ -154,7 +184,7 @@ def test_enqueue_only_path_falls_back_on_the_device():
     import torch
     W, k = 32, 200
     base = O.synth_rows(0x71E9, 0, 0, 3, W)
-    tied = np.ascontiguousarray(base[np.random.default_rng(12).integers(0, 3, size=400_000)])
+    tied = overflowing_table()
     rnd = O.synth_rows(0x71EA, 0, 0, 400_000, W)
     blk = capi.result_block_bytes(k)
     st = torch.cuda.Stream(device=0)
