@@ -82,7 +82,7 @@ constexpr int kTimingRing = 1024;
 // single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart) + the
 // arrival counters (128 B apart)
 constexpr size_t kTicketWords = static_cast<size_t>(gsim::kFusedCheckpoints) * 9 * 32;
-constexpr size_t kSummBytes = 4096 * 4 + kTicketWords * 4 + static_cast<size_t>(gsim::kFusedArriveCounters) * 128;
+constexpr size_t kSummBytes = 4096 * 4 + kTicketWords * 4 + static_cast<size_t>(gsim::kFusedArriveWords) * 128;
 constexpr int kQueryRing = 16;
 constexpr int kPipe = 8; // single queries of one gsim_db_search_each call enqueued ahead of the one being waited for (< kQueryRing)
 
@@ -398,7 +398,7 @@ bool fused_applies(const Shard& s, uint32_t k)
     static const long long max_rows = std::getenv("GSIM_FUSED_MAX_ROWS") ? std::atoll(std::getenv("GSIM_FUSED_MAX_ROWS")) : -1;
     if (!enabled || k == 0 || k > gsim::kFusedMaxK || s.nrows == 0 || !gsim::fused_supported(s.fgeo)) return false;
     // thresholds need >= k summary keys; without them every row is published (tiny tables only)
-    if (gsim::fused_summary_keys(s.fgeo.nwaves, k) == 0 && s.nrows > 8192) return false;
+    if ((gsim::fused_summary_keys(s.fgeo.nwaves, k) == 0 || gsim::fused_final_keys(s.fgeo.nwaves / 4, k) == 0) && s.nrows > 8192) return false;
     return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
 }
 
@@ -483,6 +483,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.arrive = s.d_summ + 4096 + kTicketWords;
         f.summ = s.d_summ;
         f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k);
+        f.final_keys = gsim::fused_final_keys(s.fgeo.nwaves / 4, k);
         f.tickets = s.d_summ + 4096;
         f.result = out;
         f.row_base = row_base;
@@ -677,6 +678,8 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "3/4-ckpt(w0)", a, b, c);
         stat(23, 1, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "sel:elected", a, b, c);
+        stat(22, 1, &a, &b, &c);
+        if (c > 0) std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n", "sel:elected-2nd", a, b, c);
         stat(12, 4, &a, &b, &c);
         std::fprintf(stderr, "  %-16s %8.2f %8.2f %8.2f\n  end %.2f\n", "wave scan-end", a, b, c, (t[nwg * 24] - t0) / 100.0);
         { // streaming end per workgroup class: blockIdx % 8 (the XCD a block lands on) and blockIdx / 32 (dispatch order)
@@ -1046,7 +1049,7 @@ int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32
     // as the previous one's leave, and its launch, the previous one's close and the kernel boundary overlap
     // (1 M rows: ~10 us per query).  From ~16 M rows on the boundary is below 2 % and two streaming kernels at once only
     // disturb each other.  Not on a stream the caller supplied (its ordering contract is one stream).
-    static const int overlap_on = env_int("GSIM_OVERLAP", 1);
+    static const int overlap_on = env_int("GSIM_OVERLAP", 0);
     static const long long overlap_max = std::getenv("GSIM_OVERLAP_MAX_BYTES") ? std::atoll(std::getenv("GSIM_OVERLAP_MAX_BYTES")) : (2ll << 30);
     const bool two_lanes = overlap_on && !s.on_alt && s.stream == s.own_stream && fused_applies(s, k) &&
                            static_cast<long long>(s.nrows * s.W * 4ull) <= overlap_max;

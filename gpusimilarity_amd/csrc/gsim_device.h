@@ -27,10 +27,10 @@ struct QueryState {
     uint32_t nfinal;             // finalists appended by the compaction
     uint32_t done;               // select-kernel workgroups that have finished (ticket)
     uint32_t gtau;               // table-wide threshold bin shared by all workgroups of the scan (monotone)
+    uint32_t elected;            // single-launch path: highest in-loop checkpoint (1-based) whose threshold election has been held
     uint32_t redo;               // single-launch path gave up (candidate overflow, heavy ties): the gated
                                  // classic kernels behind it run the query; their select kernel clears it
     // --- single-launch path (fused_kernel) ---
-    uint32_t npub;               // (unused since round 3: workgroups publish into fixed regions)
     uint32_t arrived;            // (unused since round 3: the arrival counters live next to the tickets)
     uint32_t sel_done;           // selector workgroups that have written their hits (ticket)
     uint32_t final_ready;        // (unused since round 3: every selector derives the final threshold itself)
@@ -75,15 +75,16 @@ constexpr uint32_t kFusedMaxK = 8192;       // largest k the single-launch path 
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
 constexpr int kFusedSelectors = 256;        // workgroups of the grid: every one of them ranks its share of the finalists
 constexpr uint32_t kFusedRegion = 4 * kFusedWaveCap; // published entries (16 B each) of one workgroup: its fixed region of the list
-constexpr uint32_t kFusedHeaderBytes = 64;  // per workgroup: {count, sorted flag, the four waves' end-of-scan summaries}
-constexpr uint32_t kFusedArriveCounters = 8; // arrival counters (workgroup b adds to counter b % 8), 128 B apart
+constexpr uint32_t kFusedHeaderBytes = 16;  // per workgroup: {entries | sorted << 31, 0, its end-of-scan report (64-bit key)}
+constexpr uint32_t kFusedArriveWords = 17;  // arrival: 8 group counters (b % 8), 1 top counter, 8 generation words, 128 B apart
 
 struct FusedArgs {
     void* pub;            // device, nwg regions of kFusedRegion x 16 B {key, cb, 0}: what each workgroup publishes
     void* hdr;            // device, nwg headers of kFusedHeaderBytes
-    uint32_t* arrive;     // device, kFusedArriveCounters counters 128 B apart (zero between queries)
+    uint32_t* arrive;     // device, kFusedArriveWords words 128 B apart (zero between queries)
     uint32_t* summ;       // device, nwaves score keys: the waves' in-loop checkpoint summaries (zero between queries)
-    uint32_t summ_keys;   // M: every wave reports its M-th best key (fused_summary_keys), 0 = no checkpoints
+    uint32_t summ_keys;   // M: at the in-loop checkpoints every wave reports its M-th best key (fused_summary_keys), 0 = no checkpoints
+    uint32_t final_keys;  // Mw: at the end of the scan every workgroup reports its Mw-th best key (fused_final_keys), 0 = no final threshold
     uint32_t* tickets;    // device, kFusedCheckpoints x 9 counters 128 B apart (8 per-group + 1 top), zero between queries
     void* result;         // result block: device memory or device-visible pinned host memory
     uint32_t row_base;
@@ -101,6 +102,7 @@ inline size_t fused_hdr_bytes(uint32_t nwg) { return static_cast<size_t>(nwg) * 
 hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s);
 bool fused_supported(const ScanGeometry& g);
 uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k);
+uint32_t fused_final_keys(uint32_t nwg, uint32_t k);
 
 // Geometry of the scan grid for a table (host side, no device work).
 ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll);

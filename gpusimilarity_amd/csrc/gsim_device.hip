@@ -503,24 +503,25 @@ struct FusedShared {
                     uint32_t idx[kFusedMineCap];
                     uint32_t cb[kFusedMineCap];
                 } mine;
-                u64 rep[(kScanBlock / 64) * kFusedSelectors]; // the waves' end-of-scan reports, during the election only
+                u64 rep[kFusedSelectors]; // the workgroups' end-of-scan reports, during the election only
             } u;
         } sel;
     };
-    uint32_t hist[256];           // election: digit histogram
-    uint32_t rn[kFusedSelectors]; // per region: entries | sorted << 31
-    uint16_t cont[kFusedSelectors]; // regions with more finalists than the requested prefix holds
-    u64 wfin[kScanBlock / 64];    // the streaming waves' end-of-scan reports (M-th best 64-bit key)
+    uint32_t rn[kFusedSelectors];   // regions read beyond the prefix: entries | sorted << 31 (parallel to cont)
+    uint16_t cont[kFusedSelectors]; // ... their numbers: more finalists than the requested prefix holds, or not in order
+    u64 tauf;                       // the final threshold
     uint32_t tau;       // workgroup's copy of the score-key threshold (monotone; kept fresh by the service wave)
     uint32_t overflow;  // a wave's store overflowed
     uint32_t nemit;     // rows stored by the workgroup (statistics)
     uint32_t scan_done; // streaming waves that have finished
     uint32_t elect_req; // forwarder -> poller: this workgroup took the last ticket of a checkpoint, run the election
+    uint32_t fwd_done;  // the forwarder has passed on every in-loop checkpoint
+    uint32_t elected;   // the poller's copy of QueryState::elected
+    uint32_t abort;     // the poller gave up waiting for the in-loop elections (GPU shared with another queue)
     uint32_t ck_cnt[kFusedCheckpoints];             // streaming waves that have left their summary for checkpoint j
     uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
     uint32_t wcount[kScanBlock / 64];
     uint32_t nfin, nmine, ncont, ok, ticket;
-    uint32_t sel_digit, sel_rem, sel_pop;
 };
 
 __device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
@@ -572,10 +573,17 @@ struct FusedSchedule {
         }
         return 0xFFFFFFFFu;
     }
-    __device__ __forceinline__ uint32_t count() const // number of checkpoints inside the streaming loop
+    __device__ __forceinline__ uint32_t inloop() const // number of checkpoints inside the streaming loop
     {
         return last_ck + (trip(last_ck) != 0xFFFFFFFFu ? 1u : 0u);
     }
+    // Very small tables (up to 8 trips per wave, ~0.5 M 1024-bit rows): the in-loop thresholds come from a quarter of
+    // the rows at best and arrive after the scan anyway -- one more checkpoint AFTER the loop, over all rows, costs the
+    // same wait and leaves ~1.5 k rows to publish instead of 4-8 k (which few workgroups would share).
+    __device__ __forceinline__ bool end_ck() const { return min_trips <= 8; }
+    __device__ __forceinline__ uint32_t count() const { return inloop() + (end_ck() ? 1u : 0u); } // checkpoints in all
+    // few trips: the scan may end before the last in-loop threshold has been elected (see fused_poller)
+    __device__ __forceinline__ bool late() const { return min_trips < 64; }
     // (The workgroups do not finish together: the classes blockIdx % 8 = {0,1,2,7} and {3,4,5,6} -- two halves of
     // the chip -- end 3-4 % apart at 100 M rows, 10 % at 10 M, and WHICH half is the slow one changes from query to
     // query: contention, not a property of an XCD.  Remedies that were built and measured, none kept: per-class
@@ -657,7 +665,7 @@ struct FusedFilter {
         }
         if (dbg && lane == 0 && wv == 0 && ck_j == 0) dbg[9] = wall_clock64();
         if (dbg && lane == 0 && wv == 0) {
-            if (ck_j + 1 == sched.count()) dbg[17] = wall_clock64(); // the last in-loop checkpoint (3/4 of the trips)
+            if (ck_j + 1 == sched.inloop()) dbg[17] = wall_clock64(); // the last in-loop checkpoint (3/4 of the trips)
             else if (ck_j >= 1 && ck_j <= 5) dbg[17 + ck_j] = wall_clock64(); // after 4, 16, 64, 256, 1024 trips
         }
         ck_j++;
@@ -797,15 +805,15 @@ __device__ __forceinline__ void fused_elect(FusedShared& sh, QueryState* st, uin
 // elections its forwarder wins.
 __device__ __forceinline__ void fused_forwarder(FusedShared& sh, const FusedArgs& fa, const FusedSchedule& sched, int lane)
 {
-    if (fa.summ_keys == 0 || (fa.xflags & 2u)) return;
-    const uint32_t nck = sched.count();
+    const bool active = fa.summ_keys != 0 && !(fa.xflags & 2u);
+    const uint32_t nck = active ? sched.count() : 0u;
     const uint32_t nwg = gridDim.x;
     const uint32_t x = blockIdx.x % 8u;
     const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
+    // every wave of the grid reaches every scheduled checkpoint (the schedule is made from the FEWEST trips any wave
+    // makes), so every checkpoint's ticket completes: this wave passes all of them on, also after the streaming loop
     for (uint32_t j = 0; j < nck;) {
         if (__hip_atomic_load(&sh.ck_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != kScanBlock / 64) {
-            // the streaming loop is over: checkpoints it did not reach no longer matter
-            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
             // (the early checkpoints are a few microseconds apart; from the fourth on this wave naps ~1.7 us at a time:
             // a wave that polls LDS every 64 clocks takes issue slots from the streaming wave on its SIMD)
             if (j >= 3) __builtin_amdgcn_s_sleep(64);
@@ -827,79 +835,59 @@ __device__ __forceinline__ void fused_forwarder(FusedShared& sh, const FusedArgs
         }
         j++;
     }
+    if (lane == 0) __hip_atomic_store(&sh.fwd_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, const FusedArgs& fa, uint32_t nwaves, uint32_t k,
-                                             int lane, u64* dbg)
+// Small tables (sched.late()): the last in-loop threshold takes ~12 us from its checkpoint to every workgroup and the
+// scan may be over before that.  A workgroup that published against no threshold would publish all its rows, and
+// every selector would wade through the whole table: on such tables the streaming waves wait, after their loop, until
+// every in-loop election has been held (QueryState::elected) -- the poller stays and keeps the count fresh in LDS, for
+// at most fa.wait_ticks (then the query is handed back).
+__device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, const FusedArgs& fa, const FusedSchedule& sched,
+                                             uint32_t nwaves, uint32_t k, int lane, u64* dbg)
 {
+    const bool active = fa.summ_keys != 0 && !(fa.xflags & 2u);
+    const uint32_t nck = active ? sched.count() : 0u;
+    const bool stay = sched.late();
+    const unsigned long long t0 = wall_clock64();
     for (uint32_t spins = 0;; spins++) {
         const uint32_t g = agent_load(&st->gtau);
-        if (lane == 0 && g > __hip_atomic_load(&sh.tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.tau, g);
+        const uint32_t el = agent_load(&st->elected);
+        if (lane == 0) {
+            if (g > __hip_atomic_load(&sh.tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.tau, g);
+            __hip_atomic_store(&sh.elected, el, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // (after the threshold it belongs to)
+        }
         // a poll every ~2 us at first, every ~5 us from the 64th on, every ~60 us from the 512th on
         const uint32_t naps = spins < 512u ? 1u : 16u;
         for (uint32_t i = 0; i < naps; i++) {
-            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64) return;
             uint32_t req = 0; // (consumed with an exchange: a request stored between a plain load and a plain clear would be lost)
             if (lane == 0 && __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) req = atomicExch(&sh.elect_req, 0u);
             req = __builtin_amdgcn_readfirstlane(req);
-            if (req && fa.summ_keys) fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
+            if (req && active) {
+                fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the threshold is out before the count
+                // (the HIGHEST checkpoint whose election has been held: one election may serve two requests that the same
+                // workgroup won back to back, and only the last checkpoint's matters to those who wait)
+                if (lane == 0) atomicMax(&st->elected, req);
+                break; // (poll at once: this workgroup's own waves want the count too)
+            }
+            if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64 &&
+                __hip_atomic_load(&sh.fwd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 &&
+                __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+                // streaming over, every checkpoint forwarded, no election owed by this workgroup
+                if (!stay || el >= nck) return;
+                if (wall_clock64() - t0 > fa.wait_ticks) { // (only when part of the grid cannot start: a shared GPU)
+                    if (lane == 0) {
+                        atomicOr(&st->redo, 1u);
+                        __hip_atomic_store(&sh.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    return;
+                }
+            }
             if (spins < 64u) __builtin_amdgcn_s_sleep(8); // (units of 64 clocks: ~0.2 us; a small table is over in 20-50 us)
             else __builtin_amdgcn_s_sleep(127);                    // ~3.4 us
         }
     }
-}
-
-// The selectors' final threshold: the r-th largest of the nv end-of-scan reports in sh.sel.u.rep (each the M-th best
-// 64-bit key of one wave over ALL its rows), r = ceil(k / M), as a lower bound of at least 16 leading bits.  Valid as
-// the in-loop thresholds are (each of the r largest reports stands for M distinct rows at or above it in the canonical
-// order), and because the keys carry the row index it also cuts through ties: of a group of equal scores only the rows
-// that can still reach the top k stay above it.  Radix descent, 8 bits per pass, by the whole workgroup (256 threads:
-// an LDS digit histogram, wave 0 finds the digit); it stops early once at most eight reports share the prefix found so
-// far (no ties: two passes), and goes through all 64 bits only when many reports do -- heavy ties.  Every selector
-// computes the same value from the same reports.  Returns the threshold; all 256 threads must call.
-__device__ __forceinline__ u64 fused_final_threshold(FusedShared& sh, uint32_t nv, uint32_t r, int tid)
-{
-    u64 prefix = 0;
-    uint32_t remaining = r;
-    int pass = 0;
-#pragma unroll 1
-    for (; pass < 8; pass++) {
-        const int shift = 56 - 8 * pass;
-        sh.hist[tid] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < nv; i += kScanBlock) {
-            const u64 key = sh.sel.u.rep[i];
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&sh.hist[(key >> shift) & 0xFFu], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            uint32_t h[4];
-            uint32_t s4 = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                h[i] = sh.hist[tid * 4 + i];
-                s4 += h[i];
-            }
-            uint32_t bin, cnt;
-            threshold_from_counts<4>(h, s4, remaining, tid, bin, cnt);
-            if (tid == 0) {
-                const uint32_t pop = sh.hist[bin];
-                sh.sel_digit = bin;
-                sh.sel_pop = pop;
-                sh.sel_rem = remaining - (cnt - pop); // rank of the wanted report inside the digit's bin (>= 1)
-            }
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | sh.sel_digit;
-        remaining = sh.sel_rem;
-        const uint32_t pop = sh.sel_pop;
-        if (pass == 0 && sh.sel_digit == 0) return 0ull; // fewer than r non-zero reports: no threshold
-        if (pass >= 1 && pop <= 8u) {
-            pass++;
-            break;
-        }
-    }
-    return pass >= 8 ? prefix : prefix << (64 - 8 * pass);
 }
 
 template <int LPR, int U>
@@ -920,6 +908,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         sh.nemit = 0;
         sh.scan_done = 0;
         sh.elect_req = 0;
+        sh.fwd_done = 0;
+        sh.elected = 0;
+        sh.abort = 0;
     }
     if (tid < kFusedCheckpoints) sh.ck_cnt[tid] = 0;
     __syncthreads();
@@ -932,7 +923,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         return;
     }
     if (wv == kScanBlock / 64 + 1) {
-        fused_poller(sh, st, fa, g.nwaves, a.k, lane, dbg);
+        fused_poller(sh, st, fa, sched, g.nwaves, a.k, lane, dbg);
         return;
     }
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wv);
@@ -960,6 +951,13 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.next_ck = (f.M && !(fa.xflags & 2u)) ? sched.trip(0) : 0xFFFFFFFFu;
     f.dbg = dbg;
     scan_rows<LPR, U>(a, g, f, q, w, lane);
+    if (sched.end_ck() && f.M && !(fa.xflags & 2u)) { // the checkpoint after the loop: this wave's M-th best over all its rows
+        const u64 mth = f.mth_best(lane);
+        if (lane == 0) {
+            sh.wsum[wv] = static_cast<uint32_t>(mth >> 32);
+            atomicAdd(&sh.ck_cnt[sched.inloop()], 1u);
+        }
+    }
     if (lane == 0) atomicAdd(&sh.scan_done, 1u); // (the service waves leave)
     if (f.has_cutoff) {
         const uint32_t tot = wave_sum(f.kept);
@@ -968,19 +966,22 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (dbg && lane == 0) dbg[12 + wv] = wall_clock64();
     if (dbg && lane == 0 && wv == 0) dbg[1] = wall_clock64();
 
-    // ---- 3. publish: this workgroup's survivors and its four end-of-scan reports ---------------
-    // No exchange precedes it: the rows at or above the freshest in-loop threshold go into the workgroup's own region
-    // of the list (no reservation), in canonical order when there are few, and the selectors derive the final
-    // threshold themselves from the reports of all workgroups.
-    f.refresh(agent_load(&st->gtau), lane);
+    // ---- 3. publish: this workgroup's survivors and its end-of-scan report ---------------------
+    // No exchange precedes it: the rows at or above the freshest in-loop threshold the workgroup has seen go into its
+    // own region of the list (no reservation), in canonical order when there are few -- each row's position is the
+    // number of larger keys in the workgroup -- and the row at position Mw - 1 is the workgroup's REPORT: "Mw distinct
+    // rows of mine are at or above this 64-bit key".  The selectors derive the final threshold from the reports.
+    if (sched.late() && fa.summ_keys != 0 && !(fa.xflags & 2u)) { // small table: the last in-loop threshold may still be on its way
+        const uint32_t nck = sched.count();
+        while (__hip_atomic_load(&sh.elected, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nck &&
+               __hip_atomic_load(&sh.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+            __builtin_amdgcn_s_sleep(4);
+    }
+    f.refresh(0u, lane); // (the service wave kept the workgroup's LDS copy of the threshold fresh: no global load here)
     if (!f.store_off) f.compact_store(lane);
-    {
-        const u64 fin = (f.M && !f.store_off) ? f.mth_best(lane) : 0ull;
-        if (lane == 0) {
-            sh.wfin[wv] = fin;
-            sh.wcount[wv] = f.store_off ? 0u : f.staged;
-            if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
-        }
+    if (lane == 0) {
+        sh.wcount[wv] = f.store_off ? 0u : f.staged;
+        if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
     }
     __syncthreads(); // (released once the service waves have exited too)
     GSIM_STAMP(2);
@@ -994,6 +995,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     if (bad) ntot = 0;
     const bool sorted = ntot <= kFusedSortCap;
+    const uint32_t Mw = fa.final_keys; // rows a workgroup's report stands for (fused_final_keys)
+    const __amdgpu_buffer_rsrc_t hrsrc_w = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
     {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             static_cast<unsigned char*>(fa.pub) + static_cast<size_t>(blockIdx.x) * (kFusedRegion * 16u), 0, kFusedRegion * 16u, 0x00020000);
@@ -1013,25 +1016,65 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                         pos += (j + 1 < cnt && kk.y > key) ? 1u : 0u;
                     }
                 }
+                if (Mw && pos == Mw - 1u) // the workgroup's report: straight into its header (bytes 8..15)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32)}, hrsrc_w,
+                                                          blockIdx.x * kFusedHeaderBytes + 8u, 0, /*sc1*/ 16);
             }
             const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
             __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
         }
-        if (tid < 3) { // the header: {entries, sorted, 0, 0}, {report 0, report 1}, {report 2, report 3}
-            const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
-            const u64 r0 = tid == 0 ? (static_cast<u64>(sorted ? 1u : 0u) << 32 | ntot) : sh.wfin[2 * tid - 2];
-            const u64 r1 = tid == 0 ? 0ull : sh.wfin[2 * tid - 1];
-            const u32x4 hv{static_cast<uint32_t>(r0), static_cast<uint32_t>(r0 >> 32), static_cast<uint32_t>(r1), static_cast<uint32_t>(r1 >> 32)};
-            __builtin_amdgcn_raw_buffer_store_b128(hv, hrsrc, blockIdx.x * kFusedHeaderBytes + tid * 16u, 0, /*sc1*/ 16);
-        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries are out
+    if (!sorted && Mw && wv == 0) { // (many rows: ties, clusters, a late threshold) the Mw-th best of the four stores, by one wave
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
+            const uint32_t cnt = sh.wcount[w2];
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                const u64 v = sh.store.key[w2][i];
+                if (v > t3) {
+                    t3 = v;
+                    if (t3 > t2) { const u64 x = t2; t2 = t3; t3 = x; }
+                    if (t2 > t1) { const u64 x = t1; t1 = t2; t2 = x; }
+                    if (t1 > t0) { const u64 x = t0; t0 = t1; t1 = x; }
+                }
+            }
+        }
+        u64 mth = 0;
+        for (uint32_t rr = 0; rr < Mw; rr++) { // (a lane holding more than four of the best under-reports: still valid)
+            const uint32_t hi = wave_max_u32(static_cast<uint32_t>(t0 >> 32));
+            const uint32_t lo = wave_max_u32(static_cast<uint32_t>(t0 >> 32) == hi ? static_cast<uint32_t>(t0) : 0u);
+            mth = (static_cast<u64>(hi) << 32) | lo;
+            const u64 bm = __ballot(t0 == mth);
+            if (lane == __builtin_ctzll(bm)) {
+                t0 = t1;
+                t1 = t2;
+                t2 = t3;
+                t3 = 0;
+            }
+        }
+        if (lane == 0)
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{static_cast<uint32_t>(mth), static_cast<uint32_t>(mth >> 32)}, hrsrc_w,
+                                                  blockIdx.x * kFusedHeaderBytes + 8u, 0, /*sc1*/ 16);
+    }
+    // the header's first half: {entries | sorted << 31, 0}.  Its second half is the report, written above by whoever
+    // found it -- and not at all when the workgroup holds fewer than Mw rows: the selectors take a report as present
+    // only if entries >= Mw, so a stale one from an earlier query is never read.
+    if (tid == 0)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{ntot | (sorted ? 0x80000000u : 0u), 0u}, hrsrc_w, blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries (and header parts) are out
     __syncthreads();
     if (tid == 0) {
         if (bad) atomicOr(&st->redo, 1u);
-        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit));
-        // the arrival: eight counters (b % 8), an atomic nobody waits for
-        __hip_atomic_fetch_add(&fa.arrive[(blockIdx.x % kFusedArriveCounters) * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The arrival, two levels (MI355X_MICROARCH.md "barrier-xcd"): a counter per group of workgroups b % 8 (the XCD a
+        // block lands on, as observed -- only speed depends on it), the group's last arriver adds to the top counter,
+        // the last of those raises one generation word per group.  Every workgroup then polls ITS group's word: 32
+        // pollers per line instead of 256 on every line (a flat count polled by all cost 7-10 us after the last arrival).
+        const uint32_t x = blockIdx.x % 8u;
+        const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
+        if (atomicAdd(&fa.arrive[x * 32u], 1u) == group_size - 1u && atomicAdd(&fa.arrive[8u * 32u], 1u) == ngroups - 1u) {
+            for (uint32_t gq = 0; gq < 8u; gq++)
+                __hip_atomic_store(&fa.arrive[(9u + gq) * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (statistics: nobody waits for it)
     }
     GSIM_STAMP(3);
 
@@ -1044,10 +1087,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         // theirs: after fa.wait_ticks (a few scan times) without the last arrival the query goes to the classic
         // kernels, which never wait.
         const unsigned long long t_wait = wall_clock64();
+        const uint32_t* gen = &fa.arrive[(9u + blockIdx.x % 8u) * 32u];
         for (uint32_t spins = 0;; spins++) {
-            uint32_t c = 0;
-            if (lane < static_cast<int>(kFusedArriveCounters)) c = agent_load(&fa.arrive[lane * 32]);
-            if (wave_sum_dpp(c) >= nwg) break;
+            if (agent_load(gen) != 0) break;
             __builtin_amdgcn_s_sleep(2);
             if ((spins & 255u) == 255u && wall_clock64() - t_wait > fa.wait_ticks) {
                 ok = 0;
@@ -1060,53 +1102,133 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             sh.nfin = 0;
             sh.nmine = 0;
             sh.ncont = 0;
+            sh.tauf = 0ull;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // (no acquire fence: everything read below was stored write-through and is read with sc1 loads, past the L1)
     __syncthreads();
     GSIM_STAMP(4);
     // ONE round trip: the header of region `tid` and the first kFusedPrefix entries of every region are requested
-    // together, before anything is known about them (regions hold last query's rows beyond their count).
+    // together, before anything is known about them (regions hold last query's rows beyond their count).  The entries
+    // go straight into LDS (global_load_lds, 16 B per lane, no registers), so that the code that filters them stays
+    // small: it is fetched cold in every launch.  Slot s = 16 g + p of the staging area receives entry (p - g) mod 16
+    // of region g: thread g later walks ITS region's entries, and the rotation spreads the 64 lanes over all banks.
+    // The staging area is the upper half of the finalist array: at most 4096 staged entries become finalists.
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, nwg * (kFusedRegion * 16u), 0x00020000);
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
     constexpr int PL = static_cast<int>(kFusedPrefix);
-    u32x4 e[PL], hd[3];
+    u32x4* staging = reinterpret_cast<u32x4*>(&sh.sel.fkey[kFusedFinalLds / 2]);
+    // A grid of fewer than 129 workgroups (small tables) leaves threads to spare: S = 2, 4, ... threads share a region,
+    // each taking sixteen consecutive entries of it ("virtual region" v = S g + part), so that the requested prefix is
+    // 16 S entries -- the finalists per region grow as the grid shrinks.
+    uint32_t lgS = 0;
+    while ((nwg << (lgS + 1u)) <= static_cast<uint32_t>(kFusedSelectors)) lgS++;
+    const uint32_t my_region = static_cast<uint32_t>(tid) >> lgS, my_part = static_cast<uint32_t>(tid) & ((1u << lgS) - 1u);
+    const u32x4 hd = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, my_region * kFusedHeaderBytes, 0, /*sc1*/ 16); // (zeros past the grid)
+    {
+        const unsigned char* pubc = static_cast<const unsigned char*>(fa.pub);
 #pragma unroll
-    for (int u = 0; u < 3; u++) hd[u] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, tid * kFusedHeaderBytes + u * 16u, 0, /*sc1*/ 16);
-#pragma unroll
-    for (int u = 0; u < PL; u++) { // entry (u * 256 + tid): region (.. / 16), index (.. % 16); regions past the grid read as zeros
-        const uint32_t ent = static_cast<uint32_t>(u * kScanBlock + tid);
-        e[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (ent / kFusedPrefix) * (kFusedRegion * 16u) + (ent % kFusedPrefix) * 16u, 0, /*sc1*/ 16);
+        for (int u = 0; u < PL; u++) {
+            const uint32_t slot = static_cast<uint32_t>(u * kScanBlock + tid);
+            const uint32_t v = slot / kFusedPrefix, j = (slot - v) % kFusedPrefix; // virtual region, entry inside it
+            const uint32_t gi = v >> lgS, ent = ((v & ((1u << lgS) - 1u)) * kFusedPrefix) + j;
+            if (gi < nwg)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*) (pubc + static_cast<size_t>(gi) * (kFusedRegion * 16u) + ent * 16u),
+                    (__attribute__((address_space(3))) void*) (staging + u * kScanBlock + wv * 64), 16, 0, /*sc1*/ 16);
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sh.rn[tid] = static_cast<uint32_t>(tid) < nwg ? ((hd[0].x < kFusedRegion ? hd[0].x : kFusedRegion) | (hd[0].y ? 0x80000000u : 0u)) : 0u;
-    if (static_cast<uint32_t>(tid) < nwg) {
-        sh.sel.u.rep[4 * tid + 0] = (static_cast<u64>(hd[1].y) << 32) | hd[1].x;
-        sh.sel.u.rep[4 * tid + 1] = (static_cast<u64>(hd[1].w) << 32) | hd[1].z;
-        sh.sel.u.rep[4 * tid + 2] = (static_cast<u64>(hd[2].y) << 32) | hd[2].x;
-        sh.sel.u.rep[4 * tid + 3] = (static_cast<u64>(hd[2].w) << 32) | hd[2].z;
+    // (the header was requested first and loads return in order: the election below runs while the prefixes land)
+    const uint32_t n_mine = (hd.x & 0x7FFFFFFFu) < kFusedRegion ? (hd.x & 0x7FFFFFFFu) : kFusedRegion; // entries of region my_region
+    const bool sorted_mine = (hd.x >> 31) != 0;
+    const u64 rep_mine = (Mw && n_mine >= Mw && my_part == 0) ? ((static_cast<u64>(hd.w) << 32) | hd.z) : 0ull; // (one thread per region holds its report)
+    sh.sel.u.rep[tid] = rep_mine;
+    __syncthreads(); // the reports of all regions
+    const bool good0 = sh.ok != 0; // (not good: headers and regions may be stale -- nothing below is used, the query is handed back)
+    // The final threshold: the r-th largest of the workgroups' reports, r = ceil(k / Mw).  Each of the r largest
+    // reports stands for Mw distinct rows at or above it in the canonical order, so at least k rows are at or above
+    // the r-th largest: no row of the top k lies below it.  The keys carry the row index: the threshold also cuts
+    // through a group of equal scores.  Every thread ranks its region's report by counting larger ones (256 broadcast
+    // reads); the thread whose report has rank r - 1 publishes it.  Every selector finds the same value.
+    if (good0 && Mw) {
+        const uint32_t rr = (a.k + Mw - 1u) / Mw;
+        const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(sh.sel.u.rep);
+        uint32_t rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < kFusedSelectors / 2; j++) {
+            const ulonglong2 kk = r2[j];
+            rank += kk.x > rep_mine ? 1u : 0u;
+            rank += kk.y > rep_mine ? 1u : 0u;
+        }
+        if (rep_mine != 0ull && rank == rr - 1u) sh.tauf = rep_mine;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's part of the prefixes is in LDS
+    __syncthreads();                                 // ... and everybody's; the threshold is known
+    const u64 tauf = good0 ? sh.tauf : ~0ull;
+    if (dbg && tid == 0) dbg[23] = wall_clock64();
+    // finalists = the published rows at or above the final threshold -> LDS.  Thread g takes region g's staged entries
+    // (all sixteen reads issued at once); the rows this selector owns (a hash of the row) are noted with their popcounts.
+    bool good = good0;
+    {
+        const uint32_t g16 = static_cast<uint32_t>(tid) * kFusedPrefix;
+        const uint32_t first = my_part * kFusedPrefix; // this thread's sixteen entries of the region: first .. first + 15
+        const uint32_t npre = (good0 && sorted_mine && n_mine > first) ? (n_mine - first < kFusedPrefix ? n_mine - first : kFusedPrefix) : 0u;
+        u32x4 ev[PL];
+#pragma unroll
+        for (int j = 0; j < PL; j++) ev[j] = staging[g16 + ((static_cast<uint32_t>(j) + static_cast<uint32_t>(tid)) % kFusedPrefix)];
+        uint32_t passm = 0; // bit j: entry j is a finalist
+#pragma unroll
+        for (int j = 0; j < PL; j++)
+            passm |= (static_cast<uint32_t>(j) < npre && ((static_cast<u64>(ev[j].y) << 32) | ev[j].x) >= tauf) ? (1u << j) : 0u;
+        const uint32_t cnt = static_cast<uint32_t>(__popc(passm));
+        // exclusive prefix sum of cnt over the wave (DPP row shifts + the row totals), one LDS atomic per wave
+        uint32_t incl = cnt;
+        { uint32_t o; o = dpp_shr<1>(incl); incl += o; o = dpp_shr<2>(incl); incl += o; o = dpp_shr<4>(incl); incl += o; o = dpp_shr<8>(incl); incl += o; }
+        const uint32_t row_tot0 = __builtin_amdgcn_readlane(incl, 15), row_tot1 = __builtin_amdgcn_readlane(incl, 31),
+                       row_tot2 = __builtin_amdgcn_readlane(incl, 47), row_tot3 = __builtin_amdgcn_readlane(incl, 63);
+        const int rowi = lane >> 4;
+        incl += (rowi > 0 ? row_tot0 : 0u) + (rowi > 1 ? row_tot1 : 0u) + (rowi > 2 ? row_tot2 : 0u);
+        const uint32_t wtot = row_tot0 + row_tot1 + row_tot2 + row_tot3;
+        uint32_t base = 0;
+        if (lane == 0 && wtot) base = atomicAdd(&sh.nfin, wtot);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t slot0 = base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < PL; j++) {
+            if (passm & (1u << j)) {
+                const uint32_t slot = slot0 + static_cast<uint32_t>(__popc(passm & ((1u << j) - 1u)));
+                sh.sel.fkey[slot] = (static_cast<u64>(ev[j].y) << 32) | ev[j].x; // (< 4096: below the staging area)
+                if ((((~ev[j].x * 2654435761u) >> 16) * nsel) >> 16 == r) { // this selector ranks it
+                    const uint32_t mp = atomicAdd(&sh.nmine, 1u);
+                    if (mp < static_cast<uint32_t>(kFusedMineCap)) {
+                        sh.sel.u.mine.idx[mp] = slot;
+                        sh.sel.u.mine.cb[mp] = ev[j].z;
+                    }
+                }
+            }
+        }
+        // more rows of this region may qualify: its list is longer than the prefix and either not in order or still
+        // above the threshold at the prefix's end
+        const uint32_t pre_all = kFusedPrefix << lgS; // entries of a region that were requested
+        if (good0 && (sorted_mine ? (my_part == (1u << lgS) - 1u && n_mine > pre_all && cnt == kFusedPrefix) : (my_part == 0 && n_mine > 0))) {
+            const uint32_t c = atomicAdd(&sh.ncont, 1u);
+            sh.cont[c] = static_cast<uint16_t>(my_region);
+            sh.rn[c] = n_mine | (sorted_mine ? 0x80000000u : 0u);
+        }
     }
     __syncthreads();
-    bool good = sh.ok != 0; // (not good: headers and regions may be stale -- nothing below is used, the query is handed back)
-    u64 tauf = ~0ull;
-    if (good) tauf = 0;
-    if (good && fa.summ_keys) tauf = fused_final_threshold(sh, nwg * (kScanBlock / 64), (a.k + fa.summ_keys - 1) / fa.summ_keys, tid);
-    if (dbg && tid == 0) dbg[23] = wall_clock64();
-    // finalists = the published rows at or above the final threshold -> LDS; the rows this selector owns (hash of the
-    // row) are noted with their popcounts
-    auto take = [&](bool in, const u32x4& ent) {
+    auto take = [&](bool in, const u32x4& ent) { // one published row per lane -> the finalists, if it is at or above the threshold
         const u64 key = (static_cast<u64>(ent.y) << 32) | ent.x;
         const bool pass = in && key >= tauf;
         const u64 m = __ballot(pass);
-        if (m == 0) return false;
+        if (m == 0) return;
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&sh.nfin, static_cast<uint32_t>(__popcll(m)));
         base = __builtin_amdgcn_readfirstlane(base);
         const uint32_t slot = base + lane_rank(m);
         if (pass && slot < static_cast<uint32_t>(kFusedFinalLds)) {
             sh.sel.fkey[slot] = key;
-            const uint32_t row = ~ent.x;
-            if (((row * 2654435761u) >> 16) % nsel == r) { // this selector ranks it
+            if ((((~ent.x * 2654435761u) >> 16) * nsel) >> 16 == r) {
                 const uint32_t mp = atomicAdd(&sh.nmine, 1u);
                 if (mp < static_cast<uint32_t>(kFusedMineCap)) {
                     sh.sel.u.mine.idx[mp] = slot;
@@ -1114,35 +1236,17 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 }
             }
         }
-        return pass;
     };
-#pragma unroll
-    for (int u = 0; u < PL; u++) {
-        const uint32_t ent = static_cast<uint32_t>(u * kScanBlock + tid);
-        const uint32_t gi = ent / kFusedPrefix, idx = ent % kFusedPrefix;
-        const uint32_t rnv = sh.rn[gi % kFusedSelectors]; // (gi < 256 always: 16 x 256 entries)
-        const uint32_t n_g = rnv & 0x7FFFFFFFu;
-        const bool pass = take(idx < n_g, e[u]);
-        // more rows of this region may qualify: its list is longer than the prefix and either not in order or still
-        // above the threshold at the prefix's end
-        if (good && idx == kFusedPrefix - 1 && n_g > kFusedPrefix && (!(rnv >> 31) || pass)) {
-            const uint32_t c = atomicAdd(&sh.ncont, 1u);
-            sh.cont[c] = static_cast<uint16_t>(gi);
-        }
-    }
-    __syncthreads();
     {
-        const uint32_t nc = good ? sh.ncont : 0u;
-        for (uint32_t ci = 0; ci < nc; ci++) { // (clustered rows, ties, unsorted regions: rare)
+        const uint32_t nc = sh.ncont;
+        for (uint32_t ci = 0; ci < nc; ci++) { // (clustered rows, ties, regions not in order: rare)
             const uint32_t gi = sh.cont[ci];
-            const uint32_t n_g = sh.rn[gi] & 0x7FFFFFFFu;
-            for (uint32_t i0 = kFusedPrefix; i0 < n_g; i0 += kScanBlock * 4) {
-                u32x4 x[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    x[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, gi * (kFusedRegion * 16u) + (i0 + u * kScanBlock + tid) * 16u, 0, /*sc1*/ 16);
-#pragma unroll
-                for (int u = 0; u < 4; u++) take(i0 + u * kScanBlock + tid < n_g, x[u]);
+            const uint32_t rnv = sh.rn[ci];
+            const uint32_t n_g = rnv & 0x7FFFFFFFu;
+#pragma unroll 1
+            for (uint32_t i0 = (rnv >> 31) ? (kFusedPrefix << lgS) : 0u; i0 < n_g; i0 += kScanBlock) {
+                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(prsrc, gi * (kFusedRegion * 16u) + (i0 + tid) * 16u, 0, /*sc1*/ 16);
+                take(i0 + tid < n_g, x);
             }
         }
     }
@@ -1231,13 +1335,14 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         __hip_atomic_store(&st->kept, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->ncand, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->gtau, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->elected, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // synchronous callers read the hand-back from the header (no gated kernels behind this launch): the next
         // launch, possibly already enqueued, starts clean
         if (fa.done_flag) __hip_atomic_store(&st->redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
-    if (tid < static_cast<int>(kFusedArriveCounters)) fa.arrive[tid * 32] = 0;
+    if (tid < static_cast<int>(kFusedArriveWords)) fa.arrive[tid * 32] = 0;
     { // the in-loop summaries: zero again for the next query (16-byte stores)
         uint4* sm = reinterpret_cast<uint4*>(fa.summ);
         const uint32_t n16 = (g.nwaves + 3) / 4;
@@ -2186,6 +2291,20 @@ uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k)
     if (m < 1) m = 1;
     if (m > 16) m = 16;
     if ((k + m - 1) / m > nwaves) return 0;
+    return m;
+}
+
+// Mw of the end-of-scan reports ("my Mw-th best key", one per workgroup): the final threshold is the r-th largest
+// report, r = ceil(k / Mw).  With rows spread evenly the number of rows above it is nwg x lambda, lambda solving
+// P(Poisson(lambda) >= Mw) = r / nwg: ~2.0 k at Mw = 2 k / nwg (r in the middle of the reports), ~1.4 k around
+// Mw = 1.25 k / nwg (r at 0.8 of them), rising again beyond -- and the selectors hold 16 Ki finalists, k up to 8 Ki.
+// 0: the grid has fewer workgroups than r would need (tiny tables: every published row is a finalist).
+uint32_t fused_final_keys(uint32_t nwg, uint32_t k)
+{
+    if (nwg == 0 || k == 0) return 0;
+    uint32_t m = (5 * k + 4 * nwg - 1) / (4 * nwg);
+    if (m < 1) m = 1;
+    if (m > 64) return 0;
     return m;
 }
 

@@ -16,6 +16,7 @@ namespace
 
 // 16 bytes per lane; a wave64 instruction covers 1 KiB of consecutive table bytes.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kStage = 128; // candidates staged in LDS per wave (a flush is triggered above 64)
 
@@ -114,6 +115,12 @@ __device__ __forceinline__ float apply_cutoff(float s, float cutoff)
 template <int CTRL> __device__ __forceinline__ uint32_t dpp(uint32_t v)
 {
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
+}
+
+// row_shr:N within each row of 16 lanes; lanes without a source read 0 (prefix sums)
+template <int N> __device__ __forceinline__ uint32_t dpp_shr(uint32_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x110 + N, 0xF, 0xF, true));
 }
 
 // Sum over each aligned group of LPR consecutive lanes; every lane of the group
