@@ -117,18 +117,6 @@ struct Shard {
     void* d_pub = nullptr;      // single-launch path: the workgroups' published-candidate regions (128 KB each)
     void* d_hdr = nullptr;      // ... and their headers (64 B each)
     uint32_t* d_summ = nullptr; // single-launch path: per-wave checkpoint summaries (16 KB, zero between queries)
-    // Second lane of the single-launch path (small tables, gsim_db_search_each): its own stream, per-query state and
-    // publish buffers, so that consecutive queries alternate between two streams and the next kernel's workgroups
-    // move in while the previous kernel's closing tail (ticket, header, re-zeroing, end-of-launch bookkeeping) runs.
-    struct Lane {
-        hipStream_t stream = nullptr;
-        gsim::QueryState* d_state = nullptr;
-        void* d_pub = nullptr;
-        void* d_hdr = nullptr;
-        uint32_t* d_summ = nullptr;
-        bool state_dirty = false;
-    } alt;
-    bool alt_ready = false, on_alt = false;
     uint32_t* h_done = nullptr; // single-launch path: pinned words (one per pipeline slot) the kernel stores the query's epoch into
     uint32_t epoch = 0;
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
@@ -232,12 +220,6 @@ int free_shard(Shard& s)
     if (s.d_pub) (void) hipFree(s.d_pub);
     if (s.d_hdr) (void) hipFree(s.d_hdr);
     if (s.d_summ) (void) hipFree(s.d_summ);
-    if (s.alt.stream) (void) hipStreamSynchronize(s.alt.stream);
-    if (s.alt.d_state) (void) hipFree(s.alt.d_state);
-    if (s.alt.d_pub) (void) hipFree(s.alt.d_pub);
-    if (s.alt.d_hdr) (void) hipFree(s.alt.d_hdr);
-    if (s.alt.d_summ) (void) hipFree(s.alt.d_summ);
-    if (s.alt.stream) (void) hipStreamDestroy(s.alt.stream);
     if (s.d_dbg) (void) hipFree(s.d_dbg);
     if (s.h_done) (void) hipHostFree(s.h_done);
     if (s.h_pipe) (void) hipHostFree(s.h_pipe);
@@ -333,35 +315,6 @@ int ensure_classic_scratch(Shard& s)
     GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
     s.classic_ready = true;
     return GSIM_OK;
-}
-
-// The second lane's buffers (see Shard::Lane), made on first use.
-int ensure_alt_lane(Shard& s)
-{
-    if (s.alt_ready) return GSIM_OK;
-    GSIM_HIP(set_device(s.device));
-    GSIM_HIP(hipStreamCreateWithFlags(&s.alt.stream, hipStreamNonBlocking));
-    GSIM_HIP(hipMalloc(&s.alt.d_state, sizeof(gsim::QueryState)));
-    GSIM_HIP(hipMemset(s.alt.d_state, 0, sizeof(gsim::QueryState)));
-    GSIM_HIP(hipMalloc(&s.alt.d_pub, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
-    GSIM_HIP(hipMalloc(&s.alt.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
-    GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.alt.d_summ), kSummBytes));
-    GSIM_HIP(hipMemset(s.alt.d_summ, 0, kSummBytes));
-    s.alt_ready = true;
-    return GSIM_OK;
-}
-
-// Make lane `alt` (false: the shard's own) the one every enqueue / wait on the shard uses.
-void use_lane(Shard& s, bool alt)
-{
-    if (alt == s.on_alt) return;
-    std::swap(s.stream, s.alt.stream);
-    std::swap(s.d_state, s.alt.d_state);
-    std::swap(s.d_pub, s.alt.d_pub);
-    std::swap(s.d_hdr, s.alt.d_hdr);
-    std::swap(s.d_summ, s.alt.d_summ);
-    std::swap(s.state_dirty, s.alt.state_dirty);
-    s.on_alt = alt;
 }
 
 int ensure_result_capacity(Shard& s, uint32_t k)
@@ -565,7 +518,6 @@ int drain_timing(gsim_db* db, Shard& s)
     if (s.ev_used == 0 && s.bev_used == 0) return GSIM_OK;
     GSIM_HIP(set_device(s.device));
     GSIM_HIP(hipStreamSynchronize(s.stream));
-    if (s.alt_ready) GSIM_HIP(hipStreamSynchronize(s.alt.stream));
     for (uint32_t i = 0; i < s.bev_used; i++) {
         float ms = 0.f;
         GSIM_HIP(hipEventElapsedTime(&ms, s.bev[2 * i], s.bev[2 * i + 1]));
@@ -594,13 +546,6 @@ int read_totals(Shard& s, unsigned long long* ncand, unsigned long long* nfinal,
     *ncand = s.h_state->ncand_sum;
     *nfinal = s.h_state->nfinal_sum;
     if (nredo) *nredo = s.h_state->redo_sum;
-    if (s.alt_ready) { // the other lane keeps its own running totals
-        GSIM_HIP(hipStreamSynchronize(s.alt.stream));
-        GSIM_HIP(hipMemcpy(s.h_state, s.alt.d_state, sizeof(gsim::QueryState), hipMemcpyDeviceToHost));
-        *ncand += s.h_state->ncand_sum;
-        *nfinal += s.h_state->nfinal_sum;
-        if (nredo) *nredo += s.h_state->redo_sum;
-    }
     return GSIM_OK;
 }
 
@@ -722,7 +667,6 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
     }
     if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
-    use_lane(s, false); // the four-kernel pipeline runs on the shard's own lane (one scratch per shard)
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
     int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
     if (rc != GSIM_OK) return rc;
@@ -1044,37 +988,14 @@ int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32
         s.h_pipe_block = blk;
     }
     const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
-    // Small tables: consecutive queries alternate between two lanes (streams with their own per-query state).  A
-    // kernel of the single-launch path holds a CU's LDS, so two never share a CU -- the next one's workgroups move in
-    // as the previous one's leave, and its launch, the previous one's close and the kernel boundary overlap
-    // (1 M rows: ~10 us per query).  From ~16 M rows on the boundary is below 2 % and two streaming kernels at once only
-    // disturb each other.  Not on a stream the caller supplied (its ordering contract is one stream).
-    static const int overlap_on = env_int("GSIM_OVERLAP", 0);
-    static const long long overlap_max = std::getenv("GSIM_OVERLAP_MAX_BYTES") ? std::atoll(std::getenv("GSIM_OVERLAP_MAX_BYTES")) : (2ll << 30);
-    const bool two_lanes = overlap_on && !s.on_alt && s.stream == s.own_stream && fused_applies(s, k) &&
-                           static_cast<long long>(s.nrows * s.W * 4ull) <= overlap_max;
-    if (two_lanes) {
-        const int rc = ensure_alt_lane(s);
-        if (rc != GSIM_OK) return rc;
-    }
-    struct LaneGuard { // whatever happens, the shard leaves on its own lane
-        Shard& s;
-        ~LaneGuard() { use_lane(s, false); }
-    } guard{s};
     uint32_t issued = 0;
-    bool slot_lane[kPipe] = {};
     for (uint32_t done = 0; done < nq; done++) {
         for (; issued < nq && issued - done < static_cast<uint32_t>(kPipe); issued++) {
-            // (the four-kernel pipeline's scratch exists once per shard: queries that take it -- a table whose queries
-            // keep being handed back -- all go through the shard's own lane, one after the other)
-            slot_lane[issued % kPipe] = two_lanes && (issued & 1u) && s.fused_skip == 0 && s.redo_streak == 0;
-            use_lane(s, slot_lane[issued % kPipe]);
             const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta, row_base,
                                          s.h_pipe + (issued % kPipe) * s.h_pipe_block, true, kAuto, issued % kPipe);
             if (rc != GSIM_OK) return rc;
         }
         void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
-        use_lane(s, slot_lane[done % kPipe]);
         const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta, row_base,
                                          out, done % kPipe);
         if (rc != GSIM_OK) return rc;
