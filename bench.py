@@ -226,7 +226,8 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
         elapsed = float(t.item())
     tm = table.timing()
     table.enable_timing(False)
-    n = max(1, tm["queries"])
+    n = max(1, tm["queries"])  # queries timed with HIP events (the first 1024 of the timed region)
+    nall = max(1, steps * qps)  # queries the device-side totals cover (all of the timed region)
     kernel_ms = tm["scan_ms_sum"] / n
     algo = R * (fp_bits // 8)  # bytes per launch of the dominant kernel on one GPU
     achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -243,7 +244,7 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
                             "(profiles/); bench.py cannot run them",
             "kernel_ms_avg": kernel_ms, "other_kernels_ms_avg": tm["select_ms_sum"] / n,
             "algorithmic_bytes_per_launch": algo,
-            "candidates_per_query": tm["candidates_sum"] / n, "published_per_query": tm["finalists_sum"] / n,
+            "candidates_per_query": tm["candidates_sum"] / nall, "finalists_per_query": tm["finalists_sum"] / nall,
             "queries_handed_back": tm["handed_back"], "timed_with_hip_events": tm["queries"],
         },
     }
@@ -332,6 +333,8 @@ def main():
     ap.add_argument("--kind", choices=["sparse", "dense", "morgan"], default="sparse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other single-GPU BASELINE configs (N = 1 only)")
+    ap.add_argument("--no-server-latency", action="store_true",
+                    help="skip the end-to-end gpusimserver record (scripts/server_latency.py, N = 1 only)")
     ap.add_argument("--batch-queries", type=int, default=0,
                     help="BASELINE configs[4] instead of the headline run: Tversky(0.3, 0.7) batches of this many "
                          "queries per step (use with --fp-bits 2048); a step is one batch")
@@ -506,6 +509,17 @@ def main():
         out["configs"] = cfgs
         out["configs_note"] = ("configs[0] (small.fsim, CPU path) is timed under cpu_baseline.parts; configs[3] (1B rows over 8 GPUs) "
                                "is this script at --gpus 8")
+    if world == 1 and not sharded and not args.no_server_latency and not args.no_configs:
+        # the reference's own published metric: server-side search latency through the socket backend, at two of its
+        # slide-12/13 table sizes (ChEMBL 1 618 358 rows, Enamine 56 667 620 rows), Morgan-shaped rows, k = 20 and 1000
+        try:
+            env = dict(os.environ, SL_REQUESTS="30")
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "server_latency.py"), "1618358", "56667620"],
+                               env=env, capture_output=True, timeout=300)
+            out["server_latency"] = json.loads(p.stdout.decode().strip().splitlines()[-1]) if p.returncode == 0 else \
+                {"error": p.stderr.decode("utf-8", "replace")[-500:]}
+        except Exception as e:  # a report, never a reason to lose the headline
+            out["server_latency"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

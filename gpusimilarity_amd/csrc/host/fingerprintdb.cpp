@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <thread>
 
 #include "../../../include/gpusim_hip.h"
 
@@ -80,6 +81,42 @@ FingerprintDB::FingerprintDB(int fp_bitcount, int fp_count, const std::string& d
     m_ids.swap(ids_vector);
 }
 
+FingerprintDB::FingerprintDB(int fp_bitcount, unsigned long long fp_count, const std::string& dbkey, unsigned long long seed, int kind)
+    : m_dbkey(dbkey), m_synthetic(true), m_seed(seed), m_kind(kind)
+{
+    if (fp_count > 0x7FFFFFFFull) throw std::runtime_error("synthetic table: too many rows for one device");
+    m_fp_intsize = fp_bitcount / static_cast<int>(sizeof(int) * 8);
+    m_total_count = static_cast<int>(fp_count);
+    if (gsim_db_create(static_cast<uint32_t>(fp_bitcount), &m_db) != GSIM_OK) throw_last("FingerprintDB");
+    m_total_data_size = static_cast<size_t>(m_total_count) * static_cast<size_t>(m_fp_intsize) * sizeof(int);
+    // "S%010d\0" and "ZINC%010d\0": 12 + 15 bytes per row, one arena
+    const size_t per = 12 + 15;
+    m_arena.resize(static_cast<size_t>(m_total_count) * per);
+    m_smiles.resize(static_cast<size_t>(m_total_count));
+    m_ids.resize(static_cast<size_t>(m_total_count));
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    std::vector<std::thread> pool;
+    const size_t n = static_cast<size_t>(m_total_count), chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const size_t lo = chunk * t, hi = lo + chunk < n ? lo + chunk : n;
+        if (lo >= hi) break;
+        pool.emplace_back([this, lo, hi, per] {
+            for (size_t r = lo; r < hi; r++) {
+                char* sm = m_arena.data() + r * per;
+                char* id = sm + 12;
+                std::snprintf(sm, 12, "S%010zu", r);
+                std::snprintf(id, 15, "ZINC%010zu", r);
+                m_smiles[r] = sm;
+                m_ids[r] = id;
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    std::fprintf(stderr, "Synthetic database of %d molecules (kind %d, %d bits)\n", m_total_count, kind, fp_bitcount);
+}
+
 FingerprintDB::~FingerprintDB()
 {
     if (m_db) gsim_db_destroy(m_db);
@@ -87,6 +124,15 @@ FingerprintDB::~FingerprintDB()
 
 void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices)
 {
+    if (m_synthetic) { // generated in HBM, one device (the one get_next_gpu picks)
+        (void) fold_factor;
+        (void) ndevices;
+        const unsigned int dev = get_next_gpu(m_total_data_size);
+        if (gsim_db_generate(m_db, m_seed, m_kind, 0, static_cast<uint64_t>(m_total_count), static_cast<int>(dev)) != GSIM_OK)
+            throw_last("copyToGPU (synthetic)");
+        m_on_gpu = true;
+        return;
+    }
     if (fold_factor > 1 && gsim_db_set_fold_factor(m_db, fold_factor) != GSIM_OK) throw_last("copyToGPU");
     if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
     m_fold_factor = static_cast<int>(gsim_db_fold_factor(m_db));

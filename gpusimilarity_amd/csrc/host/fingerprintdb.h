@@ -33,6 +33,10 @@ class FingerprintDB
     // the smiles / ids vectors (:164-165).
     FingerprintDB(int fp_bitcount, int fp_count, const std::string& dbkey, std::vector<std::vector<char>>& data,
                   std::vector<char*>& smiles_vector, std::vector<char*>& ids_vector);
+    // A synthetic table for benchmarks (no reference counterpart): fp_count rows of the counter-based generator
+    // (gsim_db_generate: GSIM_SYNTH_SPARSE / _DENSE / _MORGAN) made directly in HBM by copyToGPU; SMILES / ID strings are
+    // "S<row>" / "ZINC<row>".  No host copy of the fingerprints: search_cpu is not available.
+    FingerprintDB(int fp_bitcount, unsigned long long fp_count, const std::string& dbkey, unsigned long long seed, int kind);
     ~FingerprintDB();
     FingerprintDB(const FingerprintDB&) = delete;
     FingerprintDB& operator=(const FingerprintDB&) = delete;
@@ -71,6 +75,10 @@ class FingerprintDB
     std::vector<char*> m_ids;
     std::string m_dbkey;
     bool m_on_gpu = false;
+    bool m_synthetic = false;
+    unsigned long long m_seed = 0;
+    int m_kind = 0;
+    std::vector<char> m_arena; // synthetic tables: the strings' storage
 };
 
 // fingerprintdb_cuda.cpp:92-103

@@ -128,6 +128,19 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
 
     std::vector<TableFacts> facts;
     for (const auto& database_fname : database_fnames) {
+        if (database_fname.rfind("synthetic:", 0) == 0) {
+            // benchmark table, no file: "synthetic:<rows>[:<sparse|dense|morgan>[:<bits>]]" -> database "synthetic", key "pass"
+            unsigned long long rows = 0;
+            char kind_s[16] = "sparse";
+            int bits = 1024;
+            if (std::sscanf(database_fname.c_str(), "synthetic:%llu:%15[a-z]:%d", &rows, kind_s, &bits) < 1 || rows == 0 || bits <= 0 ||
+                bits % 32 != 0)
+                throw std::invalid_argument("bad synthetic database spec: " + database_fname);
+            const std::string ks = kind_s;
+            const int kind = ks == "dense" ? 1 : ks == "morgan" ? 2 : 0;
+            m_databases["synthetic"] = std::make_shared<FingerprintDB>(bits, rows, "pass", 0x5EED0001ull, kind);
+            continue;
+        }
         int fp_bitcount = 0, fp_count = 0;
         std::string dbkey;
         std::vector<std::vector<char>> fingerprint_data;

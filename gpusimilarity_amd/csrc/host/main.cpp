@@ -1,6 +1,7 @@
 // main.cpp -- `gpusimserver`: the backend process python/gpusim_server.py spawns.
 // Flags as the reference's main.cpp:21-62: --cpu_only, --gpu_bitcount N, positional
-// .fsim files; plus --gpus N (shard every table over N GPUs, 0 = all).
+// .fsim files; plus --gpus N (shard every table over N GPUs, 0 = all) and, in place of a file,
+// "synthetic:<rows>[:<kind>[:<bits>]]" (a benchmark table generated in HBM; scripts/server_latency.py).
 #include <sys/stat.h>
 
 #include <csignal>
@@ -67,6 +68,7 @@ int main(int argc, char* argv[])
         return 1;
     }
     for (const auto& f : db_fnames) {
+        if (f.rfind("synthetic:", 0) == 0) continue; // a generated benchmark table, not a file (gpusim_server.cpp)
         struct stat st;
         if (stat(f.c_str(), &st) != 0) {
             std::fprintf(stderr, "File: \" %s \" not found.\n", f.c_str());
