@@ -680,6 +680,34 @@ bool hit_before(const gsim_hit& x, const gsim_hit& y)
     return x.row < y.row;
 }
 
+// FingerprintDB::search's merge (fingerprintdb_cuda.cu:363-380: std::sort of all storages' results, first k kept).  The
+// shards' lists arrive in canonical order and their keys are unique, so the first k of the sorted union are the first
+// k of a k-way merge: O(k log #lists) instead of sorting #lists x k hits (8 x 1000: ~20 us instead of ~0.4 ms per query).
+// `lists` holds the concatenated lists, `ends[i]` the end of list i in it.  Returns the number of hits written.
+uint32_t merge_canonical_lists(const std::vector<gsim_hit>& lists, const std::vector<size_t>& ends, uint32_t k, gsim_hit* out)
+{
+    struct Head {
+        size_t pos, end;
+    };
+    std::vector<Head> heads;
+    size_t begin = 0;
+    for (size_t e : ends) {
+        if (e > begin) heads.push_back({begin, e});
+        begin = e;
+    }
+    auto later = [&](const Head& x, const Head& y) { return hit_before(lists[y.pos], lists[x.pos]); }; // (a max-heap on "comes first")
+    std::make_heap(heads.begin(), heads.end(), later);
+    uint32_t n = 0;
+    while (n < k && !heads.empty()) {
+        std::pop_heap(heads.begin(), heads.end(), later);
+        Head& h = heads.back();
+        out[n++] = lists[h.pos++];
+        if (h.pos < h.end) std::push_heap(heads.begin(), heads.end(), later);
+        else heads.pop_back();
+    }
+    return n;
+}
+
 // FoldFingerprintFunctorCPU (calculation_functors.cpp:22-41): bit `pos` of the fingerprint is
 // OR-ed into bit `pos % (32 * Wf)`; since 32 * Wf is a multiple of 32 that is word (w % Wf), same
 // bit -- i.e. the F consecutive blocks of Wf words are OR-ed together.
@@ -945,6 +973,7 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
     }
     uint64_t ap = 0;
     merged.clear();
+    std::vector<size_t> ends;
     for (auto& s : db->shards) {
         GSIM_HIP(set_device(s.device));
         int rc = finish_query_sync(db, s, query, k, cutoff, metric, alpha, beta,
@@ -958,15 +987,10 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
             *count = h->count;
         } else {
             merged.insert(merged.end(), hh, hh + h->count);
+            ends.push_back(merged.size());
         }
     }
-    if (nsh > 1) {
-        // std::sort + truncate (fingerprintdb_cuda.cu:363-380)
-        std::sort(merged.begin(), merged.end(), hit_before);
-        const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
-        std::memcpy(hits, merged.data(), sizeof(gsim_hit) * n);
-        *count = n;
-    }
+    if (nsh > 1) *count = merge_canonical_lists(merged, ends, k, hits); // fingerprintdb_cuda.cu:363-380
     if (approx) *approx = ap;
     return GSIM_OK;
 }
@@ -1529,6 +1553,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
             for (uint32_t q = 0; q < nb; q++) {
                 uint64_t ap = 0;
                 merged.clear();
+                std::vector<size_t> ends;
                 bool bad = overflow;
                 for (auto& s : db->shards) {
                     if (s.nrows == 0) continue;
@@ -1537,14 +1562,13 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                     ap += h->approx;
                     const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
                     merged.insert(merged.end(), hh, hh + h->count);
+                    ends.push_back(merged.size());
                 }
                 if (bad) {
                     redo[q] = 1;
                     continue;
                 }
-                if (nsh > 1) std::sort(merged.begin(), merged.end(), hit_before);
-                const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
-                if (n) std::memcpy(hits + static_cast<size_t>(base + q) * kout, merged.data(), sizeof(gsim_hit) * n);
+                const uint32_t n = merge_canonical_lists(merged, ends, k, hits + static_cast<size_t>(base + q) * kout);
                 counts[base + q] = n;
                 if (approx) approx[base + q] = ap;
             }
@@ -1667,6 +1691,8 @@ int gsim_merge_host(const void* blocks, uint32_t nblocks, size_t block_bytes, ui
     if (!blocks || !result || nblocks == 0) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
     if (block_bytes < sizeof(gsim_result_header)) return fail(GSIM_ERR_INVALID, "block_bytes too small");
     std::vector<gsim_hit> all;
+    std::vector<size_t> ends;
+    bool canonical = true;
     uint64_t approx = 0;
     uint32_t flags = 0;
     for (uint32_t i = 0; i < nblocks; i++) {
@@ -1678,11 +1704,20 @@ int gsim_merge_host(const void* blocks, uint32_t nblocks, size_t block_bytes, ui
         const size_t old = all.size();
         all.resize(old + h.count);
         if (h.count) std::memcpy(all.data() + old, b + sizeof(h), static_cast<size_t>(h.count) * sizeof(gsim_hit));
+        canonical = canonical && std::is_sorted(all.begin() + static_cast<std::ptrdiff_t>(old), all.end(), hit_before);
+        ends.push_back(all.size());
         approx += h.approx;
         flags |= h.flags;
     }
-    std::sort(all.begin(), all.end(), hit_before);
     gsim_result_header out;
+    if (canonical) { // blocks made by the search kernels are in canonical order: a k-way merge is the sorted union's head
+        std::vector<gsim_hit> head(std::min<size_t>(all.size(), k));
+        const uint32_t n = merge_canonical_lists(all, ends, static_cast<uint32_t>(head.size()), head.data());
+        head.resize(n);
+        all.swap(head);
+    } else {
+        std::sort(all.begin(), all.end(), hit_before);
+    }
     out.count = static_cast<uint32_t>(std::min<size_t>(all.size(), k));
     out.flags = flags;
     out.approx = approx;
