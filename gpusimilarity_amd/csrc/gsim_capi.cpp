@@ -78,6 +78,9 @@ hipError_t set_device(int logical)
     return hipSetDevice(phys_device(logical));
 }
 
+// Host memory the kernels write and the host reads WHILE the kernel still runs (completion words, result blocks): it has
+// to be coherent (fine-grained) whatever the runtime's default for pinned memory is (HIP_HOST_COHERENT).
+constexpr unsigned kHostPolled = hipHostMallocCoherent;
 constexpr int kTimingRing = 1024;
 // single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart) + the
 // arrival counters (128 B apart)
@@ -285,7 +288,7 @@ int setup_shard(gsim_db* db, Shard& s)
     GSIM_HIP(hipMalloc(&s.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
     GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_summ), kSummBytes));
     GSIM_HIP(hipMemset(s.d_summ, 0, kSummBytes));
-    GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_done), 64, hipHostMallocDefault));
+    GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_done), 64, kHostPolled));
     std::memset(s.h_done, 0, 64);
     GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(s.W) * 4 * kQueryRing, hipHostMallocDefault));
     for (int i = 0; i < kQueryRing; i++) {
@@ -330,7 +333,7 @@ int ensure_result_capacity(Shard& s, uint32_t k)
     if (need > s.h_result_bytes) {
         if (s.h_result) GSIM_HIP(hipHostFree(s.h_result));
         s.h_result = nullptr;
-        GSIM_HIP(hipHostMalloc(&s.h_result, need, hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(&s.h_result, need, kHostPolled));
         s.h_result_bytes = need;
     }
     return GSIM_OK;
@@ -1008,7 +1011,7 @@ int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32
         if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
         s.h_pipe = nullptr;
         s.h_pipe_block = 0;
-        GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, kHostPolled));
         s.h_pipe_block = blk;
     }
     const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);

@@ -3,6 +3,8 @@
 set -uo pipefail
 echo "== single queries, 1024-bit rows, Tanimoto top-1000 (scripts/time_single.py) =="
 python scripts/time_single.py 100000 1000000 10000000 30000000 100000000 2>&1 | grep rows
+echo "== Morgan-shaped rows (GSIM_SYNTH_MORGAN), 1024-bit =="
+TS_KIND=morgan python scripts/time_single.py 1000000 10000000 100000000 2>&1 | grep rows
 echo "== other widths, 100 M rows (2048-bit: 60 M) =="
 for b in 128 256 512; do TS_BITS=$b TS_REPS=50 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/bits $b  /"; done
 TS_BITS=2048 TS_REPS=50 python scripts/time_single.py 60000000 2>&1 | grep rows | sed "s/^/bits 2048  /"
@@ -12,7 +14,7 @@ for b in 160 192 896 1536; do TS_BITS=$b TS_REPS=30 python scripts/time_single.p
 echo "== four-kernel pipeline for comparison (GSIM_FUSED=0), 1024-bit =="
 GSIM_FUSED=0 TS_REPS=50 python scripts/time_single.py 1000000 10000000 100000000 2>&1 | grep rows
 echo "== k sweep, 100 M x 1024-bit =="
-for k in 1 10 100 1000 2048 4096 8192; do TS_K=$k TS_REPS=30 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/k $k  /"; done
+for k in 1 10 100 1000 2048 4096 8192 20000; do TS_K=$k TS_REPS=30 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/k $k  /"; done
 echo "== 256-query Tversky(0.3,0.7) batches on the matrix cores (scripts/time_batch.py) =="
 python scripts/time_batch.py 125000000
 TB_BITS=1024 python scripts/time_batch.py 125000000
