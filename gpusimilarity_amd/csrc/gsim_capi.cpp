@@ -113,6 +113,12 @@ struct Shard {
     unsigned long long* d_final = nullptr;
     uint32_t* d_final_cb = nullptr;
     uint32_t final_cap = 0;
+    // folded tables: the storage's FULL fingerprints in HBM too (when they fit), and the re-score's buffers
+    uint32_t* d_full = nullptr;
+    uint32_t* d_fq = nullptr;              // the full query (+ one word: the NaN flag)
+    uint32_t* h_fq = nullptr;              // ... its pinned staging
+    unsigned long long* d_key2 = nullptr;  // re-scored keys, 64 Ki
+    uint32_t* d_cb2 = nullptr;
     unsigned long long* d_large = nullptr; // k > kSelectCap: the gathered top-k keys (sorted in place), next_pow2(k) entries
     uint32_t large_cap = 0;
     gsim::LargeKState* d_lk = nullptr;
@@ -218,6 +224,11 @@ int free_shard(Shard& s)
     if (s.d_seg_count) (void) hipFree(s.d_seg_count);
     if (s.d_final) (void) hipFree(s.d_final);
     if (s.d_result) (void) hipFree(s.d_result);
+    if (s.d_full) (void) hipFree(s.d_full);
+    if (s.d_fq) (void) hipFree(s.d_fq);
+    if (s.h_fq) (void) hipHostFree(s.h_fq);
+    if (s.d_key2) (void) hipFree(s.d_key2);
+    if (s.d_cb2) (void) hipFree(s.d_cb2);
     if (s.d_large) (void) hipFree(s.d_large);
     if (s.d_lk) (void) hipFree(s.d_lk);
     if (s.d_pub) (void) hipFree(s.d_pub);
@@ -1050,6 +1061,67 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
     std::vector<gsim_hit> merged;
     std::vector<int> idx;
     std::vector<float> sc;
+    // The re-score runs on the device when every storage also holds its full fingerprints in HBM (gsim_db_finalize puts
+    // them there when they fit) and the candidate list fits the device sort; GSIM_FOLD_RESCORE=host forces the host path.
+    static const bool force_host = std::getenv("GSIM_FOLD_RESCORE") && std::string(std::getenv("GSIM_FOLD_RESCORE")) == "host";
+    bool on_device = !force_host && want <= 65536 && k > 0;
+    for (auto& s : db->shards) on_device = on_device && s.d_full != nullptr;
+    // the host path for one storage: its folded candidates (in s.h_result) re-scored with the host copy of the full rows
+    auto rescore_on_host = [&](Shard& s, const uint32_t* query) {
+        const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
+        const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+        const uint32_t n = h->count;
+        idx.resize(n);
+        sc.resize(n);
+        std::vector<uint16_t> cm(n), pc(n);
+        for (uint32_t j = 0; j < n; j++) { // tanimoto_similarity_cpu on the FULL fingerprints (:387-399)
+            const uint32_t* d = db->host_rows.data() + (s.first_row + hh[j].row) * W;
+            int total = 0, common = 0, pd = 0;
+            for (uint32_t w = 0; w < W; w++) {
+                const int p2 = __builtin_popcount(d[w]);
+                pd += p2;
+                total += __builtin_popcount(query[w]) + p2;
+                common += __builtin_popcount(query[w] & d[w]);
+            }
+            idx[j] = static_cast<int>(j);
+            sc[j] = static_cast<float>(common) / static_cast<float>(total - common);
+            cm[j] = static_cast<uint16_t>(common);
+            pc[j] = static_cast<uint16_t>(pd);
+        }
+        // top_results_bubble_sort(indices, scores, k) (fingerprintdb_cuda.cpp:92-103): k passes of a bubble sort with
+        // a strict '>' -- stable, so its first k entries are the first k of a stable descending sort.  That sort is
+        // what runs here (O(n log n) instead of O(k n): k = 1000, F = 8 means 32 k candidates x 1000 passes per
+        // storage and query); the literal bubble sort only when a NaN score (0/0: two empty fingerprints) is
+        // present, for which '>' is not an order and the two would differ.
+        bool has_nan = false;
+        for (uint32_t j = 0; j < n; j++) has_nan = has_nan || sc[j] != sc[j];
+        if (!has_nan) {
+            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return sc[x] > sc[y]; });
+            std::vector<float> sorted(n);
+            for (uint32_t j = 0; j < n; j++) sorted[j] = sc[idx[j]];
+            sc.swap(sorted);
+        } else {
+            for (uint32_t a = 0; a < k && a < n; a++) {
+                for (uint32_t b = n - 1; b > a; b--) {
+                    if (sc[b] > sc[b - 1]) {
+                        std::swap(idx[b], idx[b - 1]);
+                        std::swap(sc[b], sc[b - 1]);
+                    }
+                }
+            }
+        }
+        const uint32_t keep = std::min(k, n);
+        for (uint32_t a = 0; a < keep; a++) {
+            if (sc[a] < cutoff) break;
+            gsim_hit o;
+            o.row = db->row_base + static_cast<uint32_t>(s.first_row) + hh[idx[a]].row;
+            o.score = sc[a];
+            o.common = cm[idx[a]];
+            o.popc_db = pc[idx[a]];
+            merged.push_back(o);
+        }
+        return h->approx;
+    };
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * W;
         fold_row(query, W, F, fq.data());
@@ -1058,72 +1130,54 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
         for (size_t i = 0; i < db->shards.size(); i++) {
             Shard& s = db->shards[i];
             kshard[i] = static_cast<uint32_t>(std::min<uint64_t>(want, s.nrows));
-            int rc = ensure_result_capacity(s, kshard[i]);
+            int rc = ensure_result_capacity(s, std::max(kshard[i], k));
             if (rc != GSIM_OK) return rc;
-            rc = enqueue_query(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result, true);
+            if (!on_device) {
+                rc = enqueue_query(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result, true);
+                if (rc != GSIM_OK) return rc;
+                continue;
+            }
+            // device route, all enqueued on the storage's stream: folded search -> candidates' block in device memory ->
+            // re-score with the full rows, sort, first k at or above the cutoff -> pinned host block
+            GSIM_HIP(set_device(s.device));
+            const uint32_t npad = next_pow2_u32(kshard[i] ? kshard[i] : 1);
+            if (!s.d_fq) {
+                GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_fq), static_cast<size_t>(W) * 4 + 64));
+                GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_key2), static_cast<size_t>(65536) * 8));
+                GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cb2), static_cast<size_t>(65536) * 4));
+                GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_fq), static_cast<size_t>(W) * 4 + 64, hipHostMallocDefault));
+            }
+            GSIM_HIP(hipStreamSynchronize(s.stream)); // (the pinned staging of the previous query's fingerprint is free)
+            std::memcpy(s.h_fq, query, static_cast<size_t>(W) * 4);
+            s.h_fq[W] = 0;
+            GSIM_HIP(hipMemcpyAsync(s.d_fq, s.h_fq, static_cast<size_t>(W) * 4 + 4, hipMemcpyHostToDevice, s.stream)); // (+ the NaN flag, cleared)
+            rc = enqueue_query(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.d_result, false);
             if (rc != GSIM_OK) return rc;
+            GSIM_HIP(gsim::launch_fold_rescore(s.d_result, s.d_full, s.d_fq, W, qa, s.d_key2, s.d_cb2, npad, s.d_fq + W, k, cutoff,
+                                               db->row_base + static_cast<uint32_t>(s.first_row), s.h_result, s.stream));
+            GSIM_HIP(hipMemcpyAsync(s.h_fq + W, s.d_fq + W, 4, hipMemcpyDeviceToHost, s.stream));
         }
         uint64_t ap = 0;
         merged.clear();
         for (size_t i = 0; i < db->shards.size(); i++) {
             Shard& s = db->shards[i];
             GSIM_HIP(set_device(s.device));
+            if (on_device) {
+                int rc = wait_stream(s.stream);
+                if (rc != GSIM_OK) return rc;
+                if (s.h_fq[W] == 0) { // (no NaN among the re-scored candidates: the block in s.h_result is the storage's answer)
+                    const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
+                    const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+                    ap += h->approx;
+                    merged.insert(merged.end(), hh, hh + h->count);
+                    continue;
+                }
+                rc = enqueue_query(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result, true);
+                if (rc != GSIM_OK) return rc;
+            }
             int rc = finish_query_sync(db, s, fq.data(), kshard[i], cutoff, GSIM_METRIC_TANIMOTO, 0.f, 0.f, 0, s.h_result);
             if (rc != GSIM_OK) return rc;
-            const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
-            const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
-            ap += h->approx;
-            const uint32_t n = h->count;
-            idx.resize(n);
-            sc.resize(n);
-            std::vector<uint16_t> cm(n), pc(n);
-            for (uint32_t j = 0; j < n; j++) { // tanimoto_similarity_cpu on the FULL fingerprints (:387-399)
-                const uint32_t* d = db->host_rows.data() + (s.first_row + hh[j].row) * W;
-                int total = 0, common = 0, pd = 0;
-                for (uint32_t w = 0; w < W; w++) {
-                    const int p2 = __builtin_popcount(d[w]);
-                    pd += p2;
-                    total += __builtin_popcount(query[w]) + p2;
-                    common += __builtin_popcount(query[w] & d[w]);
-                }
-                (void) qa;
-                idx[j] = static_cast<int>(j);
-                sc[j] = static_cast<float>(common) / static_cast<float>(total - common);
-                cm[j] = static_cast<uint16_t>(common);
-                pc[j] = static_cast<uint16_t>(pd);
-            }
-            // top_results_bubble_sort(indices, scores, k) (fingerprintdb_cuda.cpp:92-103): k passes of a bubble sort with
-            // a strict '>' -- stable, so its first k entries are the first k of a stable descending sort.  That sort is
-            // what runs here (O(n log n) instead of O(k n): k = 1000, F = 8 means 32 k candidates x 1000 passes per
-            // storage and query); the literal bubble sort only when a NaN score (0/0: two empty fingerprints) is
-            // present, for which '>' is not an order and the two would differ.
-            bool has_nan = false;
-            for (uint32_t j = 0; j < n; j++) has_nan = has_nan || sc[j] != sc[j];
-            if (!has_nan) {
-                std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return sc[x] > sc[y]; });
-                std::vector<float> sorted(n);
-                for (uint32_t j = 0; j < n; j++) sorted[j] = sc[idx[j]];
-                sc.swap(sorted);
-            } else {
-                for (uint32_t a = 0; a < k && a < n; a++) {
-                    for (uint32_t b = n - 1; b > a; b--) {
-                        if (sc[b] > sc[b - 1]) {
-                            std::swap(idx[b], idx[b - 1]);
-                            std::swap(sc[b], sc[b - 1]);
-                        }
-                    }
-                }
-            }
-            const uint32_t keep = std::min(k, n);
-            for (uint32_t a = 0; a < keep; a++) {
-                if (sc[a] < cutoff) break;
-                gsim_hit o;
-                o.row = db->row_base + static_cast<uint32_t>(s.first_row) + hh[idx[a]].row;
-                o.score = sc[a];
-                o.common = cm[idx[a]];
-                o.popc_db = pc[idx[a]];
-                merged.push_back(o);
-            }
+            ap += rescore_on_host(s, query);
         }
         if (db->shards.size() > 1) std::stable_sort(merged.begin(), merged.end(), hit_before);
         const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
@@ -1313,6 +1367,21 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
             if (bytes) GSIM_HIP(hipMemcpy(s.d_rows, folded.data(), bytes, hipMemcpyHostToDevice));
             int rc = setup_shard(db, s);
             if (rc != GSIM_OK) return rc;
+            // The full fingerprints as well, when the device has room for them (on a 288 GB MI355X it practically always
+            // has: folding is then a speed device, not a capacity one): the candidates are re-scored on the GPU.  Without
+            // them the re-score runs on the host, as in the reference (fingerprintdb_cuda.cu:307-331).
+            static const int full_on_device = env_int("GSIM_FOLD_FULL_ON_DEVICE", 1);
+            const size_t full_bytes = static_cast<size_t>(s.nrows) * db->W * 4;
+            size_t fr = 0, tot = 0;
+            if (full_on_device && full_bytes && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > full_bytes + (size_t(2) << 30)) {
+                if (hipMalloc(reinterpret_cast<void**>(&s.d_full), full_bytes) == hipSuccess) {
+                    const int urc = upload_rows(s.d_full, db->host_rows.data() + s.first_row * db->W, full_bytes, nullptr);
+                    if (urc != GSIM_OK) return urc;
+                } else {
+                    (void) hipGetLastError();
+                    s.d_full = nullptr;
+                }
+            }
         }
         db->finalized = true;
         return GSIM_OK;

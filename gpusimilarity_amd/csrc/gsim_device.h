@@ -140,6 +140,14 @@ hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_
                             uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags,
                             void* d_result, hipStream_t s);
 
+// Folded tables: re-score the candidates of a folded search (result block `folded_block`, device memory) with the full
+// fingerprints, stable sort by the new score, first min(k, .) at or above the cutoff -> out_block (fingerprintdb_cuda.cu:
+// 307-331).  npad = candidates rounded up to a power of two (<= 65536): size of keys / cbs.  *nan_flag is set when a
+// score is NaN (the caller then takes the host path).
+hipError_t launch_fold_rescore(const void* folded_block, const uint32_t* full_rows, const uint32_t* full_query, uint32_t W, uint32_t qpop,
+                               unsigned long long* keys, uint32_t* cbs, uint32_t npad, uint32_t* nan_flag, uint32_t k, float cutoff,
+                               uint32_t row_base, void* out_block, hipStream_t s);
+
 // Merge of result blocks (multi-GPU gather) for nq queries: the lists of query q are the blocks
 // q, q + nq, ... (nblocks of them); merged block q goes to d_results + q * block_bytes.
 hipError_t launch_merge_batch(const void* d_blocks, uint32_t nblocks, uint32_t nq, size_t block_bytes, uint32_t k,

@@ -1309,12 +1309,16 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // one write-back for the workgroup (system scope)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        sh.ticket = atomicAdd(&st->sel_done, 1u);
+        // the ticket also carries "this selector saw the query fail" (bit 16 up): the closer learns it without another
+        // round trip (a workgroup that set QueryState::redo while publishing did so before the grid-wide wait: every
+        // selector read it after the wait and is not `good`)
+        sh.ticket = atomicAdd(&st->sel_done, good ? 1u : 0x10001u);
     }
     __syncthreads();
     GSIM_STAMP(7);
-    if (sh.ticket != nsel - 1) return;
-    const uint32_t redo = agent_load(&st->redo);
+    if ((sh.ticket & 0xFFFFu) != nsel - 1) return;
+    const uint32_t redo = ((sh.ticket >> 16) != 0 || !good) ? 1u : 0u;
+    if (redo && tid == 0) atomicOr(&st->redo, 1u); // (the gated classic kernels behind an enqueue-only launch read it)
     if (tid == 0) {
         gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
         hdr->count = redo ? 0u : (nfin < a.k ? nfin : a.k);
@@ -1987,6 +1991,78 @@ __global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u6
     }
 }
 
+// ---------------------------------------------------------------------------
+// folded tables: the candidates' re-score with the full fingerprints, on the device
+// ---------------------------------------------------------------------------
+// fingerprintdb_cuda.cu:307-331: the R = k F (int)log2(2F) best FOLDED scores of a storage are re-scored with the full
+// fingerprints (tanimoto_similarity_cpu, :387-399), stably sorted by the new score (top_results_bubble_sort: strict '>',
+// so ties keep the order of the folded list) and the first min(k, R) kept up to the first one below the cutoff.  The
+// reference does this on the host (slide 19 lists it as future GPU work); here the full rows are resident as well
+// (288 GB hold both) and three small launches do it: re-score into keys (score key << 32 | ~position), a bitonic sort
+// of the <= 64 Ki keys, emission.  A NaN score (0 / 0: two empty fingerprints) is not ordered by '>': it raises a flag
+// and the host path, which has the literal bubble sort for that case, answers the query.
+__global__ __launch_bounds__(256) void fold_rescore_kernel(const void* folded_block, const uint32_t* full_rows, const uint32_t* full_query,
+                                                           uint32_t W, uint32_t qpop, u64* keys, uint32_t* cbs, uint32_t npad,
+                                                           uint32_t* nan_flag)
+{
+    const gsim_result_header* hdr = reinterpret_cast<const gsim_result_header*>(folded_block);
+    const gsim_hit* cand = reinterpret_cast<const gsim_hit*>(hdr + 1);
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npad) return;
+    if (j >= hdr->count) {
+        keys[j] = 0ull; // padding of the sort: below every real key
+        return;
+    }
+    const uint32_t* r = full_rows + static_cast<u64>(cand[j].row) * W;
+    uint32_t cc = 0, bb = 0;
+    for (uint32_t i = 0; i < W; i++) {
+        const uint32_t x = r[i];
+        cc += __popc(x & full_query[i]);
+        bb += __popc(x);
+    }
+    const float s = score_of(GSIM_METRIC_TANIMOTO, 0.f, 0.f, qpop, bb, cc);
+    if (s != s) atomicOr(nan_flag, 1u);
+    keys[j] = (static_cast<u64>(order_key(s)) << 32) | static_cast<u64>(~j);
+    cbs[j] = (cc << 16) | bb;
+}
+
+__global__ __launch_bounds__(256) void fold_emit_kernel(const void* folded_block, const u64* sorted_keys, const uint32_t* cbs, uint32_t k,
+                                                        float cutoff, uint32_t row_base, void* out_block)
+{
+    const gsim_result_header* fh = reinterpret_cast<const gsim_result_header*>(folded_block);
+    const gsim_hit* cand = reinterpret_cast<const gsim_hit*>(fh + 1);
+    gsim_result_header* oh = reinterpret_cast<gsim_result_header*>(out_block);
+    gsim_hit* out = reinterpret_cast<gsim_hit*>(oh + 1);
+    const uint32_t keep = fh->count < k ? fh->count : k;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the list is in descending score order: "up to the first one below the cutoff" = the entries at or above it
+    if (i < keep) {
+        const u64 key = sorted_keys[i];
+        const float s = key_score(static_cast<uint32_t>(key >> 32));
+        if (!(s < cutoff)) {
+            const uint32_t j = ~static_cast<uint32_t>(key);
+            const uint32_t cb = cbs[j];
+            gsim_hit h;
+            h.row = cand[j].row + row_base;
+            h.score = s;
+            h.common = static_cast<uint16_t>(cb >> 16);
+            h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
+            out[i] = h;
+        }
+    }
+    if (i == 0) { // the count: how many of the first `keep` are at or above the cutoff (they form a prefix)
+        uint32_t lo = 0, hi = keep;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (!(key_score(static_cast<uint32_t>(sorted_keys[mid] >> 32)) < cutoff)) lo = mid + 1;
+            else hi = mid;
+        }
+        oh->count = lo;
+        oh->flags = fh->flags;
+        oh->approx = fh->approx;
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64 to)
 {
     const u64 i = from + static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -2341,6 +2417,19 @@ hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists,
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(select_kernel, dim3(kSelectBlocks), dim3(kSelectThreads), kSelectLds, s, a, finalists,
                        finalists_cb, finalists_cap, row_base, d_result);
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_rescore(const void* folded_block, const uint32_t* full_rows, const uint32_t* full_query, uint32_t W, uint32_t qpop,
+                               unsigned long long* keys, uint32_t* cbs, uint32_t npad, uint32_t* nan_flag, uint32_t k, float cutoff,
+                               uint32_t row_base, void* out_block, hipStream_t s)
+{
+    hipLaunchKernelGGL(fold_rescore_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, folded_block, full_rows, full_query, W, qpop, keys, cbs,
+                       npad, nan_flag);
+    hipError_t e = launch_bitonic_global(keys, npad, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fold_emit_kernel, dim3((k + 255) / 256 ? (k + 255) / 256 : 1), dim3(256), 0, s, folded_block, keys, cbs, k, cutoff, row_base,
+                       out_block);
     return hipGetLastError();
 }
 

@@ -442,6 +442,34 @@ def test_baseline_sizes_properties(nrows):
     t.close()
 
 
+def test_folded_search_host_rescore_route_and_nan_scores():
+    """The re-score of a folded table's candidates runs on the device when the full fingerprints are in HBM as well;
+    the host route (the reference's, fingerprintdb_cuda.cu:307-331) stays: forced here through GSIM_FOLD_RESCORE=host in a
+    child process, and taken automatically when a re-scored value is NaN (two empty fingerprints: 0 / 0), for which only
+    the literal bubble sort reproduces the reference's order."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GSIM_FOLD_RESCORE="host")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "test_folded_search_matches_reference_semantics"], env=env, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stdout.decode("utf-8", "replace")[-3000:]
+    # NaN: empty rows in the table, an empty query
+    n, W, F = 40_000, 32, 4
+    db = O.synth_rows(0xF01E, 0, 0, n, W)
+    db[::7] = 0
+    t = capi.Table(W * 32).set_fold_factor(F)
+    t.add_rows(db)
+    t.finalize(0, 1)
+    for q in (np.zeros(W, dtype=np.uint32), db[3], db[7]):
+        for k, cutoff in ((20, 0.0), (200, 0.0)):
+            hits, approx = t.search(q, k, cutoff)
+            want, wap = O.search_folded(q, db, F, k, cutoff)
+            assert int(approx[0]) == wap
+            assert len(hits[0]) == len(want) and (hits[0]["row"] == want["row"]).all()
+            assert (bits(hits[0]["score"]) == bits(want["score"])).all()
+    t.close()
+
+
 def test_sampled_threshold_and_adversarial_row_orders():
     """6 M rows: large enough for the sample kernel (starting threshold) to run.  The
     same rows in random, score-ascending (every row beats the running threshold: the
