@@ -31,10 +31,8 @@ struct QueryState {
     uint32_t redo;               // single-launch path gave up (candidate overflow, heavy ties): the gated
                                  // classic kernels behind it run the query; their select kernel clears it
     // --- single-launch path (fused_kernel) ---
-    uint32_t arrived;            // (unused since round 3: the arrival counters live next to the tickets)
-    uint32_t sel_done;           // selector workgroups that have written their hits (ticket)
-    uint32_t final_ready;        // (unused since round 3: every selector derives the final threshold itself)
-    uint32_t pad1[2];
+    uint32_t sel_done;           // selector workgroups that have written their hits (ticket; bit 16 up: selectors that saw the query fail)
+    uint32_t pad1[3];
     // --- not reset per query: running totals for gsim_db_get_timing ---
     unsigned long long ncand_sum;
     unsigned long long nfinal_sum;

@@ -582,6 +582,10 @@ struct FusedSchedule {
     // same wait and leaves ~1.5 k rows to publish instead of 4-8 k (which few workgroups would share).
     __device__ __forceinline__ bool end_ck() const { return min_trips <= 8; }
     __device__ __forceinline__ uint32_t count() const { return inloop() + (end_ck() ? 1u : 0u); } // checkpoints in all
+    // the checkpoint whose threshold a small table's workgroups wait for before they publish: the one after the loop
+    // where there is one, else the last but one in the loop (9 ... 63 trips: the last one's election ends about when the
+    // scan does -- waiting for it cost 3 us at 1 M rows, and the one before already leaves few enough rows)
+    __device__ __forceinline__ uint32_t need() const { return end_ck() ? count() : (inloop() > 1u ? inloop() - 1u : inloop()); }
     // few trips: the scan may end before the last in-loop threshold has been elected (see fused_poller)
     __device__ __forceinline__ bool late() const { return min_trips < 64; }
     // (The workgroups do not finish together: the classes blockIdx % 8 = {0,1,2,7} and {3,4,5,6} -- two halves of
@@ -847,12 +851,11 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
                                              uint32_t nwaves, uint32_t k, int lane, u64* dbg)
 {
     const bool active = fa.summ_keys != 0 && !(fa.xflags & 2u);
-    const uint32_t nck = active ? sched.count() : 0u;
-    const bool stay = sched.late();
+    const bool stay = active && sched.late();
     const unsigned long long t0 = wall_clock64();
     for (uint32_t spins = 0;; spins++) {
-        const uint32_t g = agent_load(&st->gtau);
-        const uint32_t el = agent_load(&st->elected);
+        const u64 ge = __hip_atomic_load(reinterpret_cast<const u64*>(&st->gtau), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // {gtau, elected}: one poll
+        const uint32_t g = static_cast<uint32_t>(ge), el = static_cast<uint32_t>(ge >> 32);
         if (lane == 0) {
             if (g > __hip_atomic_load(&sh.tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.tau, g);
             __hip_atomic_store(&sh.elected, el, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); // (after the threshold it belongs to)
@@ -875,7 +878,7 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
                 __hip_atomic_load(&sh.fwd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 &&
                 __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
                 // streaming over, every checkpoint forwarded, no election owed by this workgroup
-                if (!stay || el >= nck) return;
+                if (!stay || el >= sched.need()) return;
                 if (wall_clock64() - t0 > fa.wait_ticks) { // (only when part of the grid cannot start: a shared GPU)
                     if (lane == 0) {
                         atomicOr(&st->redo, 1u);
@@ -971,8 +974,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     // own region of the list (no reservation), in canonical order when there are few -- each row's position is the
     // number of larger keys in the workgroup -- and the row at position Mw - 1 is the workgroup's REPORT: "Mw distinct
     // rows of mine are at or above this 64-bit key".  The selectors derive the final threshold from the reports.
-    if (sched.late() && fa.summ_keys != 0 && !(fa.xflags & 2u)) { // small table: the last in-loop threshold may still be on its way
-        const uint32_t nck = sched.count();
+    if (sched.late() && fa.summ_keys != 0 && !(fa.xflags & 2u)) { // small table: the in-loop thresholds may still be on their way
+        const uint32_t nck = sched.need();
         while (__hip_atomic_load(&sh.elected, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nck &&
                __hip_atomic_load(&sh.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
             __builtin_amdgcn_s_sleep(4);
