@@ -2,7 +2,7 @@
 """Soak test of the single-launch query path: many thousand queries over the same table, every result compared with
 the one the four-kernel pipeline (GSIM_FUSED=0, a child process) gave for that query -- looks for rare races in the
 in-kernel protocol (thresholds, tickets, publication) that the parity suite's few hundred queries would not meet.
-    python scripts/soak_fused.py [rows] [iterations]      (on the GPU box)"""
+    python scripts/soak_fused.py [rows] [iterations]      (on the GPU box; SOAK_KIND=sparse|morgan)"""
 import os, pickle, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,18 +13,19 @@ from gpusimilarity_amd import capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000
 W, NQ = 32, 48
-cases = [(1000, 0.0), (10, 0.0), (100, 0.07), (2048, 0.0)]
+cases = [(1000, 0.0), (10, 0.0), (100, 0.07), (2048, 0.0), (8192, 0.0)]
+KIND = {"sparse": capi.SYNTH_SPARSE, "morgan": capi.SYNTH_MORGAN}[os.environ.get("SOAK_KIND", "sparse")]
 
 
 def queries():
-    own = [synth_row(DB_SEED, capi.SYNTH_SPARSE, query_row(i, n), W) for i in range(NQ - 8)]
+    own = [synth_row(DB_SEED, KIND, query_row(i, n), W) for i in range(NQ - 8)]
     fresh = [synth_row(DB_SEED + 7, capi.SYNTH_SPARSE, 1000 + i, W) for i in range(8)]
     return np.ascontiguousarray(np.stack(own + fresh))
 
 
 def table():
     t = capi.Table(32 * W)
-    t.generate(DB_SEED, capi.SYNTH_SPARSE, 0, n, 0)
+    t.generate(DB_SEED, KIND, 0, n, 0)
     return t
 
 
@@ -59,5 +60,5 @@ while done < iters:
                 print("MISMATCH iteration %d query %d k %d cutoff %g" % (done + j, qi, k, cutoff), flush=True)
     done += NQ
 tm = t.timing()
-print("soak: rows %d, %d queries in %.1f s, mismatches %d, handed back %d" % (n, done, time.time() - t0, bad, tm["handed_back"]))
+print("soak (%s rows): rows %d, %d queries in %.1f s, mismatches %d, handed back %d" % (os.environ.get("SOAK_KIND", "sparse"), n, done, time.time() - t0, bad, tm["handed_back"]))
 sys.exit(1 if bad else 0)
