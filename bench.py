@@ -182,7 +182,11 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
     distinct = min(nq, 64)  # distinct queries, cycled
     queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(distinct)]
     bufs = table.make_search_buffers(qps, k)
-    ss = ShardedSearch(table, k, ctx["dev"], stream=ctx["stream"]) if sharded else None
+    # two gather+merge objects on the one stream: while the host waits for query i's hits, query i + 1's local search,
+    # all-gather and merge are already enqueued behind it (each object has its own blocks and completion event)
+    pair = [ShardedSearch(table, k, ctx["dev"], stream=ctx["stream"]) for _ in range(2)] if sharded else None
+    ss = pair[0] if sharded else None
+    last = [ss]
     steps_q = [np.ascontiguousarray(np.stack([queries[(s_ * qps + j) % distinct] for j in range(qps)])) for s_ in range(warmup + steps)]
 
     def one_step(s_):
@@ -193,15 +197,21 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
             # next one is launched when they are there; no Python between the queries
             table.search_each_into(steps_q[s_], k, bufs)
             return
+        pending = None
         for j in range(qps):
-            ss.enqueue(steps_q[s_][j])  # local top-k -> all-gather (k*12+16 B per GPU) -> rank merge -> D2H
-            ss.synchronize()  # the query is done when its k hits are in host memory
+            cur = pair[j & 1]
+            cur.enqueue(steps_q[s_][j])  # local top-k -> all-gather (k*12+16 B per GPU) -> rank merge -> D2H
+            if pending is not None:
+                pending.synchronize()  # a query is done when its k hits are in host memory
+            pending = cur
+        pending.synchronize()
+        last[0] = pending
 
     for s_ in range(warmup):
         one_step(s_)
     if warmup:
         if sharded:
-            hits, approx, _ = ss.result()
+            hits, approx, _ = last[0].result()
         else:
             hits, approx = bufs[0][qps - 1, :bufs[1][qps - 1]], int(bufs[2][qps - 1])
         want_row = query_row((warmup * qps - 1) % distinct, total_rows)
@@ -459,9 +469,9 @@ def main():
             "query_execution": ("one query at a time on the GPU; gsim_db_search_each keeps up to 8 of the step's queries "
                                 "enqueued ahead (own result block each), no query shares a table pass with another"
                                 if not sharded else
-                                "one query at a time, NOT pipelined: local search, all-gather, merge, D2H, host waits, then the "
-                                "next (the N = 1 line keeps 8 queries enqueued and holds 100 M rows per GPU, this one %d M: "
-                                "compare per-GPU rates, not ms/query)" % (R // 1_000_000)),
+                                "one query at a time on every GPU: local search, all-gather, merge, D2H; the next query's are "
+                                "enqueued behind it while the host waits for this one's hits (two in flight; the N = 1 line keeps 8 "
+                                "and holds 100 M rows per GPU, this one %d M: compare per-GPU rates, not ms/query)" % (R // 1_000_000)),
         },
         "whole_path_hbm_frac": res["whole_path_hbm_frac"],
         "roofline": res["roofline"],

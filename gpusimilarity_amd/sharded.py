@@ -55,8 +55,13 @@ class _Gather:
         # configuration -- two ranks sharing one GPU, which RCCL refuses; production is nccl = RCCL)
         self.staged = self.on_gpu and self.world > 1 and self.backend != "nccl"
         self.stream = None
+        self.done = None
         if self.on_gpu:
             self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+            # recorded behind every enqueue's last operation (the copy of the merged block to pinned host memory):
+            # synchronize() waits for THIS object's last result only, so a second object on the same stream can have
+            # the next query's search, gather and merge enqueued behind it meanwhile
+            self.done = torch.cuda.Event()
         self.table = None
         if isinstance(local, capi.Table):
             if not self.on_gpu:
@@ -85,9 +90,9 @@ class _Gather:
             self.dist.all_gather_into_tensor(gathered, local, group=self.group)
 
     def synchronize(self):
-        """Wait until the last enqueued result is in host memory."""
+        """Wait until the last enqueued result of this object is in host memory."""
         if self.on_gpu:
-            self.stream.synchronize()
+            self.done.synchronize()
 
     def describe(self):
         """Facts about this rank's place in the group (bench.py puts them into its JSON line)."""
@@ -139,6 +144,7 @@ class ShardedSearch(_Gather):
                 capi.merge_device(self.device.index or 0, self.stream.cuda_stream, self.gathered.data_ptr(),
                                   self.world, self.blk, self.k, self.merged.data_ptr())
                 self.host_out.copy_(self.merged, non_blocking=True)
+                self.done.record(self.stream)
             else:
                 out = capi.merge_host(self.gathered.numpy().tobytes(), self.world, self.blk, self.k)
                 self.host_out.copy_(self.torch.frombuffer(bytearray(out), dtype=self.torch.uint8))
@@ -196,6 +202,7 @@ class ShardedBatchSearch(_Gather):
                 capi.merge_device_batch(self.device.index or 0, self.stream.cuda_stream, gathered.data_ptr(),
                                         self.world, nq, self.blk, self.k, self.merged.data_ptr())
                 self.host_out[:n].copy_(self.merged[:n], non_blocking=True)
+                self.done.record(self.stream)
             else:
                 raw = gathered.numpy().tobytes()
                 out = bytearray()
