@@ -488,7 +488,9 @@ constexpr int kFusedFinalLds = 16384;   // finalists a selector ranks (LDS)
 constexpr int kFusedMineCap = 2048;     // ... of which it owns at most this many
 constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder, poller/elector)
 constexpr uint32_t kFusedPrefix = 16;   // entries of every region a selector requests before it knows the region's count
-constexpr uint32_t kFusedSortCap = 256; // a workgroup with up to this many rows publishes them in canonical order
+constexpr uint32_t kFusedSortCap = 128; // a workgroup with up to this many rows publishes them in canonical order (the count is
+                                        // quadratic: 256 rows that all sit in one wave's store cost 10 us)
+constexpr uint32_t kFusedItems = 2048;  // 64-entry reads beyond the prefixes a selector lists at a time
 
 struct FusedShared {
     union {
@@ -507,8 +509,6 @@ struct FusedShared {
             } u;
         } sel;
     };
-    uint32_t rn[kFusedSelectors];   // regions read beyond the prefix: entries | sorted << 31 (parallel to cont)
-    uint16_t cont[kFusedSelectors]; // ... their numbers: more finalists than the requested prefix holds, or not in order
     u64 tauf;                       // the final threshold
     uint32_t tau;       // workgroup's copy of the score-key threshold (monotone; kept fresh by the service wave)
     uint32_t overflow;  // a wave's store overflowed
@@ -521,7 +521,8 @@ struct FusedShared {
     uint32_t ck_cnt[kFusedCheckpoints];             // streaming waves that have left their summary for checkpoint j
     uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
     uint32_t wcount[kScanBlock / 64];
-    uint32_t nfin, nmine, ncont, ok, ticket;
+    uint32_t nfin, nmine, ok, ticket, nitems;
+    uint32_t items[kFusedItems];    // further reads of the selectors, 64 entries each: region | first entry / 16 << 8 | (entries - 1) << 17
 };
 
 __device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             sh.ok = (ok && agent_load(&st->redo) == 0) ? 1u : 0u; // (one reader: the value is the same for the whole workgroup)
             sh.nfin = 0;
             sh.nmine = 0;
-            sh.ncont = 0;
+            sh.nitems = 0;
             sh.tauf = 0ull;
         }
     }
@@ -1172,6 +1173,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     // finalists = the published rows at or above the final threshold -> LDS.  Thread g takes region g's staged entries
     // (all sixteen reads issued at once); the rows this selector owns (a hash of the row) are noted with their popcounts.
     bool good = good0;
+    uint32_t my_at = 0, my_nch = 0, my_from = 0, my_n = 0; // this thread's region: its items in the list of further reads
     {
         const uint32_t g16 = static_cast<uint32_t>(tid) * kFusedPrefix;
         const uint32_t first = my_part * kFusedPrefix; // this thread's sixteen entries of the region: first .. first + 15
@@ -1185,16 +1187,30 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             passm |= (static_cast<uint32_t>(j) < npre && ((static_cast<u64>(ev[j].y) << 32) | ev[j].x) >= tauf) ? (1u << j) : 0u;
         const uint32_t cnt = static_cast<uint32_t>(__popc(passm));
         // exclusive prefix sum of cnt over the wave (DPP row shifts + the row totals), one LDS atomic per wave
-        uint32_t incl = cnt;
-        { uint32_t o; o = dpp_shr<1>(incl); incl += o; o = dpp_shr<2>(incl); incl += o; o = dpp_shr<4>(incl); incl += o; o = dpp_shr<8>(incl); incl += o; }
-        const uint32_t row_tot0 = __builtin_amdgcn_readlane(incl, 15), row_tot1 = __builtin_amdgcn_readlane(incl, 31),
-                       row_tot2 = __builtin_amdgcn_readlane(incl, 47), row_tot3 = __builtin_amdgcn_readlane(incl, 63);
-        const int rowi = lane >> 4;
-        incl += (rowi > 0 ? row_tot0 : 0u) + (rowi > 1 ? row_tot1 : 0u) + (rowi > 2 ? row_tot2 : 0u);
-        const uint32_t wtot = row_tot0 + row_tot1 + row_tot2 + row_tot3;
-        uint32_t base = 0;
-        if (lane == 0 && wtot) base = atomicAdd(&sh.nfin, wtot);
+        auto wave_scan = [&](uint32_t v, uint32_t& tot) -> uint32_t { // inclusive prefix sum over the wave, and the total
+            uint32_t incl = v;
+            { uint32_t o; o = dpp_shr<1>(incl); incl += o; o = dpp_shr<2>(incl); incl += o; o = dpp_shr<4>(incl); incl += o; o = dpp_shr<8>(incl); incl += o; }
+            const uint32_t row_tot0 = __builtin_amdgcn_readlane(incl, 15), row_tot1 = __builtin_amdgcn_readlane(incl, 31),
+                           row_tot2 = __builtin_amdgcn_readlane(incl, 47), row_tot3 = __builtin_amdgcn_readlane(incl, 63);
+            const int rowi = lane >> 4;
+            incl += (rowi > 0 ? row_tot0 : 0u) + (rowi > 1 ? row_tot1 : 0u) + (rowi > 2 ? row_tot2 : 0u);
+            tot = row_tot0 + row_tot1 + row_tot2 + row_tot3;
+            return incl;
+        };
+        // more rows of this region may qualify: its list is longer than the prefix and either not in order or still
+        // above the threshold at the prefix's end.  The rest of it is cut into items of 64 entries (below).
+        const uint32_t pre_all = kFusedPrefix << lgS; // entries of a region that were requested
+        const bool more = good0 && (sorted_mine ? (my_part == (1u << lgS) - 1u && n_mine > pre_all && cnt == kFusedPrefix) : (my_part == 0 && n_mine > 0));
+        my_n = n_mine;
+        my_from = sorted_mine ? pre_all : 0u;
+        my_nch = more ? (my_n - my_from + 63u) / 64u : 0u;
+        uint32_t wtot, wtot2;
+        const uint32_t incl = wave_scan(cnt, wtot), incl2 = wave_scan(my_nch, wtot2);
+        uint32_t base = 0, base2 = 0;
+        if (lane == 0 && wtot) base = atomicAdd(&sh.nfin, wtot); // (one LDS atomic per wave and list, not one per lane)
+        if (lane == 0 && wtot2) base2 = atomicAdd(&sh.nitems, wtot2);
         base = __builtin_amdgcn_readfirstlane(base);
+        my_at = __builtin_amdgcn_readfirstlane(base2) + incl2 - my_nch;
         const uint32_t slot0 = base + incl - cnt;
 #pragma unroll
         for (int j = 0; j < PL; j++) {
@@ -1210,16 +1226,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 }
             }
         }
-        // more rows of this region may qualify: its list is longer than the prefix and either not in order or still
-        // above the threshold at the prefix's end
-        const uint32_t pre_all = kFusedPrefix << lgS; // entries of a region that were requested
-        if (good0 && (sorted_mine ? (my_part == (1u << lgS) - 1u && n_mine > pre_all && cnt == kFusedPrefix) : (my_part == 0 && n_mine > 0))) {
-            const uint32_t c = atomicAdd(&sh.ncont, 1u);
-            sh.cont[c] = static_cast<uint16_t>(my_region);
-            sh.rn[c] = n_mine | (sorted_mine ? 0x80000000u : 0u);
-        }
     }
-    __syncthreads();
     auto take = [&](bool in, const u32x4& ent) { // one published row per lane -> the finalists, if it is at or above the threshold
         const u64 key = (static_cast<u64>(ent.y) << 32) | ent.x;
         const bool pass = in && key >= tauf;
@@ -1241,15 +1248,43 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         }
     };
     {
-        const uint32_t nc = sh.ncont;
-        for (uint32_t ci = 0; ci < nc; ci++) { // (clustered rows, ties, regions not in order: rare)
-            const uint32_t gi = sh.cont[ci];
-            const uint32_t rnv = sh.rn[ci];
-            const uint32_t n_g = rnv & 0x7FFFFFFFu;
+        // Regions read beyond their prefix (series of analogs in neighbouring rows, ties, regions not in order).  Their
+        // further entries are cut into items of 64 (one per lane), listed in LDS; every wave takes every fourth item,
+        // eight at a time with the eight loads in flight together: 32 items per round trip, whichever regions they
+        // belong to (region by region, 256 entries at a time, the usual thirty short remainders cost 8 us here).
+        // item = region | first entry / 16 << 8 | (entries - 1) << 17; the thread of a region writes its items at the
+        // positions the prefix sums above gave it.  A list longer than kFusedItems is taken in passes.
 #pragma unroll 1
-            for (uint32_t i0 = (rnv >> 31) ? (kFusedPrefix << lgS) : 0u; i0 < n_g; i0 += kScanBlock) {
-                const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(prsrc, gi * (kFusedRegion * 16u) + (i0 + tid) * 16u, 0, /*sc1*/ 16);
-                take(i0 + tid < n_g, x);
+        for (uint32_t pass0 = 0;; pass0 += kFusedItems) {
+            if (pass0) __syncthreads(); // the previous pass has been read
+            {
+                const uint32_t lo = my_at > pass0 ? my_at : pass0;
+                const uint32_t hi = my_at + my_nch < pass0 + kFusedItems ? my_at + my_nch : pass0 + kFusedItems;
+                for (uint32_t i = lo; i < hi; i++) {
+                    const uint32_t start = my_from + (i - my_at) * 64u;
+                    const uint32_t cnt = my_n - start < 64u ? my_n - start : 64u;
+                    sh.items[i - pass0] = my_region | ((start / 16u) << 8) | ((cnt - 1u) << 17);
+                }
+            }
+            __syncthreads(); // the items -- and, the first time, their number and the finalists of the prefixes
+            const uint32_t nitems = sh.nitems;
+            if (pass0 >= nitems) break;
+            const uint32_t npass = nitems - pass0 < kFusedItems ? nitems - pass0 : kFusedItems;
+            constexpr int IF = 8;
+#pragma unroll 1
+            for (uint32_t i0 = static_cast<uint32_t>(wv); i0 < npass; i0 += 4u * IF) {
+                u32x4 x[IF];
+                uint32_t lim = 0;
+#pragma unroll
+                for (int u = 0; u < IF; u++) {
+                    const uint32_t idx = i0 + 4u * static_cast<uint32_t>(u);
+                    const uint32_t item = sh.items[idx < npass ? idx : i0]; // (past the list: this wave's first item again, not taken)
+                    const uint32_t start = ((item >> 8) & 0x1FFu) * 16u, cnt = ((item >> 17) & 63u) + 1u;
+                    lim |= (idx < npass && static_cast<uint32_t>(lane) < cnt) ? (1u << u) : 0u;
+                    x[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (item & 0xFFu) * (kFusedRegion * 16u) + (start + static_cast<uint32_t>(lane)) * 16u, 0, /*sc1*/ 16);
+                }
+#pragma unroll
+                for (int u = 0; u < IF; u++) take((lim >> u) & 1u, x[u]);
             }
         }
     }
