@@ -624,6 +624,17 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
             *mn = n ? lo : 0, *mx = hi, *av = n ? sum / n : 0;
         };
         double a, b, c;
+        { // what the workgroups published: the headers stay as the query left them
+            std::vector<uint32_t> hd(nwg * 4);
+            (void) hipMemcpy(hd.data(), s.d_hdr, hd.size() * 4, hipMemcpyDeviceToHost);
+            unsigned long long rows = 0;
+            uint32_t unsorted = 0, most = 0;
+            for (size_t g = 0; g < nwg; g++) {
+                const uint32_t n = hd[4 * g] & 0x7FFFFFFFu;
+                rows += n, most = std::max(most, n), unsorted += (hd[4 * g] >> 31) ? 0u : 1u;
+            }
+            std::fprintf(stderr, "published: %llu rows by %zu workgroups (most: %u; %u lists not in order)\n", rows, nwg, most, unsorted);
+        }
         std::fprintf(stderr, "fused phases, us after the first workgroup started (min/avg/max over workgroups):\n");
         const char* names[] = {"start", "scan-end(w0)", "compacted", "published", "sel:all-arrived", "sel:filtered", "sel:ranked", "sel:fenced",
                                "tau-first-seen", "ckpt0-done", "elect-start", "elect-end"};
@@ -1893,6 +1904,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
     db->acc.candidates_sum = 0;
     db->acc.finalists_sum = 0;
     db->acc.handed_back = 0;
+    db->acc.handed_back_why = 0;
     for (auto& s : db->shards) {
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
@@ -1903,6 +1915,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
         db->acc.candidates_sum += c - s.base_ncand;
         db->acc.finalists_sum += f - s.base_nfinal;
         db->acc.handed_back += r - s.base_nredo;
+        db->acc.handed_back_why |= s.h_state->redo_why & 31u; // (bit 5 = "a selector saw it fail": not a reason of its own)
     }
     *out = db->acc;
     return GSIM_OK;

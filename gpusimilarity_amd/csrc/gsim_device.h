@@ -32,13 +32,22 @@ struct QueryState {
                                  // classic kernels behind it run the query; their select kernel clears it
     // --- single-launch path (fused_kernel) ---
     uint32_t sel_done;           // selector workgroups that have written their hits (ticket; bit 16 up: selectors that saw the query fail)
-    uint32_t pad1[3];
+    uint32_t redo_why;           // ... not reset per query: the union of the reasons (kRedo*) of every query handed back so far
+    uint32_t pad1[2];
     // --- not reset per query: running totals for gsim_db_get_timing ---
     unsigned long long ncand_sum;
     unsigned long long nfinal_sum;
     unsigned long long queries;
     unsigned long long redo_sum; // queries the single-launch path handed back to the four-kernel pipeline
 };
+
+// Why the single-launch path handed a query back (bits of QueryState::redo; the gated kernels only test for non-zero).
+constexpr uint32_t kRedoStore = 1;        // a wave met more rows at its threshold than its LDS store holds / a region overflowed
+constexpr uint32_t kRedoElectionWait = 2; // small table: a threshold election did not arrive within wait_ticks (shared GPU)
+constexpr uint32_t kRedoArrivalWait = 4;  // the grid-wide arrival did not complete within wait_ticks (shared GPU)
+constexpr uint32_t kRedoFinalists = 8;    // more rows at or above the final threshold than a selector's LDS holds
+constexpr uint32_t kRedoOwned = 16;       // ... or more of them owned by one selector than its list holds
+constexpr uint32_t kRedoSeen = 32;        // a selector found the query already failed
 
 struct ScanGeometry {
     uint32_t lanes_per_row; // 16-byte lanes per fingerprint (fp words / 4), 0 = generic path

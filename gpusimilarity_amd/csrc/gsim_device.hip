@@ -882,7 +882,7 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
                 if (!stay || el >= sched.need()) return;
                 if (wall_clock64() - t0 > fa.wait_ticks) { // (only when part of the grid cannot start: a shared GPU)
                     if (lane == 0) {
-                        atomicOr(&st->redo, 1u);
+                        atomicOr(&st->redo, kRedoElectionWait);
                         __hip_atomic_store(&sh.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     return;
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries (and header parts) are out
     __syncthreads();
     if (tid == 0) {
-        if (bad) atomicOr(&st->redo, 1u);
+        if (bad) atomicOr(&st->redo, kRedoStore);
         // The arrival, two levels (MI355X_MICROARCH.md "barrier-xcd"): a counter per group of workgroups b % 8 (the XCD a
         // block lands on, as observed -- only speed depends on it), the group's last arriver adds to the top counter,
         // the last of those raises one generation word per group.  Every workgroup then polls ITS group's word: 32
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             __builtin_amdgcn_s_sleep(2);
             if ((spins & 255u) == 255u && wall_clock64() - t_wait > fa.wait_ticks) {
                 ok = 0;
-                if (lane == 0) atomicOr(&st->redo, 1u);
+                if (lane == 0) atomicOr(&st->redo, kRedoArrivalWait);
                 break;
             }
         }
@@ -1290,6 +1290,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     __syncthreads();
     const uint32_t nfin = sh.nfin;
+    uint32_t why = good ? 0u : kRedoSeen;
+    if (good && nfin > static_cast<uint32_t>(kFusedFinalLds)) why = kRedoFinalists;
     good = good && nfin <= static_cast<uint32_t>(kFusedFinalLds);
     if (good) {
         if (tid == 0 && (nfin & 1u)) sh.sel.fkey[nfin] = 0ull; // pad to a pair for the b128 reads (nfin < kFusedFinalLds or even)
@@ -1297,6 +1299,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         GSIM_STAMP(5);
         const uint32_t nmine = sh.nmine;
         good = nmine <= static_cast<uint32_t>(kFusedMineCap);
+        if (!good) why = kRedoOwned;
         if (good) {
             gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
             gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
@@ -1339,7 +1342,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             }
         }
     }
-    if (!good && tid == 0) atomicOr(&st->redo, 1u);
+    if (!good && tid == 0) atomicOr(&st->redo, why);
     // ---- 5. the last selector closes the query -----------------------------------------------
     GSIM_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its hits have left the CU
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     GSIM_STAMP(7);
     if ((sh.ticket & 0xFFFFu) != nsel - 1) return;
     const uint32_t redo = ((sh.ticket >> 16) != 0 || !good) ? 1u : 0u;
-    if (redo && tid == 0) atomicOr(&st->redo, 1u); // (the gated classic kernels behind an enqueue-only launch read it)
+    if (redo && tid == 0) atomicOr(&st->redo, kRedoSeen); // (the gated classic kernels behind an enqueue-only launch read it)
     if (tid == 0) {
         gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
         hdr->count = redo ? 0u : (nfin < a.k ? nfin : a.k);
@@ -1374,6 +1377,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         st->nfinal_sum += redo ? 0u : nfin;
         st->queries += redo ? 0u : 1u;
         st->redo_sum += redo ? 1u : 0u;
+        if (redo) st->redo_why |= __hip_atomic_load(&st->redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->kept, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->ncand, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->gtau, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -81,6 +81,10 @@ typedef struct {
     uint64_t batches;        /* multi-query passes timed (gsim_db_search with nq >= 4)                  */
     double batch_kernel_ms_sum; /* sum of their dominant kernel's durations (the matrix-core contraction,
                                    or all table passes of the VALU route)                               */
+    uint64_t handed_back_why;   /* union of the reasons, since the handle was created: 1 a wave's candidate store or a
+                                   workgroup's list overflowed (heavy ties, ascending scores), 2 / 4 a wait ran out
+                                   (GPU shared with another process), 8 more rows at the final threshold than a
+                                   selector holds, 16 more of them owned by one selector than its list holds           */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */

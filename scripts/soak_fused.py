@@ -44,6 +44,7 @@ ref = pickle.load(open(path, "rb"))
 t, qs = table(), queries()
 t.enable_timing(True)
 bad, done, t0 = 0, 0, time.time()
+hb_by_case, hb_seen = {}, 0
 rng = np.random.default_rng(1)
 while done < iters:
     k, cutoff = cases[int(rng.integers(len(cases)))]
@@ -59,6 +60,12 @@ while done < iters:
             if bad < 5:
                 print("MISMATCH iteration %d query %d k %d cutoff %g" % (done + j, qi, k, cutoff), flush=True)
     done += NQ
+    hb = t.timing()["handed_back"]
+    if hb != hb_seen:
+        hb_by_case[(k, cutoff)] = hb_by_case.get((k, cutoff), 0) + hb - hb_seen
+        hb_seen = hb
 tm = t.timing()
+if hb_by_case:
+    print("handed back by (k, cutoff):", sorted(hb_by_case.items()))
 print("soak (%s rows): rows %d, %d queries in %.1f s, mismatches %d, handed back %d" % (os.environ.get("SOAK_KIND", "sparse"), n, done, time.time() - t0, bad, tm["handed_back"]))
 sys.exit(1 if bad else 0)
