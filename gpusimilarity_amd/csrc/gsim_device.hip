@@ -489,10 +489,12 @@ constexpr int kFusedMineCap = 2048;     // ... of which it owns at most this man
 constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder, poller/elector)
 constexpr uint32_t kFusedPrefix = 16;   // entries of every region a selector requests before it knows the region's count
 constexpr uint32_t kFusedSortCap = 128; // a workgroup with up to this many rows publishes them in canonical order (the count is
-                                        // quadratic: 256 rows that all sit in one wave's store cost 10 us)
-constexpr uint32_t kFusedItems = 2048;  // 64-entry reads beyond the prefixes a selector lists at a time
+                                        // quadratic: 256 rows that all sit in one wave's store cost 10 us); more: in bucket order
+constexpr uint32_t kFusedItems = 1024;  // 64-entry reads beyond the prefixes a selector lists per round (at most 4 per region)
+constexpr uint32_t kFusedRankDirect = 2048; // up to this many finalists a selector ranks its rows by comparing each with every finalist
+constexpr uint32_t kFusedBins = 1024;   // buckets of the order in which a workgroup with more than kFusedSortCap rows publishes them
 
-struct FusedShared {
+struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
     union {
         struct { // while streaming
             u64 key[kScanBlock / 64][kFusedWaveCap];
@@ -521,9 +523,26 @@ struct FusedShared {
     uint32_t ck_cnt[kFusedCheckpoints];             // streaming waves that have left their summary for checkpoint j
     uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
     uint32_t wcount[kScanBlock / 64];
-    uint32_t nfin, nmine, ok, ticket, nitems;
-    uint32_t items[kFusedItems];    // further reads of the selectors, 64 entries each: region | first entry / 16 << 8 | (entries - 1) << 17
+    uint32_t nfin, nmine, ok, ticket;
+    uint32_t nitems[4];             // selectors: items listed for round r at [r % 4]
+    uint32_t hmin, hmax;            // publish: range of the workgroup's score keys
+    uint32_t repbin;                // ... the bucket its report lies in (kFusedBins: none)
+    uint32_t repabove;              // ... the rows in higher buckets
+    u64 repmin;                     // ... the report
+    uint32_t rn[kFusedSelectors];   // selectors: entries | bucket shift << 16 | exact order << 31 of every region
+    union {
+        uint32_t items[2][kFusedItems]; // selectors: further reads, 64 entries each (round r in [r % 2]):
+                                        // region | first entry / 16 << 8 | (entries - 1) << 17 | last item of its region in this round << 23
+        uint32_t hist[kFusedBins];      // publish: rows per bucket, then each bucket's next position in the list
+        struct {                        // selectors, ranking many finalists by bucket:
+            uint32_t hist[kFusedBins];  //   finalists per bucket of the 64-bit key, then the finalists in higher buckets
+            uint32_t head[kFusedBins];  //   the first of this selector's rows in the bucket (+ 1); they are chained
+            uint32_t queue[kScanBlock / 64][128]; // per wave: (finalist, row of this selector in its bucket) pairs to compare
+        } rk;
+    };
 };
+
+static_assert(sizeof(FusedShared) <= 160 * 1024, "FusedShared exceeds the LDS of a CU");
 
 __device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
 {
@@ -909,6 +928,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (tid == 0) {
         sh.tau = 0;
         sh.overflow = 0;
+        sh.hmin = ~0u;
+        sh.hmax = 0u;
         sh.nemit = 0;
         sh.scan_done = 0;
         sh.elect_req = 0;
@@ -983,6 +1004,22 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     f.refresh(0u, lane); // (the service wave kept the workgroup's LDS copy of the threshold fresh: no global load here)
     if (!f.store_off) f.compact_store(lane);
+    { // (for the bucket order below: the range of the workgroup's score keys, the buckets' counters)
+        uint32_t lo = ~0u, hi = 0u;
+        const uint32_t nst = f.store_off ? 0u : f.staged;
+        for (uint32_t i = lane; i < nst; i += 64) {
+            const uint32_t h = static_cast<uint32_t>(f.skey[i] >> 32);
+            lo = h < lo ? h : lo;
+            hi = h > hi ? h : hi;
+        }
+        hi = wave_max_u32(hi);
+        lo = ~wave_max_u32(~lo);
+        if (lane == 0 && nst) {
+            atomicMax(&sh.hmax, hi);
+            atomicMin(&sh.hmin, lo);
+        }
+        for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) sh.hist[i] = 0;
+    }
     if (lane == 0) {
         sh.wcount[wv] = f.store_off ? 0u : f.staged;
         if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
@@ -990,80 +1027,137 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     __syncthreads(); // (released once the service waves have exited too)
     GSIM_STAMP(2);
     const bool bad = __hip_atomic_load(&sh.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
-    uint32_t ntot = 0, off = 0;
+    uint32_t ntot = 0;
 #pragma unroll
     for (int i = 0; i < kScanBlock / 64; i++) {
         const uint32_t c = sh.wcount[i];
-        off += i < wv ? c : 0u;
         ntot += c;
     }
     if (bad) ntot = 0;
+    // Up to kFusedSortCap rows: canonical order, each row's position is the number of larger keys in the workgroup.  More
+    // (a late threshold on a short table, a large k, series of analogs, ties): BUCKET order -- a counting sort by
+    // (score key >> shift), 1024 buckets over the workgroup's range of score keys, highest bucket first, any order
+    // inside a bucket.  Either way a selector reads a list from its head and stops at the first entry that proves the
+    // rest lies below the final threshold: whatever a workgroup publishes beyond the finalists costs nobody a read
+    // (unordered lists were read in full by every selector: k = 8192 on 1 M rows published 180 k rows, 200 us).
     const bool sorted = ntot <= kFusedSortCap;
     const uint32_t Mw = fa.final_keys; // rows a workgroup's report stands for (fused_final_keys)
     const __amdgpu_buffer_rsrc_t hrsrc_w = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
-    {
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            static_cast<unsigned char*>(fa.pub) + static_cast<size_t>(blockIdx.x) * (kFusedRegion * 16u), 0, kFusedRegion * 16u, 0x00020000);
-        const uint32_t mine_n = bad ? 0u : f.staged;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<unsigned char*>(fa.pub) + static_cast<size_t>(blockIdx.x) * (kFusedRegion * 16u), 0, kFusedRegion * 16u, 0x00020000);
+    const uint32_t mine_n = bad ? 0u : f.staged;
+    uint32_t shift = 0;
+    if (sorted) {
         for (uint32_t i = lane; i < mine_n; i += 64) {
             const u64 key = f.skey[i];
-            uint32_t pos = off + i;
-            if (sorted) { // canonical position inside the workgroup: the number of larger keys (keys are unique)
-                pos = 0;
+            uint32_t pos = 0; // the number of larger keys (keys are unique)
 #pragma unroll 1
-                for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
-                    const uint32_t cnt = sh.wcount[w2];
-                    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.store.key[w2]);
-                    for (uint32_t j = 0; j < cnt; j += 2) {
-                        const ulonglong2 kk = k2[j >> 1];
-                        pos += kk.x > key ? 1u : 0u;
-                        pos += (j + 1 < cnt && kk.y > key) ? 1u : 0u;
-                    }
+            for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
+                const uint32_t cnt = sh.wcount[w2];
+                const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.store.key[w2]);
+                for (uint32_t j = 0; j < cnt; j += 2) {
+                    const ulonglong2 kk = k2[j >> 1];
+                    pos += kk.x > key ? 1u : 0u;
+                    pos += (j + 1 < cnt && kk.y > key) ? 1u : 0u;
                 }
-                if (Mw && pos == Mw - 1u) // the workgroup's report: straight into its header (bytes 8..15)
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32)}, hrsrc_w,
-                                                          blockIdx.x * kFusedHeaderBytes + 8u, 0, /*sc1*/ 16);
             }
+            if (Mw && pos == Mw - 1u) // the workgroup's report: straight into its header (bytes 8..15)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32)}, hrsrc_w,
+                                                      blockIdx.x * kFusedHeaderBytes + 8u, 0, /*sc1*/ 16);
             const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
             __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
         }
-    }
-    if (!sorted && Mw && wv == 0) { // (many rows: ties, clusters, a late threshold) the Mw-th best of the four stores, by one wave
-        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
-            const uint32_t cnt = sh.wcount[w2];
-            for (uint32_t i = lane; i < cnt; i += 64) {
-                const u64 v = sh.store.key[w2][i];
-                if (v > t3) {
-                    t3 = v;
-                    if (t3 > t2) { const u64 x = t2; t2 = t3; t3 = x; }
-                    if (t2 > t1) { const u64 x = t1; t1 = t2; t2 = x; }
-                    if (t1 > t0) { const u64 x = t0; t0 = t1; t1 = x; }
+    } else {
+        const uint32_t hmin = sh.hmin, hmax = sh.hmax, span = hmax - hmin;
+        const uint32_t bits = span ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(span))) : 0u;
+        shift = bits > 10u ? bits - 10u : 0u;
+        if ((hmax >> shift) - (hmin >> shift) >= kFusedBins) shift++; // (span >> shift < 1024, the difference of the quotients may be one more)
+        const uint32_t binbase = hmin >> shift;
+        for (uint32_t i = lane; i < mine_n; i += 64) atomicAdd(&sh.hist[(static_cast<uint32_t>(f.skey[i] >> 32) >> shift) - binbase], 1u);
+        __syncthreads();
+        if (wv == 0) { // a bucket's rows follow those of every higher bucket; the report's bucket: where the count reaches Mw
+            constexpr int PER = static_cast<int>(kFusedBins) / 64;
+            uint32_t h[PER];
+            uint32_t sm = 0;
+#pragma unroll
+            for (int i = 0; i < PER; i++) {
+                h[i] = sh.hist[lane * PER + i];
+                sm += h[i];
+            }
+            uint32_t incl = sm; // rows in the buckets of lanes >= lane
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = static_cast<uint32_t>(__shfl_down(static_cast<int>(incl), d, 64));
+                if (lane + d < 64) incl += t;
+            }
+            uint32_t acc = incl - sm, rb = kFusedBins;
+#pragma unroll
+            for (int i = PER - 1; i >= 0; i--) {
+                sh.hist[lane * PER + i] = acc;
+                if (Mw && acc < Mw && acc + h[i] >= Mw) rb = static_cast<uint32_t>(lane * PER + i);
+                acc += h[i];
+            }
+            const u64 m = __ballot(rb != kFusedBins);
+            if (m == 0 ? lane == 0 : lane == __builtin_ctzll(m)) {
+                sh.repbin = rb;
+                sh.repabove = rb != kFusedBins ? sh.hist[rb] : 0u; // (this lane wrote it: the rows in higher buckets)
+            }
+        }
+        __syncthreads();
+        const uint32_t rb = sh.repbin;
+        for (uint32_t i = lane; i < mine_n; i += 64) {
+            const u64 key = f.skey[i];
+            const uint32_t b = (static_cast<uint32_t>(key >> 32) >> shift) - binbase;
+            const uint32_t pos = atomicAdd(&sh.hist[b], 1u);
+            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
+        }
+        if (wv == 0 && rb != kFusedBins) {
+            // the report, the workgroup's Mw-th best key: the count of rows, from the top bucket down, reaches Mw in bucket
+            // rb -- the (Mw - rows above)-th best of THAT bucket's rows (usually one or two; a table-wide tie: all of them)
+            const uint32_t need = Mw - sh.repabove;
+            u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
+                const uint32_t cnt = sh.wcount[w2];
+                for (uint32_t i = lane; i < cnt; i += 64) {
+                    const u64 v = sh.store.key[w2][i];
+                    if ((static_cast<uint32_t>(v >> 32) >> shift) - binbase == rb && v > t3) {
+                        t3 = v;
+                        if (t3 > t2) { const u64 x = t2; t2 = t3; t3 = x; }
+                        if (t2 > t1) { const u64 x = t1; t1 = t2; t2 = x; }
+                        if (t1 > t0) { const u64 x = t0; t0 = t1; t1 = x; }
+                    }
                 }
             }
-        }
-        u64 mth = 0;
-        for (uint32_t rr = 0; rr < Mw; rr++) { // (a lane holding more than four of the best under-reports: still valid)
-            const uint32_t hi = wave_max_u32(static_cast<uint32_t>(t0 >> 32));
-            const uint32_t lo = wave_max_u32(static_cast<uint32_t>(t0 >> 32) == hi ? static_cast<uint32_t>(t0) : 0u);
-            mth = (static_cast<u64>(hi) << 32) | lo;
-            const u64 bm = __ballot(t0 == mth);
-            if (lane == __builtin_ctzll(bm)) {
-                t0 = t1;
-                t1 = t2;
-                t2 = t3;
-                t3 = 0;
+            u64 mth = 0;
+            for (uint32_t rr = 0; rr < need; rr++) { // (a lane holding more than four of the best under-reports: still valid)
+                const uint32_t hi = wave_max_u32(static_cast<uint32_t>(t0 >> 32));
+                const uint32_t lo = wave_max_u32(static_cast<uint32_t>(t0 >> 32) == hi ? static_cast<uint32_t>(t0) : 0u);
+                mth = (static_cast<u64>(hi) << 32) | lo;
+                const u64 bm = __ballot(t0 == mth);
+                if (lane == __builtin_ctzll(bm)) {
+                    t0 = t1;
+                    t1 = t2;
+                    t2 = t3;
+                    t3 = 0;
+                }
             }
+            if (lane == 0) sh.repmin = mth;
         }
-        if (lane == 0)
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{static_cast<uint32_t>(mth), static_cast<uint32_t>(mth >> 32)}, hrsrc_w,
-                                                  blockIdx.x * kFusedHeaderBytes + 8u, 0, /*sc1*/ 16);
+        __syncthreads();
     }
-    // the header's first half: {entries | sorted << 31, 0}.  Its second half is the report, written above by whoever
-    // found it -- and not at all when the workgroup holds fewer than Mw rows: the selectors take a report as present
-    // only if entries >= Mw, so a stale one from an earlier query is never read.
-    if (tid == 0)
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{ntot | (sorted ? 0x80000000u : 0u), 0u}, hrsrc_w, blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
+    // the header: {entries | exact order << 31, bucket shift, report}.  In exact order the report was written above by the
+    // thread that held it -- and not at all when the workgroup holds fewer than Mw rows: the selectors take a report as
+    // present only if entries >= Mw, so a stale one from an earlier query is never read.
+    if (tid == 0) {
+        if (sorted) {
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{ntot | 0x80000000u, 0u}, hrsrc_w, blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
+        } else {
+            const u64 rep = sh.repmin;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ntot, shift, static_cast<uint32_t>(rep), static_cast<uint32_t>(rep >> 32)}, hrsrc_w,
+                                                   blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries (and header parts) are out
     __syncthreads();
     if (tid == 0) {
@@ -1105,7 +1199,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             sh.ok = (ok && agent_load(&st->redo) == 0) ? 1u : 0u; // (one reader: the value is the same for the whole workgroup)
             sh.nfin = 0;
             sh.nmine = 0;
-            sh.nitems = 0;
+            sh.nitems[0] = 0;
+            sh.nitems[1] = 0;
+            sh.repmin = 0ull; // (from here on: the finalists' summed distance from the threshold)
             sh.tauf = 0ull;
         }
     }
@@ -1173,63 +1269,19 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     // finalists = the published rows at or above the final threshold -> LDS.  Thread g takes region g's staged entries
     // (all sixteen reads issued at once); the rows this selector owns (a hash of the row) are noted with their popcounts.
     bool good = good0;
-    uint32_t my_at = 0, my_nch = 0, my_from = 0, my_n = 0; // this thread's region: its items in the list of further reads
-    {
-        const uint32_t g16 = static_cast<uint32_t>(tid) * kFusedPrefix;
-        const uint32_t first = my_part * kFusedPrefix; // this thread's sixteen entries of the region: first .. first + 15
-        const uint32_t npre = (good0 && sorted_mine && n_mine > first) ? (n_mine - first < kFusedPrefix ? n_mine - first : kFusedPrefix) : 0u;
-        u32x4 ev[PL];
-#pragma unroll
-        for (int j = 0; j < PL; j++) ev[j] = staging[g16 + ((static_cast<uint32_t>(j) + static_cast<uint32_t>(tid)) % kFusedPrefix)];
-        uint32_t passm = 0; // bit j: entry j is a finalist
-#pragma unroll
-        for (int j = 0; j < PL; j++)
-            passm |= (static_cast<uint32_t>(j) < npre && ((static_cast<u64>(ev[j].y) << 32) | ev[j].x) >= tauf) ? (1u << j) : 0u;
-        const uint32_t cnt = static_cast<uint32_t>(__popc(passm));
-        // exclusive prefix sum of cnt over the wave (DPP row shifts + the row totals), one LDS atomic per wave
-        auto wave_scan = [&](uint32_t v, uint32_t& tot) -> uint32_t { // inclusive prefix sum over the wave, and the total
-            uint32_t incl = v;
-            { uint32_t o; o = dpp_shr<1>(incl); incl += o; o = dpp_shr<2>(incl); incl += o; o = dpp_shr<4>(incl); incl += o; o = dpp_shr<8>(incl); incl += o; }
-            const uint32_t row_tot0 = __builtin_amdgcn_readlane(incl, 15), row_tot1 = __builtin_amdgcn_readlane(incl, 31),
-                           row_tot2 = __builtin_amdgcn_readlane(incl, 47), row_tot3 = __builtin_amdgcn_readlane(incl, 63);
-            const int rowi = lane >> 4;
-            incl += (rowi > 0 ? row_tot0 : 0u) + (rowi > 1 ? row_tot1 : 0u) + (rowi > 2 ? row_tot2 : 0u);
-            tot = row_tot0 + row_tot1 + row_tot2 + row_tot3;
-            return incl;
-        };
-        // more rows of this region may qualify: its list is longer than the prefix and either not in order or still
-        // above the threshold at the prefix's end.  The rest of it is cut into items of 64 entries (below).
-        const uint32_t pre_all = kFusedPrefix << lgS; // entries of a region that were requested
-        const bool more = good0 && (sorted_mine ? (my_part == (1u << lgS) - 1u && n_mine > pre_all && cnt == kFusedPrefix) : (my_part == 0 && n_mine > 0));
-        my_n = n_mine;
-        my_from = sorted_mine ? pre_all : 0u;
-        my_nch = more ? (my_n - my_from + 63u) / 64u : 0u;
-        uint32_t wtot, wtot2;
-        const uint32_t incl = wave_scan(cnt, wtot), incl2 = wave_scan(my_nch, wtot2);
-        uint32_t base = 0, base2 = 0;
-        if (lane == 0 && wtot) base = atomicAdd(&sh.nfin, wtot); // (one LDS atomic per wave and list, not one per lane)
-        if (lane == 0 && wtot2) base2 = atomicAdd(&sh.nitems, wtot2);
-        base = __builtin_amdgcn_readfirstlane(base);
-        my_at = __builtin_amdgcn_readfirstlane(base2) + incl2 - my_nch;
-        const uint32_t slot0 = base + incl - cnt;
-#pragma unroll
-        for (int j = 0; j < PL; j++) {
-            if (passm & (1u << j)) {
-                const uint32_t slot = slot0 + static_cast<uint32_t>(__popc(passm & ((1u << j) - 1u)));
-                sh.sel.fkey[slot] = (static_cast<u64>(ev[j].y) << 32) | ev[j].x; // (< 4096: below the staging area)
-                if ((((~ev[j].x * 2654435761u) >> 16) * nsel) >> 16 == r) { // this selector ranks it
-                    const uint32_t mp = atomicAdd(&sh.nmine, 1u);
-                    if (mp < static_cast<uint32_t>(kFusedMineCap)) {
-                        sh.sel.u.mine.idx[mp] = slot;
-                        sh.sel.u.mine.cb[mp] = ev[j].z;
-                    }
-                }
-            }
-        }
-    }
+    // Every list is in order -- exact (canonical) or by bucket: an entry that lies below the threshold (exact order), or
+    // in a lower bucket than the threshold does (bucket order), proves that everything behind it is below the threshold.
+    const uint32_t shift_mine = sorted_mine ? 0u : (hd.y & 31u);
+    const uint32_t tauf_hi = static_cast<uint32_t>(tauf >> 32);
+    auto stops = [&](u64 key, bool exact, uint32_t shift) -> bool {
+        return exact ? key < tauf : (static_cast<uint32_t>(key >> 32) >> shift) < (tauf_hi >> shift);
+    };
+    const uint32_t pre_all = kFusedPrefix << lgS; // entries of a region that were requested
+    u64 dacc = 0; // sum over the finalists this thread lists of (score key - the threshold's): scales the ranking's buckets
     auto take = [&](bool in, const u32x4& ent) { // one published row per lane -> the finalists, if it is at or above the threshold
         const u64 key = (static_cast<u64>(ent.y) << 32) | ent.x;
         const bool pass = in && key >= tauf;
+        dacc += pass ? (key - tauf) >> 32 : 0ull;
         const u64 m = __ballot(pass);
         if (m == 0) return;
         uint32_t base = 0;
@@ -1248,45 +1300,126 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         }
     };
     {
-        // Regions read beyond their prefix (series of analogs in neighbouring rows, ties, regions not in order).  Their
-        // further entries are cut into items of 64 (one per lane), listed in LDS; every wave takes every fourth item,
-        // eight at a time with the eight loads in flight together: 32 items per round trip, whichever regions they
-        // belong to (region by region, 256 entries at a time, the usual thirty short remainders cost 8 us here).
-        // item = region | first entry / 16 << 8 | (entries - 1) << 17; the thread of a region writes its items at the
-        // positions the prefix sums above gave it.  A list longer than kFusedItems is taken in passes.
-#pragma unroll 1
-        for (uint32_t pass0 = 0;; pass0 += kFusedItems) {
-            if (pass0) __syncthreads(); // the previous pass has been read
-            {
-                const uint32_t lo = my_at > pass0 ? my_at : pass0;
-                const uint32_t hi = my_at + my_nch < pass0 + kFusedItems ? my_at + my_nch : pass0 + kFusedItems;
-                for (uint32_t i = lo; i < hi; i++) {
-                    const uint32_t start = my_from + (i - my_at) * 64u;
-                    const uint32_t cnt = my_n - start < 64u ? my_n - start : 64u;
-                    sh.items[i - pass0] = my_region | ((start / 16u) << 8) | ((cnt - 1u) << 17);
+        // finalists = the published rows at or above the final threshold -> LDS.  Thread g takes region g's staged entries
+        // (all sixteen reads issued at once); the rows this selector owns (a hash of the row) are noted with their popcounts.
+        const uint32_t g16 = static_cast<uint32_t>(tid) * kFusedPrefix;
+        const uint32_t first = my_part * kFusedPrefix; // this thread's sixteen entries of the region: first .. first + 15
+        const uint32_t npre = (good0 && n_mine > first) ? (n_mine - first < kFusedPrefix ? n_mine - first : kFusedPrefix) : 0u;
+        u32x4 ev[PL];
+#pragma unroll
+        for (int j = 0; j < PL; j++) ev[j] = staging[g16 + ((static_cast<uint32_t>(j) + static_cast<uint32_t>(tid)) % kFusedPrefix)];
+        uint32_t passm = 0, stopm = 0; // bit j: entry j is a finalist / ends the list's part at or above the threshold
+#pragma unroll
+        for (int j = 0; j < PL; j++) {
+            const u64 key = (static_cast<u64>(ev[j].y) << 32) | ev[j].x;
+            const bool pass = static_cast<uint32_t>(j) < npre && key >= tauf;
+            passm |= pass ? (1u << j) : 0u;
+            dacc += pass ? (key - tauf) >> 32 : 0ull;
+            stopm |= (static_cast<uint32_t>(j) < npre && stops(key, sorted_mine, shift_mine)) ? (1u << j) : 0u;
+        }
+        const uint32_t cnt = static_cast<uint32_t>(__popc(passm));
+        auto wave_scan = [&](uint32_t v, uint32_t& tot) -> uint32_t { // inclusive prefix sum over the wave, and the total
+            uint32_t incl = v;
+            { uint32_t o; o = dpp_shr<1>(incl); incl += o; o = dpp_shr<2>(incl); incl += o; o = dpp_shr<4>(incl); incl += o; o = dpp_shr<8>(incl); incl += o; }
+            const uint32_t row_tot0 = __builtin_amdgcn_readlane(incl, 15), row_tot1 = __builtin_amdgcn_readlane(incl, 31),
+                           row_tot2 = __builtin_amdgcn_readlane(incl, 47), row_tot3 = __builtin_amdgcn_readlane(incl, 63);
+            const int rowi = lane >> 4;
+            incl += (rowi > 0 ? row_tot0 : 0u) + (rowi > 1 ? row_tot1 : 0u) + (rowi > 2 ? row_tot2 : 0u);
+            tot = row_tot0 + row_tot1 + row_tot2 + row_tot3;
+            return incl;
+        };
+        // more rows of this region may qualify: its list is longer than the requested prefix and the prefix's last part
+        // holds no entry that ends it.  The next 64 entries become an item of round 0 (below).
+        const bool more = good0 && my_part == (1u << lgS) - 1u && n_mine > pre_all && stopm == 0;
+        uint32_t wtot, wtot2;
+        const uint32_t incl = wave_scan(cnt, wtot), incl2 = wave_scan(more ? 1u : 0u, wtot2);
+        uint32_t base = 0, base2 = 0;
+        if (lane == 0 && wtot) base = atomicAdd(&sh.nfin, wtot); // (one LDS atomic per wave and list, not one per lane)
+        if (lane == 0 && wtot2) base2 = atomicAdd(&sh.nitems[0], wtot2);
+        base = __builtin_amdgcn_readfirstlane(base);
+        base2 = __builtin_amdgcn_readfirstlane(base2);
+        if (my_part == 0) sh.rn[my_region] = n_mine | (shift_mine << 16) | (sorted_mine ? 0x80000000u : 0u);
+        if (more) {
+            const uint32_t left = n_mine - pre_all;
+            sh.items[0][base2 + incl2 - 1u] = my_region | ((pre_all / 16u) << 8) | (((left < 64u ? left : 64u) - 1u) << 17) | (1u << 23);
+        }
+        const uint32_t slot0 = base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < PL; j++) {
+            if (passm & (1u << j)) {
+                const uint32_t slot = slot0 + static_cast<uint32_t>(__popc(passm & ((1u << j) - 1u)));
+                sh.sel.fkey[slot] = (static_cast<u64>(ev[j].y) << 32) | ev[j].x; // (< 4096: below the staging area)
+                if ((((~ev[j].x * 2654435761u) >> 16) * nsel) >> 16 == r) { // this selector ranks it
+                    const uint32_t mp = atomicAdd(&sh.nmine, 1u);
+                    if (mp < static_cast<uint32_t>(kFusedMineCap)) {
+                        sh.sel.u.mine.idx[mp] = slot;
+                        sh.sel.u.mine.cb[mp] = ev[j].z;
+                    }
                 }
             }
-            __syncthreads(); // the items -- and, the first time, their number and the finalists of the prefixes
-            const uint32_t nitems = sh.nitems;
-            if (pass0 >= nitems) break;
-            const uint32_t npass = nitems - pass0 < kFusedItems ? nitems - pass0 : kFusedItems;
-            constexpr int IF = 8;
+        }
+    }
+    {
+        // Lists read beyond their prefix (a large k, series of analogs in neighbouring rows, ties), in rounds.  An item is 64
+        // entries of one region (one per lane); every wave takes every fourth item of the round's list, eight at a time
+        // with the eight loads in flight together: 32 items per round trip, whichever regions they belong to.  A region's
+        // last item of a round, if it holds no entry that ends the list, lists the region's items of the next round:
+        // as many entries again as have been read beyond the prefix, at most 4 items (the list holds 4 per region).
+        // item = region | first entry / 16 << 8 | (entries - 1) << 17 | last of its region << 23.
+        constexpr int IF = 8;
 #pragma unroll 1
-            for (uint32_t i0 = static_cast<uint32_t>(wv); i0 < npass; i0 += 4u * IF) {
+        for (uint32_t round = 0;; round++) {
+            if (tid == 0) sh.nitems[(round + 2u) % 4u] = 0; // (last read two rounds ago -- every wave is past that --, appended to in the next round)
+            __syncthreads(); // this round's items and their number (the first time: and the finalists of the prefixes)
+            const uint32_t nit = sh.nitems[round % 4u];
+            if (nit == 0) break;
+            const uint32_t* cur = sh.items[round & 1u];
+            uint32_t* nxt = sh.items[(round + 1u) & 1u];
+#pragma unroll 1
+            for (uint32_t i0 = static_cast<uint32_t>(wv); i0 < nit; i0 += 4u * IF) {
                 u32x4 x[IF];
+                uint32_t itm[IF];
                 uint32_t lim = 0;
 #pragma unroll
                 for (int u = 0; u < IF; u++) {
                     const uint32_t idx = i0 + 4u * static_cast<uint32_t>(u);
-                    const uint32_t item = sh.items[idx < npass ? idx : i0]; // (past the list: this wave's first item again, not taken)
-                    const uint32_t start = ((item >> 8) & 0x1FFu) * 16u, cnt = ((item >> 17) & 63u) + 1u;
-                    lim |= (idx < npass && static_cast<uint32_t>(lane) < cnt) ? (1u << u) : 0u;
-                    x[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (item & 0xFFu) * (kFusedRegion * 16u) + (start + static_cast<uint32_t>(lane)) * 16u, 0, /*sc1*/ 16);
+                    itm[u] = cur[idx < nit ? idx : i0]; // (past the list: this wave's first item again, not taken)
+                    const uint32_t start = ((itm[u] >> 8) & 0x1FFu) * 16u, cnt = ((itm[u] >> 17) & 63u) + 1u;
+                    lim |= (idx < nit && static_cast<uint32_t>(lane) < cnt) ? (1u << u) : 0u;
+                    x[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (itm[u] & 0xFFu) * (kFusedRegion * 16u) + (start + static_cast<uint32_t>(lane)) * 16u, 0, /*sc1*/ 16);
                 }
 #pragma unroll
-                for (int u = 0; u < IF; u++) take((lim >> u) & 1u, x[u]);
+                for (int u = 0; u < IF; u++) {
+                    const bool in = ((lim >> u) & 1u) != 0;
+                    take(in, x[u]);
+                    if (i0 + 4u * static_cast<uint32_t>(u) < nit && (itm[u] >> 23) != 0) { // (wave-uniform) the region's last item of this round
+                        const uint32_t reg = itm[u] & 0xFFu, rnv = sh.rn[reg];
+                        const uint32_t n_g = rnv & 0xFFFFu, end = ((itm[u] >> 8) & 0x1FFu) * 16u + ((itm[u] >> 17) & 63u) + 1u;
+                        const u64 key = (static_cast<u64>(x[u].y) << 32) | x[u].x;
+                        const bool stop = __ballot(in && stops(key, (rnv >> 31) != 0, (rnv >> 16) & 31u)) != 0;
+                        if (!stop && end < n_g) {
+                            uint32_t ni = (end - pre_all) / 64u; // as many entries again as read so far beyond the prefix
+                            const uint32_t left = (n_g - end + 63u) / 64u;
+                            ni = ni < 1u ? 1u : (ni > 4u ? 4u : ni);
+                            ni = ni < left ? ni : left;
+                            uint32_t at = 0;
+                            if (lane == 0) at = atomicAdd(&sh.nitems[(round + 1u) % 4u], ni);
+                            at = __builtin_amdgcn_readfirstlane(at);
+                            if (static_cast<uint32_t>(lane) < ni) {
+                                const uint32_t st0 = end + static_cast<uint32_t>(lane) * 64u;
+                                const uint32_t c = n_g - st0 < 64u ? n_g - st0 : 64u;
+                                nxt[at + lane] = reg | ((st0 / 16u) << 8) | ((c - 1u) << 17) | (static_cast<uint32_t>(lane) == ni - 1u ? (1u << 23) : 0u);
+                            }
+                        }
+                    }
+                }
             }
         }
+    }
+    { // (three 16-bit slices: each sums to less than 2^22 over the wave)
+        const u64 tot = static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc) & 0xFFFFu)) + (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 16) & 0xFFFFu)) << 16) +
+                        (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 32) & 0xFFFFu)) << 32);
+        if (lane == 0) atomicAdd(&sh.repmin, tot); // (zero since the selectors' start)
     }
     __syncthreads();
     const uint32_t nfin = sh.nfin;
@@ -1295,6 +1428,10 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     good = good && nfin <= static_cast<uint32_t>(kFusedFinalLds);
     if (good) {
         if (tid == 0 && (nfin & 1u)) sh.sel.fkey[nfin] = 0ull; // pad to a pair for the b128 reads (nfin < kFusedFinalLds or even)
+        for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) { // (for the ranking by bucket; the items are done with)
+            sh.rk.hist[i] = 0;
+            sh.rk.head[i] = 0;
+        }
         __syncthreads();
         GSIM_STAMP(5);
         const uint32_t nmine = sh.nmine;
@@ -1303,13 +1440,122 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         if (good) {
             gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
             gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+            auto write_hit = [&](u64 mine, uint32_t rank, uint32_t cb) {
+                gsim_hit h;
+                h.row = ~static_cast<uint32_t>(mine) + fa.row_base;
+                h.score = key_score(static_cast<uint32_t>(mine >> 32));
+                h.common = static_cast<uint16_t>(cb >> 16);
+                h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
+                hits[rank] = h;
+            };
+            // (the bucket route keeps a 16-byte node per row of this selector in the unused end of the finalist array)
+            const bool by_bucket = nfin > kFusedRankDirect && nfin + 2u * nmine + 2u <= static_cast<uint32_t>(kFusedFinalLds);
+            if (by_bucket) {
+                // Many finalists (a large k): comparing each of this selector's rows with every finalist is nfin^2 / #selectors
+                // 64-bit compares per selector (k = 8192: 40 us).  Instead: a histogram of the finalists over 1024 buckets of
+                // the 64-bit key between the threshold and the largest key; rank = finalists in higher buckets + larger keys
+                // in the row's own bucket, the latter counted in ONE pass over the finalists -- each looks up whether its
+                // bucket holds rows of this selector (chained per bucket) and is compared with those only.
+                // (the buckets: 1023 equal steps of the key from the threshold to four times the finalists' mean distance
+                // from it, and one for everything above -- the scores thin out quickly above the threshold, and the
+                // largest key, the query's own row, is far away: steps up to IT left 95 % of the finalists in 60 buckets)
+                const u64 base = tauf; // (every finalist is at or above the threshold)
+                // 4 x the mean distance of the score keys from the threshold's, in 1023 steps of 2^(shift - 32)
+                const u64 reach = (sh.repmin << 2) / nfin + 1ull;
+                const uint32_t rbits = 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(reach)));
+                const uint32_t shift = 32u + (rbits > 10u ? rbits - 10u : 0u);
+                auto bucket = [&](u64 key) -> uint32_t {
+                    const u64 d = (key - base) >> shift;
+                    return d < kFusedBins - 1u ? static_cast<uint32_t>(d) : kFusedBins - 1u;
+                };
+                // node t, 16 bytes from the array's end downwards: {the row's key, the bucket's next row + 1, larger keys in the bucket}
+                u32x4* nodes = reinterpret_cast<u32x4*>(&sh.sel.fkey[kFusedFinalLds]);
+                for (uint32_t t = static_cast<uint32_t>(tid); t < nmine; t += kScanBlock) {
+                    const u64 key = sh.sel.fkey[sh.sel.u.mine.idx[t]];
+                    const uint32_t before = atomicExch(&sh.rk.head[bucket(key)], t + 1u);
+                    *(nodes - 1 - static_cast<int>(t)) = u32x4{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), before, 0u};
+                }
+                __syncthreads(); // the chains
+                // A finalist whose bucket holds rows of this selector -- one in twenty -- is compared with them.  Walking the
+                // chains where they are met kept whole waves waiting on a few lanes' dependent reads (18 us); the (finalist,
+                // node) pairs go through a queue of the wave instead and are taken 64 at a time, every lane busy.
+                {
+                    uint32_t* q = sh.rk.queue[wv];
+                    uint32_t qn = 0; // (wave-uniform)
+                    auto drain = [&](bool all) {
+                        while (qn >= 64u || (all && qn != 0u)) {
+                            const uint32_t n = qn < 64u ? qn : 64u;
+                            const bool has = static_cast<uint32_t>(lane) < n;
+                            const uint32_t e = has ? q[qn - n + static_cast<uint32_t>(lane)] : 0u; // finalist | node << 14
+                            __builtin_amdgcn_wave_barrier();
+                            qn -= n;
+                            uint32_t onward = 0;
+                            if (has) {
+                                u32x4* nd = nodes - static_cast<int>(e >> 14);
+                                const u32x4 node = *nd;
+                                if (sh.sel.fkey[e & 0x3FFFu] > ((static_cast<u64>(node.y) << 32) | node.x)) atomicAdd(reinterpret_cast<uint32_t*>(nd) + 3, 1u);
+                                onward = node.z;
+                            }
+                            const u64 m = __ballot(onward != 0u);
+                            if (onward) q[qn + lane_rank(m)] = (e & 0x3FFFu) | (onward << 14);
+                            qn += static_cast<uint32_t>(__popcll(m));
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    };
+                    for (uint32_t j0 = static_cast<uint32_t>(wv) * 64u; j0 < nfin; j0 += kScanBlock) {
+                        const uint32_t j = j0 + static_cast<uint32_t>(lane);
+                        uint32_t at = 0;
+                        if (j < nfin) {
+                            const uint32_t bk = bucket(sh.sel.fkey[j]);
+                            atomicAdd(&sh.rk.hist[bk], 1u);
+                            at = sh.rk.head[bk];
+                        }
+                        const u64 m = __ballot(at != 0u);
+                        if (at) q[qn + lane_rank(m)] = j | (at << 14);
+                        qn += static_cast<uint32_t>(__popcll(m));
+                        __builtin_amdgcn_wave_barrier();
+                        drain(false);
+                    }
+                    drain(true);
+                }
+                __syncthreads();
+                if (wv == 0) { // hist[b] <- the finalists in buckets above b
+                    constexpr int PER = static_cast<int>(kFusedBins) / 64;
+                    uint32_t h[PER];
+                    uint32_t sm = 0;
+#pragma unroll
+                    for (int i = 0; i < PER; i++) {
+                        h[i] = sh.rk.hist[lane * PER + i];
+                        sm += h[i];
+                    }
+                    uint32_t incl = sm;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t t = static_cast<uint32_t>(__shfl_down(static_cast<int>(incl), d, 64));
+                        if (lane + d < 64) incl += t;
+                    }
+                    uint32_t acc = incl - sm;
+#pragma unroll
+                    for (int i = PER - 1; i >= 0; i--) {
+                        sh.rk.hist[lane * PER + i] = acc;
+                        acc += h[i];
+                    }
+                }
+                __syncthreads();
+                for (uint32_t t = static_cast<uint32_t>(tid); t < nmine; t += kScanBlock) {
+                    const u32x4 node = *(nodes - 1 - static_cast<int>(t));
+                    const u64 mine = (static_cast<u64>(node.y) << 32) | node.x;
+                    const uint32_t rank = sh.rk.hist[bucket(mine)] + node.w;
+                    if (rank < a.k) write_hit(mine, rank, sh.sel.u.mine.cb[t]);
+                }
+            }
             const uint32_t npair = (nfin + 1u) >> 1;
             const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.sel.fkey);
             // RG lanes share one row: each counts the larger keys among every RG-th pair
             // (ds_read_b128, two keys per read, several reads in flight), then a shuffle sum
             constexpr int RG = 16;
             const uint32_t sub = static_cast<uint32_t>(tid % RG);
-            for (uint32_t t0 = 0; t0 < nmine; t0 += kScanBlock / RG) {
+            for (uint32_t t0 = 0; t0 < nmine && !by_bucket; t0 += kScanBlock / RG) {
                 const uint32_t t = t0 + static_cast<uint32_t>(tid / RG);
                 const bool have = t < nmine;
                 const u64 mine = have ? sh.sel.fkey[sh.sel.u.mine.idx[t]] : ~0ull;
@@ -1330,15 +1576,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 }
 #pragma unroll
                 for (int d = RG / 2; d > 0; d >>= 1) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), d, 64));
-                if (have && sub == 0 && rank < a.k) {
-                    const uint32_t cb = sh.sel.u.mine.cb[t];
-                    gsim_hit h;
-                    h.row = ~static_cast<uint32_t>(mine) + fa.row_base;
-                    h.score = key_score(static_cast<uint32_t>(mine >> 32));
-                    h.common = static_cast<uint16_t>(cb >> 16);
-                    h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
-                    hits[rank] = h;
-                }
+                if (have && sub == 0 && rank < a.k) write_hit(mine, rank, sh.sel.u.mine.cb[t]);
             }
         }
     }
