@@ -1004,22 +1004,6 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     f.refresh(0u, lane); // (the service wave kept the workgroup's LDS copy of the threshold fresh: no global load here)
     if (!f.store_off) f.compact_store(lane);
-    { // (for the bucket order below: the range of the workgroup's score keys, the buckets' counters)
-        uint32_t lo = ~0u, hi = 0u;
-        const uint32_t nst = f.store_off ? 0u : f.staged;
-        for (uint32_t i = lane; i < nst; i += 64) {
-            const uint32_t h = static_cast<uint32_t>(f.skey[i] >> 32);
-            lo = h < lo ? h : lo;
-            hi = h > hi ? h : hi;
-        }
-        hi = wave_max_u32(hi);
-        lo = ~wave_max_u32(~lo);
-        if (lane == 0 && nst) {
-            atomicMax(&sh.hmax, hi);
-            atomicMin(&sh.hmin, lo);
-        }
-        for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) sh.hist[i] = 0;
-    }
     if (lane == 0) {
         sh.wcount[wv] = f.store_off ? 0u : f.staged;
         if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
@@ -1068,6 +1052,22 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
         }
     } else {
+        { // the range of the workgroup's score keys; the buckets' counters
+            uint32_t lo = ~0u, hi = 0u;
+            for (uint32_t i = lane; i < mine_n; i += 64) {
+                const uint32_t h = static_cast<uint32_t>(f.skey[i] >> 32);
+                lo = h < lo ? h : lo;
+                hi = h > hi ? h : hi;
+            }
+            hi = wave_max_u32(hi);
+            lo = ~wave_max_u32(~lo);
+            if (lane == 0 && mine_n) {
+                atomicMax(&sh.hmax, hi);
+                atomicMin(&sh.hmin, lo);
+            }
+            for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) sh.hist[i] = 0;
+        }
+        __syncthreads();
         const uint32_t hmin = sh.hmin, hmax = sh.hmax, span = hmax - hmin;
         const uint32_t bits = span ? 32u - static_cast<uint32_t>(__clz(static_cast<int>(span))) : 0u;
         shift = bits > 10u ? bits - 10u : 0u;
@@ -1416,11 +1416,6 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             }
         }
     }
-    { // (three 16-bit slices: each sums to less than 2^22 over the wave)
-        const u64 tot = static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc) & 0xFFFFu)) + (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 16) & 0xFFFFu)) << 16) +
-                        (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 32) & 0xFFFFu)) << 32);
-        if (lane == 0) atomicAdd(&sh.repmin, tot); // (zero since the selectors' start)
-    }
     __syncthreads();
     const uint32_t nfin = sh.nfin;
     uint32_t why = good ? 0u : kRedoSeen;
@@ -1428,10 +1423,6 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     good = good && nfin <= static_cast<uint32_t>(kFusedFinalLds);
     if (good) {
         if (tid == 0 && (nfin & 1u)) sh.sel.fkey[nfin] = 0ull; // pad to a pair for the b128 reads (nfin < kFusedFinalLds or even)
-        for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) { // (for the ranking by bucket; the items are done with)
-            sh.rk.hist[i] = 0;
-            sh.rk.head[i] = 0;
-        }
         __syncthreads();
         GSIM_STAMP(5);
         const uint32_t nmine = sh.nmine;
@@ -1460,6 +1451,16 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 // from it, and one for everything above -- the scores thin out quickly above the threshold, and the
                 // largest key, the query's own row, is far away: steps up to IT left 95 % of the finalists in 60 buckets)
                 const u64 base = tauf; // (every finalist is at or above the threshold)
+                { // the summed distance, wave by wave (three 16-bit slices: each sums to less than 2^22 over the wave)
+                    const u64 tot = static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc) & 0xFFFFu)) + (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 16) & 0xFFFFu)) << 16) +
+                                    (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 32) & 0xFFFFu)) << 32);
+                    if (lane == 0) atomicAdd(&sh.repmin, tot); // (zero since the selectors' start)
+                }
+                for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) { // (the items are done with)
+                    sh.rk.hist[i] = 0;
+                    sh.rk.head[i] = 0;
+                }
+                __syncthreads();
                 // 4 x the mean distance of the score keys from the threshold's, in 1023 steps of 2^(shift - 32)
                 const u64 reach = (sh.repmin << 2) / nfin + 1ull;
                 const uint32_t rbits = 64u - static_cast<uint32_t>(__clzll(static_cast<long long>(reach)));
