@@ -31,7 +31,7 @@ HEADER_DTYPE = np.dtype([("count", "<u4"), ("flags", "<u4"), ("approx", "<u8")])
 class GsimTiming(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("scan_ms_sum", C.c_double), ("select_ms_sum", C.c_double),
                 ("candidates_sum", C.c_uint64), ("finalists_sum", C.c_uint64), ("handed_back", C.c_uint64),
-                ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64)]
+                ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64), ("batches_dense_cutoff", C.c_uint64)]
 
 
 class GsimError(RuntimeError):

@@ -132,9 +132,15 @@ template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, v4i rb, v1
 // except 2048-bit rows with MT = 2: two query tiles per wave need 256 registers for the expanded queries
 // alone, which only fits with ONE wave per SIMD (512 registers per lane) -- four waves x 64 queries; the
 // operand work per MFMA halves and a wave overlaps its own VALU with its own four MFMA chains.
-template <int WORDS, int MT, int NT = (MT == 1 ? 2 : 1), int WV = kMWaves>
+// DN = the dense-cutoff variant (MT = 1): the rows at or above a cutoff that keeps a sizeable part of the table are COUNTED
+// from the accumulators (gsim_prefilter.h cutoff_band: two fused multiply-adds and two compares per pair, sixteen counters
+// per lane) instead of going through the exact path one by one; only pairs inside the band, and the top-k candidates at the
+// queries' current thresholds, are staged.  Its constants share the LDS arrays of the plain variant's two query tiles:
+// kap_u/kap_v[.][0] = tile test at the top-k threshold, kap_u/kap_v[.][1] = "surely kept", kap_a[.][0]/[1] = u, v of "surely not".
+template <int WORDS, int MT, int NT = (MT == 1 ? 2 : 1), int WV = kMWaves, bool DN = false>
 __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
 {
+    static_assert(!DN || MT == 1, "the dense-cutoff variant holds one query tile per wave");
     constexpr int QW = 32 * MT;         // queries per wave
     constexpr int KG = WORDS / 8;       // 256-bit groups per row
     constexpr int CPR = WORDS / 4;      // 16-byte chunks per row
@@ -173,8 +179,10 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
     // the flags) would send that fraction of all pairs through the exact path: leave such batches
     // to the VALU pass (the host re-runs them when it sees the flag).
     if (WV < kMWaves && lane == 0) rr.seg_count[w + WV] = 0; // the candidate segments of the waves that do not exist
-    if (has_cutoff && (*((g_u32p) rr.flags) & 8u)) {
-        if (lane == 0) rr.seg_count[w] = 0;
+    // (the plain variant leaves such a batch alone, the dense variant -- launched right behind it -- every other one)
+    const bool dense_batch = has_cutoff && (*((g_u32p) rr.flags) & 8u) != 0;
+    if (DN ? !dense_batch : dense_batch) {
+        if (lane == 0 && !DN) rr.seg_count[w] = 0;
         return;
     }
 
@@ -203,6 +211,23 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
         const PrefilterConstants pk = prefilter_constants(a.metric == GSIM_METRIC_TVERSKY, a.alpha, a.beta, sh.qpop[wq][lane],
                                                           level, valid);
         const int hh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3); // accumulator slot of query i of a tile
+        if (DN) {
+            // the candidates' level: the query's top-k threshold, whatever the cutoff (the cutoff itself is applied to
+            // every staged pair by the exact path); the band of the cutoff for the count
+            const PrefilterConstants pt = prefilter_constants(a.metric == GSIM_METRIC_TVERSKY, a.alpha, a.beta, sh.qpop[wq][lane],
+                                                              prefilter_level(false, 0.0f, tau), valid);
+            const CutoffBand cb = cutoff_band(a.metric == GSIM_METRIC_TVERSKY, a.alpha, a.beta, sh.qpop[wq][lane], a.cutoff, valid);
+            sh.kap_u[wq][0][hh][r] = pt.u;
+            sh.kap_v[wq][0][hh][r] = pt.v;
+            sh.kap_b[wq][0][hh][r] = pt.kb; // (pair test of the candidates: c >= fma(kb, b, ka))
+            sh.kap_b[wq][1][hh][r] = pt.ka;
+            sh.kap_u[wq][1][hh][r] = cb.us;
+            sh.kap_v[wq][1][hh][r] = cb.vs;
+            sh.kap_a[wq][0][hh][r] = cb.un;
+            sh.kap_a[wq][1][hh][r] = cb.vn;
+            sh.tau[wq][lane] = tau;
+            return;
+        }
         sh.kap_a[wq][m][hh][r] = pk.ka;
         sh.kap_b[wq][m][hh][r] = pk.kb;
         sh.kap_u[wq][m][hh][r] = pk.u;
@@ -234,13 +259,14 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
             const bool have = e < staged;
             const uint32_t row = have ? stg_row[e] : 0u;
             const uint32_t cb = have ? stg_cb[e] : 0u;
-            const uint32_t qi = have ? stg_q[e] : 0u;
+            const uint32_t qraw = have ? stg_q[e] : 0u; // query of the tile | candidate << 30 | to be counted << 31 (dense variant)
+            const uint32_t qi = qraw & 0x3FFFFFFFu;
             float sc = score_of(a.metric, a.alpha, a.beta, sh.qpop[wq][qi], cb & 0xFFFFu, cb >> 16);
             sc = apply_cutoff(sc, a.cutoff);
             const uint32_t bin = batch_bin(sc);
             const bool keep = have && (!has_cutoff || sc != 0.0f); // fingerprintdb_cuda.cu:265-271
-            if (has_cutoff && keep) atomicAdd(&sh.kept[wq][qi], 1u); // LDS; one global add per wave and query at the end
-            const bool cand = keep && bin >= sh.tau[wq][qi];
+            if (has_cutoff && keep && (!DN || (qraw >> 31) != 0)) atomicAdd(&sh.kept[wq][qi], 1u); // LDS; one global add per wave and query at the end
+            const bool cand = keep && bin >= sh.tau[wq][qi] && (!DN || ((qraw >> 30) & 1u) != 0);
             const u64 mc = __ballot(cand);
             if (cand) {
                 const uint32_t pos = cursor + lane_rank(mc);
@@ -289,6 +315,9 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
         }
     };
 
+    uint32_t kcnt[DN ? 16 : 1]; // dense variant: rows surely at or above the cutoff, per accumulator slot (= query) of this lane
+#pragma unroll
+    for (int r = 0; r < (DN ? 16 : 1); r++) kcnt[r] = 0;
     u64 blk = blockIdx.x;
     int buf = 0;
     if (blk < nblocks) issue_block(blk, 0);
@@ -384,45 +413,154 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
                     // Fast test, vector ALU only (a compare per pair into a scalar mask would stall on
                     // the VALU->SALU dependency 32 times), two instructions per pair: the bound solved
                     // for popc(row), maximum over the 16 queries of the lane, one compare per tile.
-                    const f32x4* kup = reinterpret_cast<const f32x4*>(sh.kap_u[wq][m][h]);
-                    const f32x4* kvp = reinterpret_cast<const f32x4*>(sh.kap_v[wq][m][h]);
-                    float mx[NT];
+                    u64 bits = 0, rmask = 0, bits_cand = 0, bits_count = 0;
+                    if (DN) {
+                        // dense cutoff: every pair is classified against the cutoff's band -- counted, dismissed, or (rarely)
+                        // left to the exact path -- and, as in the plain variant, against the query's top-k threshold
+                        const f32x4* kut = reinterpret_cast<const f32x4*>(sh.kap_u[wq][0][h]);
+                        const f32x4* kvt = reinterpret_cast<const f32x4*>(sh.kap_v[wq][0][h]);
+                        const f32x4* kus = reinterpret_cast<const f32x4*>(sh.kap_u[wq][1][h]);
+                        const f32x4* kvs = reinterpret_cast<const f32x4*>(sh.kap_v[wq][1][h]);
+                        const f32x4* kun = reinterpret_cast<const f32x4*>(sh.kap_a[wq][0][h]);
+                        const f32x4* kvn = reinterpret_cast<const f32x4*>(sh.kap_a[wq][1][h]);
+                        float mxt[NT], ph[NT], pl[NT];
+                        uint32_t tsure[NT], tmaybe[NT];
 #pragma unroll
-                    for (int tt = 0; tt < NT; tt++) mx[tt] = -3.0e38f;
+                        for (int tt = 0; tt < NT; tt++) {
+                            mxt[tt] = -3.0e38f;
+                            ph[tt] = active[tt] ? pbf[tt] + 0.01f : __builtin_inff(); // (rows past the table's end: nothing passes)
+                            pl[tt] = active[tt] ? pbf[tt] - 0.01f : __builtin_inff();
+                            tsure[tt] = 0;
+                            tmaybe[tt] = 0;
+                        }
+                        // (three passes over the accumulators, kept apart: unrolled together the constants of all of them are
+                        // loaded ahead and the expanded queries spill)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; r4++) {
-                        const f32x4 vu = kup[r4], vv = kvp[r4];
-                        // two pairs per instruction: v_pk_fma_f32 on the accumulator's register pairs, v_max3_f32
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const f32x4 vut = kut[r4], vvt = kvt[r4];
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const f32x2 u2{vu[e], vu[e + 1]}, v2{vv[e], vv[e + 1]};
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 ut2{vut[e], vut[e + 1]}, vt2{vvt[e], vvt[e + 1]};
 #pragma unroll
-                            for (int tt = 0; tt < NT; tt++) {
-                                const f32x2 c2{acc[m][tt][4 * r4 + e], acc[m][tt][4 * r4 + e + 1]};
-                                const f32x2 t2v = __builtin_elementwise_fma(c2, u2, v2);
-                                mx[tt] = fmaxf(fmaxf(mx[tt], t2v.x), t2v.y);
+                                for (int tt = 0; tt < NT; tt++) {
+                                    const f32x2 c2{acc[m][tt][4 * r4 + e], acc[m][tt][4 * r4 + e + 1]};
+                                    const f32x2 t2v = __builtin_elementwise_fma(c2, ut2, vt2);
+                                    mxt[tt] = fmaxf(fmaxf(mxt[tt], t2v.x), t2v.y);
+                                }
                             }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const f32x4 vus = kus[r4], vvs = kvs[r4];
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 us2{vus[e], vus[e + 1]}, vs2{vvs[e], vvs[e + 1]};
+#pragma unroll
+                                for (int tt = 0; tt < NT; tt++) {
+                                    const f32x2 c2{acc[m][tt][4 * r4 + e], acc[m][tt][4 * r4 + e + 1]};
+                                    const f32x2 s2v = __builtin_elementwise_fma(c2, us2, vs2);
+                                    const uint32_t s0 = s2v.x >= ph[tt] ? 1u : 0u, s1 = s2v.y >= ph[tt] ? 1u : 0u;
+                                    kcnt[4 * r4 + e] += s0;
+                                    kcnt[4 * r4 + e + 1] += s1;
+                                    tsure[tt] += s0 + s1;
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) {
+                            const f32x4 vun = kun[r4], vvn = kvn[r4];
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 un2{vun[e], vun[e + 1]}, vn2{vvn[e], vvn[e + 1]};
+#pragma unroll
+                                for (int tt = 0; tt < NT; tt++) {
+                                    const f32x2 c2{acc[m][tt][4 * r4 + e], acc[m][tt][4 * r4 + e + 1]};
+                                    const f32x2 n2v = __builtin_elementwise_fma(c2, un2, vn2);
+                                    tmaybe[tt] += (n2v.x >= pl[tt] ? 1u : 0u) + (n2v.y >= pl[tt] ? 1u : 0u);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        bool anyd = false;
+#pragma unroll
+                        for (int tt = 0; tt < NT; tt++) anyd = anyd || (active[tt] && mxt[tt] >= pbf[tt] - 0.01f) || tmaybe[tt] != tsure[tt];
+                        if (__builtin_expect(__ballot(anyd) != 0, 0)) {
+                            const f32x4* kbt = reinterpret_cast<const f32x4*>(sh.kap_b[wq][0][h]);
+                            const f32x4* kat = reinterpret_cast<const f32x4*>(sh.kap_b[wq][1][h]);
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; r4++) {
+                                const f32x4 vb = kbt[r4], va = kat[r4];
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int r = 4 * r4 + e;
+#pragma unroll
+                                    for (int tt = 0; tt < NT; tt++)
+                                        bits_cand |= (active[tt] && acc[m][tt][r] >= __builtin_fmaf(vb[e], pbf[tt], va[e])) ? (1ull << (16 * tt + r)) : 0ull;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; r4++) {
+                                const f32x4 vus = kus[r4], vvs = kvs[r4], vun = kun[r4], vvn = kvn[r4];
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int r = 4 * r4 + e;
+#pragma unroll
+                                    for (int tt = 0; tt < NT; tt++) {
+                                        const float c = acc[m][tt][r];
+                                        const bool inband = __builtin_fmaf(c, vun[e], vvn[e]) >= pl[tt] && !(__builtin_fmaf(c, vus[e], vvs[e]) >= ph[tt]);
+                                        bits_count |= inband ? (1ull << (16 * tt + r)) : 0ull;
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            bits = bits_cand | bits_count;
                         }
                     }
                     bool any = false;
+                    if (!DN) {
+                        const f32x4* kup = reinterpret_cast<const f32x4*>(sh.kap_u[wq][m][h]);
+                        const f32x4* kvp = reinterpret_cast<const f32x4*>(sh.kap_v[wq][m][h]);
+                        float mx[NT];
 #pragma unroll
-                    for (int tt = 0; tt < NT; tt++) any = any || (active[tt] && mx[tt] >= pbf[tt] - 0.01f);
-                    // which accumulator registers hold a passing pair (bit 16 tt + r: row tile tt)
-                    u64 bits = 0, rmask = 0;
-                    if (__ballot(any) != 0) {
-                        const f32x4* kap = reinterpret_cast<const f32x4*>(sh.kap_a[wq][m][h]);
-                        const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][m][h]);
+                        for (int tt = 0; tt < NT; tt++) mx[tt] = -3.0e38f;
 #pragma unroll
                         for (int r4 = 0; r4 < 4; r4++) {
-                            const f32x4 va = kap[r4], vb = kbp[r4];
+                            const f32x4 vu = kup[r4], vv = kvp[r4];
+                            // two pairs per instruction: v_pk_fma_f32 on the accumulator's register pairs, v_max3_f32
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const int r = 4 * r4 + e;
+                            for (int e = 0; e < 4; e += 2) {
+                                const f32x2 u2{vu[e], vu[e + 1]}, v2{vv[e], vv[e + 1]};
 #pragma unroll
-                                for (int tt = 0; tt < NT; tt++)
-                                    bits |= (active[tt] && acc[m][tt][r] >= __builtin_fmaf(vb[e], pbf[tt], va[e]))
-                                                ? (1ull << (16 * tt + r))
-                                                : 0ull;
+                                for (int tt = 0; tt < NT; tt++) {
+                                    const f32x2 c2{acc[m][tt][4 * r4 + e], acc[m][tt][4 * r4 + e + 1]};
+                                    const f32x2 t2v = __builtin_elementwise_fma(c2, u2, v2);
+                                    mx[tt] = fmaxf(fmaxf(mx[tt], t2v.x), t2v.y);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NT; tt++) any = any || (active[tt] && mx[tt] >= pbf[tt] - 0.01f);
+                    }
+                    // which accumulator registers hold a passing pair (bit 16 tt + r: row tile tt)
+                    if (DN ? __ballot(bits != 0) != 0 : __ballot(any) != 0) {
+                        if (!DN) {
+                            const f32x4* kap = reinterpret_cast<const f32x4*>(sh.kap_a[wq][m][h]);
+                            const f32x4* kbp = reinterpret_cast<const f32x4*>(sh.kap_b[wq][m][h]);
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; r4++) {
+                                const f32x4 va = kap[r4], vb = kbp[r4];
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int r = 4 * r4 + e;
+#pragma unroll
+                                    for (int tt = 0; tt < NT; tt++)
+                                        bits |= (active[tt] && acc[m][tt][r] >= __builtin_fmaf(vb[e], pbf[tt], va[e]))
+                                                    ? (1ull << (16 * tt + r))
+                                                    : 0ull;
+                                }
                             }
                         }
                         // OR over the wavefront, 32 bits at a time
@@ -463,7 +601,8 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
                             const uint32_t slot = staged + lane_rank(mp);
                             stg_row[slot] = static_cast<uint32_t>(rws);
                             stg_cb[slot] = (static_cast<uint32_t>(cf) << 16) + pbs;
-                            stg_q[slot] = static_cast<uint32_t>(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h); // query of the wave
+                            stg_q[slot] = static_cast<uint32_t>(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) | // query of the wave
+                                          (DN ? (static_cast<uint32_t>((bits_cand >> bit) & 1ull) << 30) | (static_cast<uint32_t>((bits_count >> bit) & 1ull) << 31) : 0u);
                         }
                         staged += static_cast<uint32_t>(__popcll(mp));
                         if (staged > kMStage - 64) {
@@ -521,6 +660,13 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
         for (int d = 0; d < 9; d++) atomicAdd(&rr.flags[2 + d], static_cast<uint32_t>(tacc[d] >> 6));
 #endif
     if (staged) drain_stage();
+    if (DN) { // this lane's counts -> the wave's per-query counts (slot r of lane half h is query (r & 3) + 8 (r >> 2) + 4 h of the tile)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (kcnt[r]) atomicAdd(&sh.kept[wq][(r & 3) + 8 * (r >> 2) + 4 * h], kcnt[r]);
+        __builtin_amdgcn_wave_barrier();
+        if (wq == 0 && lane == 0) atomicOr(rr.flags, 16u); // the dense route ran: the host does not re-run the batch on the VALU pass
+    }
     if (has_cutoff && lane < QW && q0t + lane < nq && sh.kept[wq][lane])
         atomicAdd(&qstate[q0t + lane].kept, static_cast<u64>(sh.kept[wq][lane]));
     if (lane == 0) {
@@ -823,6 +969,14 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
     return true;
 }
 
+// Is there a band for the dense-cutoff variant (the same for every query of a batch up to 2048-bit rows)?
+bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff)
+{
+    static const int enabled = std::getenv("GSIM_BATCH_MFMA_DENSE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_DENSE")) : 1;
+    if (std::getenv("GSIM_BATCH_MFMA_DENSE_OFF_FOR_TEST")) return false; // (read at every call: a test compares the two routes in one process)
+    return enabled && cutoff_band(metric == GSIM_METRIC_TVERSKY, alpha, beta, 2048u, cutoff, true).on;
+}
+
 // The scan of one pass (a.nq <= kMfmaQueries queries from a.q0); with a cutoff only after
 // launch_batch_mfma_sample (it flags cutoffs that keep too many rows); thresholds come
 // from the sample passes launched before it, finish with launch_batch_finish.
@@ -868,6 +1022,21 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
         }
     } else {
         return hipErrorInvalidValue;
+    }
+    // A cutoff the sample pass found to keep a sizeable part of the table (flag 8, read on the device): the plain kernel
+    // above has returned at once, the dense variant -- one query tile per wave, the kept rows counted in registers --
+    // runs the batch; any other batch it leaves alone.  Weights without a usable band (cutoff_band): the VALU pass,
+    // re-enqueued by the host when it finds flag 8 without flag 16.
+    if (a.cutoff > 0.0f && batch_mfma_dense_applies(a.metric, a.alpha, a.beta, a.cutoff)) {
+        const u64 nblocks = (a.nrows + (kMChunks / (a.W / 4)) - 1) / (kMChunks / (a.W / 4));
+        if (a.W == 64)
+            hipLaunchKernelGGL((batch_mfma_kernel<64, 1, 1, kMWaves, true>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        else if (a.W == 32)
+            hipLaunchKernelGGL((batch_mfma_kernel<32, 1, 2, kMWaves, true>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        else if (a.W == 16)
+            hipLaunchKernelGGL((batch_mfma_kernel<16, 1, 2, kMWaves, true>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+        else
+            hipLaunchKernelGGL((batch_mfma_kernel<8, 1, 2, kMWaves, true>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
     }
     return hipGetLastError();
 }

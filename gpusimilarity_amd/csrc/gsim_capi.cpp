@@ -202,6 +202,7 @@ struct gsim_db {
     uint32_t row_base = 0;
     bool timing = false;
     gsim_timing acc{};
+    unsigned long long dense_batches = 0; // multi-query passes whose dense cutoff the matrix-core pass counted itself
     // One search at a time per handle (the reference serialises searches behind a function-static
     // mutex, fingerprintdb_cuda.cu:236): concurrent callers queue here.
     std::mutex search_mutex;
@@ -1611,7 +1612,8 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
                 GSIM_HIP(set_device(s.device));
                 rc = wait_stream(s.stream);
                 if (rc != GSIM_OK) return rc;
-                if (s.h_bflags[0] & 8u) dense_cutoff = true;
+                if ((s.h_bflags[0] & 24u) == 8u) dense_cutoff = true; // (8: a dense cutoff; 16: the matrix-core pass counted it itself)
+                if (s.h_bflags[0] & 16u) db->dense_batches++;
             }
             if (dense_cutoff) { // the cutoff keeps too many rows for the matrix-core pass: VALU pass
                 for (auto& s : db->shards) {
@@ -1727,7 +1729,8 @@ int gsim_db_search_batch_device(gsim_db* db, const uint32_t* queries, uint32_t n
             GSIM_HIP(set_device(s.device));
             rc = wait_stream(s.stream);
             if (rc != GSIM_OK) return rc;
-            if (s.h_bflags[0] & 8u) { // the cutoff keeps too many rows for the matrix-core pass: VALU pass
+            if (s.h_bflags[0] & 16u) db->dense_batches++;
+            if ((s.h_bflags[0] & 24u) == 8u) { // the cutoff keeps too many rows for the exact path and has no band: VALU pass
                 rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, db->row_base, out + base * blk, false);
                 if (rc != GSIM_OK) return rc;
                 rc = wait_stream(s.stream);
@@ -1917,6 +1920,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
         db->acc.handed_back += r - s.base_nredo;
         db->acc.handed_back_why |= s.h_state->redo_why & 31u; // (bit 5 = "a selector saw it fail": not a reason of its own)
     }
+    db->acc.batches_dense_cutoff = db->dense_batches;
     *out = db->acc;
     return GSIM_OK;
 }

@@ -217,6 +217,7 @@ hipError_t launch_row_popcounts(const void* rows, uint64_t nrows, uint32_t W, ui
 inline size_t row_popcount_bytes(uint64_t nrows) { return static_cast<size_t>((nrows + 7) / 8 + 1) * 16; }
 uint32_t batch_mfma_waves(int num_cus);
 hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s);
+bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff);
 bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err);
 bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus);
 hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,

@@ -96,6 +96,53 @@ GSIM_HD bool prefilter_pair_passes(const PrefilterConstants& k, float c, float b
     return c >= fmaf(k.kb, b, k.ka);
 }
 
+// ---- dense cutoffs on the matrix cores ---------------------------------------------------------
+// `approx` counts the rows with score >= cutoff: when the cutoff keeps a sizeable part of the table those rows
+// cannot all go through the exact path.  The count is linear in the counts as well, so the kernel decides almost
+// every pair with two fused multiply-adds and counts in registers:
+//     surely kept       fmaf(c, us, vs) >= b + 0.01      =>  RN(c / den) >= cutoff (and c != 0)
+//     surely not kept   fmaf(c, un, vn) <  b - 0.01      =>  not kept
+// with (us, vs) / (un, vn) the bound solved for b at f (1 + 2^-18) / f (1 - 2^-18).  Budget, in units of b: the
+// rounding of f, of its products and of the fma stays below 0.007 for a + b <= 4096 while D > 0.05 (the division
+// by D amplifies one rounding of D at most twenty times), the rounding of the reference's own denominator and
+// quotient is worth 0.0013; the margins give 0.0156 + 0.01 on either side.  Only the pairs in between -- the
+// bound passes within ~0.005 counts of an integer -- go to the exact path.  prefilter_check.cpp checks both
+// implications over every (a, b, c), a grid of cutoffs and every pair's own score (and its neighbours) as cutoff.
+struct CutoffBand {
+    float us, vs, un, vn;
+    bool on; // false: no usable band for these weights / this cutoff (the VALU pass takes dense cutoffs then)
+};
+
+GSIM_HD CutoffBand cutoff_band(bool tversky, float alpha, float beta, uint32_t qa, float cutoff, bool valid)
+{
+    CutoffBand k;
+    k.us = 0.0f;
+    k.vs = -3.0e38f; // surely kept: never
+    k.un = 0.0f;
+    k.vn = valid ? 3.0e38f : -3.0e38f; // surely not kept: never (padding query: always)
+    k.on = false;
+    const float al = tversky ? alpha : 1.0f;
+    const float be = tversky ? beta : 1.0f;
+    const float T = cutoff;
+    const float D = 1.0f - T * (1.0f - al - be);
+    if (!(T > 0.0f) || !(T <= 1.0f) || !(al >= 0.0f) || !(be > 1.0e-3f) || !(al <= 16.0f) || !(be <= 16.0f) || !(D > 0.05f)) return k;
+    const float f = T / D;
+    const float fs = f * (1.0f + 3.814697265625e-6f), fn = f * (1.0f - 3.814697265625e-6f); // (1 +- 2^-18)
+    const float kas = fs * al * static_cast<float>(qa), kbs = fs * be;
+    const float kan = fn * al * static_cast<float>(qa), kbn = fn * be;
+    if (!(kbs > 1.0e-4f) || !(kbn > 1.0e-4f) || !(kas < 1.0e4f)) return k;
+    k.on = true;
+    if (!valid) return k;
+    k.us = 1.0f / kbs;
+    k.vs = -kas * k.us;
+    k.un = 1.0f / kbn;
+    k.vn = -kan * k.un;
+    return k;
+}
+
+GSIM_HD bool band_surely_kept(const CutoffBand& k, float c, float b) { return fmaf(c, k.us, k.vs) >= b + 0.01f; }
+GSIM_HD bool band_surely_not_kept(const CutoffBand& k, float c, float b) { return fmaf(c, k.un, k.vn) < b - 0.01f; }
+
 // ---- VALU multi-query pass (gsim_batch.hip) ---------------------------------------------------
 // There the denominator of the score is at hand (den = score_den(...), the f32 value the exact
 // divide uses), so the tests are on c against a multiple of den:

@@ -85,6 +85,8 @@ typedef struct {
                                    workgroup's list overflowed (heavy ties, ascending scores), 2 / 4 a wait ran out
                                    (GPU shared with another process), 8 more rows at the final threshold than a
                                    selector holds, 16 more of them owned by one selector than its list holds           */
+    uint64_t batches_dense_cutoff; /* multi-query passes, since the handle was created, whose cutoff kept so many rows that the
+                                      matrix-core pass counted them from its accumulators (gsim_prefilter.h cutoff_band)      */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */

@@ -157,6 +157,27 @@ int main(int argc, char** argv)
                             check_cut(nextafterf(s, 0.0f));
                         }
                     }
+                    // (e) the band of the dense-cutoff route: "surely kept" / "surely not kept" must agree with the exact test
+                    {
+                        auto check_band = [&](float cutoff) {
+                            const gsim::CutoffBand kb = gsim::cutoff_band(tv, alpha, beta, a, cutoff, true);
+                            if (!kb.on) return;
+                            const bool kept = s >= cutoff && s != 0.0f;
+                            n++;
+                            gsim::CutoffBand kk = kb;
+                            if (g_sabotage != 1.0f) { // negative control: a band that is too narrow by that factor
+                                kk.us *= g_sabotage, kk.vs *= g_sabotage;
+                            }
+                            if (gsim::band_surely_kept(kk, cf, bf) && !kept) report("band-surely", a, b, c, s, cutoff, ktau[0]);
+                            if (gsim::band_surely_not_kept(kb, cf, bf) && kept) report("band-surely-not", a, b, c, s, cutoff, ktau[0]);
+                        };
+                        for (float cutoff : cutoffs) check_band(cutoff);
+                        if (s > 0.0f) {
+                            check_band(s);
+                            check_band(nextafterf(s, 2.0f));
+                            check_band(nextafterf(s, 0.0f));
+                        }
+                    }
                     // (c) cutoff == this pair's own score
                     if (s > 0.0f) {
                         const gsim::PrefilterConstants k = gsim::prefilter_constants(tv, alpha, beta, a, gsim::prefilter_level(true, s, 0), true);

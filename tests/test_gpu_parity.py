@@ -850,24 +850,39 @@ def test_matrix_core_pass_large_k_and_tiny_tables(W, n, nq, k):
 @pytest.mark.parametrize("W,n", [(32, 20_000_000), (64, 17_000_000)])
 def test_matrix_core_pass_with_cutoff(W, n):
     """Batches with a cutoff on tables large enough for the matrix-core sample pass: a selective
-    cutoff stays on the matrix cores (rows at or above it are counted on the exact path), a cutoff
-    that keeps a large part of the table is flagged by the sample pass and re-run on the VALU pass.
-    Either way hits AND approximate counts equal the single-query pipeline's."""
+    cutoff stays on the matrix cores with the rows at or above it counted on the exact path; a cutoff
+    that keeps a large part of the table (flagged by the sample pass) runs on the dense-cutoff variant,
+    which counts the kept rows from the accumulators (gsim_prefilter.h cutoff_band) and sends only the
+    pairs inside the band and the top-k candidates through the exact path; with the variant switched off
+    the VALU pass takes those.  Every way hits AND approximate counts equal the single-query pipeline's."""
     t = capi.Table(W * 32)
     t.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
     own = [O.synth_rows(0x5EED0001, 0, O.query_row(i, n), 1, W)[0] for i in range(40)]
     fresh = [O.synth_rows(0x5EED0002, 0, 700 + i, 1, W)[0] for i in range(8)]
     qs = np.stack(own + fresh)
-    cases = [(0.2, {}), (0.12, dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))),
-             (0.02, {}), (1.5, {})]
+    tv = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    cases = [(0.2, {}), (0.12, tv), (0.02, {}), (0.04, tv), (0.07, {}), (1.5, {})]
+    dense, sparse = {0.02, 0.04, 0.07}, {0.2, 1.5} # (0.12 Tversky: dense on the 1024-bit table, not on the 2048-bit one)
     results = []
     for cutoff, kw in cases:
+        before = t.timing()["batches_dense_cutoff"]
         hits, approx = t.search(qs, 100, np.float32(cutoff), **kw)
+        took_dense = t.timing()["batches_dense_cutoff"] > before
+        assert (took_dense or cutoff not in dense) and not (took_dense and cutoff in sparse), "cutoff %g: route" % cutoff
         for i in range(len(qs)):
             one, ap1 = t.search(qs[i], 100, np.float32(cutoff), **kw)
             assert int(approx[i]) == int(ap1[0]), "W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], ap1[0])
             assert_hits_equal(hits[i], one[0], "W=%d cutoff=%g q=%d" % (W, cutoff, i))
         results.append((hits, approx))
+    # the same dense cutoff through the VALU pass (the route of weights without a band)
+    os.environ["GSIM_BATCH_MFMA_DENSE_OFF_FOR_TEST"] = "1"
+    try:
+        hits_v, approx_v = t.search(qs, 100, np.float32(0.02))
+    finally:
+        del os.environ["GSIM_BATCH_MFMA_DENSE_OFF_FOR_TEST"]
+    assert [int(x) for x in approx_v] == [int(x) for x in results[2][1]]
+    for i in range(len(qs)):
+        assert_hits_equal(hits_v[i], results[2][0][i], "VALU route q=%d" % i)
     t.close()
     # ... and a subset directly against the ORACLE on the whole table: hits and approximate counts
     db = _host_table(0x5EED0001, n, W)
