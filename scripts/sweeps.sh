@@ -15,6 +15,9 @@ echo "== four-kernel pipeline for comparison (GSIM_FUSED=0), 1024-bit =="
 GSIM_FUSED=0 TS_REPS=50 python scripts/time_single.py 1000000 10000000 100000000 2>&1 | grep rows
 echo "== k sweep, 100 M x 1024-bit =="
 for k in 1 10 100 1000 2048 4096 8192 20000; do TS_K=$k TS_REPS=30 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/k $k  /"; done
+echo "== k sweep, 1 M x 1024-bit (Morgan-shaped: second block) =="
+for k in 1 100 1000 2048 4096 8192; do TS_K=$k python scripts/time_single.py 1000000 2>&1 | grep rows | sed "s/^/k $k  /"; done
+for k in 1000 4096 8192; do TS_KIND=morgan TS_K=$k python scripts/time_single.py 1000000 2>&1 | grep rows | sed "s/^/morgan k $k  /"; done
 echo "== 256-query Tversky(0.3,0.7) batches on the matrix cores (scripts/time_batch.py) =="
 python scripts/time_batch.py 125000000
 TB_BITS=1024 python scripts/time_batch.py 125000000
@@ -22,3 +25,7 @@ TB_BITS=512 python scripts/time_batch.py 200000000
 TB_BITS=256 python scripts/time_batch.py 200000000
 TB_Q=64 python scripts/time_batch.py 125000000
 TB_Q=32 python scripts/time_batch.py 125000000
+echo "== the same batches with a cutoff: selective (exact path counts), dense (counted from the accumulators), and the VALU route for comparison =="
+python scripts/time_batch_cutoff.py 125000000 0.3 0.15 0.1 0.05
+TB_BITS=1024 python scripts/time_batch_cutoff.py 125000000 0.1
+GSIM_BATCH_MFMA_DENSE=0 python scripts/time_batch_cutoff.py 125000000 0.1
