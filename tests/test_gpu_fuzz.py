@@ -1,122 +1,54 @@
-"""Seeded differential fuzz of the HIP path against the oracle: random table sizes around the
-chunk / wave / sample boundaries, widths, k, cutoffs, metrics, tie-heavy tables (rows drawn
-from a small alphabet), single queries and multi-query calls."""
+"""Seeded random sweep of the hot path through the C ABI against the oracle: table sizes, widths, row kinds, k, cutoffs
+and metrics drawn at random (the parametrised suites sit on the geometry switches; this one walks between them).
+Single queries (the single-launch kernel and whatever it hands back) and small batches (the multi-query passes).
+Reference: FingerprintDB::search, fingerprintdb_cuda.cu:228-380."""
 import numpy as np
 import pytest
 
 import oracle_lib as O
 from gpusimilarity_amd import capi
+from test_gpu_parity import assert_hits_equal, make_table
 
 pytestmark = pytest.mark.gpu
 
 
-def hits_equal(a, b):
-    return (len(a) == len(b) and (a["row"] == b["row"]).all()
-            and (a["score"].view(np.uint32) == b["score"].view(np.uint32)).all()
-            and (a["common"] == b["common"]).all() and (a["popc_db"] == b["popc_db"]).all())
+def draw(rng):
+    W = int(rng.choice([4, 8, 16, 32, 32, 32, 64, 128]))
+    n = int(np.exp(rng.uniform(np.log(200), np.log(2_500_000 if W <= 32 else 500_000))))
+    kind = int(rng.choice([0, 0, 1, O.KIND_MORGAN])) if W == 32 else int(rng.choice([0, 1]))
+    return W, n, kind
 
 
-def random_table(rng, n, W, style):
-    if style == "sparse":
-        return O.synth_rows(int(rng.integers(1, 2**31)), 0, int(rng.integers(0, 10**6)), n, W)
-    if style == "dense":
-        return O.synth_rows(int(rng.integers(1, 2**31)), 1, 0, n, W)
-    # tie-heavy: rows drawn from a small alphabet of fingerprints (plus a few empty rows)
-    alpha = O.synth_rows(int(rng.integers(1, 2**31)), 0, 0, int(rng.integers(2, 40)), W)
-    alpha[0] = 0
-    return np.ascontiguousarray(alpha[rng.integers(0, len(alpha), size=n)])
-
-
-@pytest.mark.parametrize("seed", range(6))
-def test_fuzz_against_oracle(seed):
+@pytest.mark.parametrize("seed", range(32))
+def test_random_tables_and_queries_match_the_oracle(seed):
     rng = np.random.default_rng(0xF022 + seed)
-    sizes = [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537, 262144 + 7, 524288 - 1, 524288 + 65, 1_200_003]
-    for case in range(22):
-        W = int(rng.choice([1, 3, 4, 8, 16, 32, 32, 32, 64, 64, 128]))
-        n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(1, 300_000))
-        if W >= 64:
-            n = min(n, 120_000)
-        elif W != 32:
-            n = min(n, 600_000)
-        style = str(rng.choice(["sparse", "dense", "ties"]))
-        db = random_table(rng, n, W, style)
-        t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
-        for _ in range(3):
-            k = int(rng.choice([0, 1, 2, 7, 20, 100, 1000, 1001, 5000, n, n + 3]))
-            cutoff = float(rng.choice([0.0, 0.0, -0.5, 1e-6, 0.05, 0.2, 0.5, 1.0, 1.5]))
-            metric = int(rng.choice([0, 0, 1]))
-            al, be = (np.float32(rng.choice([0.0, 0.3, 0.5, 1.0])), np.float32(rng.choice([0.0, 0.7, 0.5, 1.0])))
-            nq = int(rng.choice([1, 1, 1, 2, 5, 9]))
-            qs = np.stack([db[rng.integers(0, n)] if rng.random() < 0.7 else
-                           O.synth_rows(int(rng.integers(1, 2**31)), int(rng.integers(0, 2)), 0, 1, W)[0] for _ in range(nq)])
-            kw = dict(metric=metric, alpha=al, beta=be) if metric else {}
-            hits, approx = t.search(qs, k, np.float32(cutoff), **kw)
-            for i in range(nq):
-                want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=4, **kw)
-                ctx = "seed=%d case=%d W=%d n=%d style=%s k=%d cutoff=%g metric=%d nq=%d q=%d" % (
-                    seed, case, W, n, style, k, cutoff, metric, nq, i)
-                assert int(approx[i]) == wap, ctx
-                assert hits_equal(hits[i], want), ctx
-        t.close()
-
-
-@pytest.mark.parametrize("seed", range(3))
-def test_fuzz_large_batches_against_oracle(seed):
-    """Batches of 64..200 queries (the matrix-core pass for 256..2048-bit rows and cutoff <= 0, the
-    VALU pass otherwise), random table shapes, metrics and k."""
-    rng = np.random.default_rng(0xBA7C4 + seed)
-    for case in range(8):
-        W = int(rng.choice([32, 64, 32, 64, 16]))
-        n = int(rng.choice([1, 33, 255, 256, 257, 511, 513, 4097, 50_000, 100_003]))
-        style = str(rng.choice(["sparse", "dense", "ties"]))
-        db = random_table(rng, n, W, style)
-        t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
-        k = int(rng.choice([1, 10, 100, 1000, n + 1]))
-        cutoff = float(rng.choice([0.0, 0.0, 0.0, -1.0, 0.1]))
-        metric = int(rng.choice([0, 1]))
-        al, be = (np.float32(rng.choice([0.0, 0.3, 1.0])), np.float32(rng.choice([0.7, 0.5, 1.0])))
-        nq = int(rng.integers(64, 201))
-        qs = np.stack([db[rng.integers(0, n)] if rng.random() < 0.7 else
-                       O.synth_rows(int(rng.integers(1, 2**31)), int(rng.integers(0, 2)), 0, 1, W)[0] for _ in range(nq)])
-        kw = dict(metric=metric, alpha=al, beta=be) if metric else {}
-        hits, approx = t.search(qs, k, np.float32(cutoff), **kw)
-        for i in range(nq):
-            want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=4, **kw)
-            ctx = "seed=%d case=%d W=%d n=%d style=%s k=%d cutoff=%g metric=%d (%g,%g) nq=%d q=%d" % (
-                seed, case, W, n, style, k, cutoff, metric, al, be, nq, i)
-            assert int(approx[i]) == wap, ctx
-            assert hits_equal(hits[i], want), ctx
-        t.close()
-
-
-@pytest.mark.parametrize("seed", range(3))
-def test_fuzz_generic_widths_against_oracle(seed):
-    """Widths that are not a power-of-two number of 16-byte lanes (scan_generic_kernel: rows transposed through LDS,
-    sample pass on large tables), single queries and small multi-query calls."""
-    rng = np.random.default_rng(0x6E2 + seed)
-    sizes = [1, 3, 63, 64, 65, 255, 257, 4095, 4097, 65537, 262144 + 7, 2_100_001]
+    W, n, kind = draw(rng)
+    db = O.synth_rows(0xF0220000 + seed, kind, 0, n, W)
+    t = make_table(db)
+    tv = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(rng.choice([0.3, 0.5, 1.0, 0.0])), beta=np.float32(rng.choice([0.7, 0.5, 1.0])))
     for case in range(14):
-        W = int(rng.choice([2, 5, 6, 7, 9, 12, 20, 24, 28, 48, 100, 130]))
-        n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(1, 200_000))
-        if W >= 48:
-            n = min(n, 150_000)
-        style = str(rng.choice(["sparse", "dense", "ties"]))
-        db = random_table(rng, n, W, style)
-        t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
-        for _ in range(3):
-            k = int(rng.choice([0, 1, 7, 100, 1000, 3000, n, n + 3]))
-            cutoff = float(rng.choice([0.0, 0.0, -0.5, 0.05, 0.3, 1.0]))
-            metric = int(rng.choice([0, 0, 1]))
-            al, be = (np.float32(rng.choice([0.0, 0.3, 1.0])), np.float32(rng.choice([0.0, 0.7, 1.0])))
-            nq = int(rng.choice([1, 1, 2, 6]))
-            qs = np.stack([db[rng.integers(0, n)] if rng.random() < 0.7 else
-                           O.synth_rows(int(rng.integers(1, 2**31)), int(rng.integers(0, 2)), 0, 1, W)[0] for _ in range(nq)])
-            kw = dict(metric=metric, alpha=al, beta=be) if metric else {}
-            hits, approx = t.search(qs, k, np.float32(cutoff), **kw)
-            for i in range(nq):
-                want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=4, **kw)
-                ctx = "generic seed=%d case=%d W=%d n=%d style=%s k=%d cutoff=%g metric=%d nq=%d q=%d" % (
-                    seed, case, W, n, style, k, cutoff, metric, nq, i)
-                assert int(approx[i]) == wap, ctx
-                assert hits_equal(hits[i], want), ctx
-        t.close()
+        own = rng.random() < 0.75
+        q = db[int(rng.integers(n))] if own else O.synth_rows(0xF0229999 + seed, 0 if kind != 1 else 1, 50 + case, 1, W)[0]
+        if case == 13 and seed % 4 == 0:
+            q = np.zeros(W, dtype=np.uint32)  # (0 / 0 -> NaN -> 0: every row ties)
+        k = int(rng.choice([1, 3, 20, 100, 1000, 1500, 2048, 3000, 5000, 8192, 9000, 20000]))
+        cutoff = float(rng.choice([0.0, 0.0, 0.0, 0.05, 0.2, 0.5, 0.9]))
+        kw = tv if rng.random() < 0.3 else {}
+        hits, approx = t.search(q, k, np.float32(cutoff), **kw)
+        want, wap = O.search(q, db, k, np.float32(cutoff), nthreads=8, **kw)
+        ctx = "seed %d case %d: n=%d W=%d kind=%d k=%d cutoff=%g %s" % (seed, case, n, W, kind, k, cutoff, "tversky" if kw else "tanimoto")
+        assert int(approx[0]) == wap, ctx
+        assert_hits_equal(hits[0], want, ctx)
+    # a batch of queries through the multi-query passes
+    nq = int(rng.choice([4, 9, 33, 70]))
+    qs = db[rng.integers(n, size=nq)]
+    k = int(rng.choice([1, 50, 1000]))
+    cutoff = float(rng.choice([0.0, 0.1]))
+    kw = tv if rng.random() < 0.5 else {}
+    hits, approx = t.search(qs, k, np.float32(cutoff), **kw)
+    for i in range(nq):
+        want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=8, **kw)
+        ctx = "seed %d batch q %d: n=%d W=%d kind=%d k=%d cutoff=%g" % (seed, i, n, W, kind, k, cutoff)
+        assert int(approx[i]) == wap, ctx
+        assert_hits_equal(hits[i], want, ctx)
+    t.close()
