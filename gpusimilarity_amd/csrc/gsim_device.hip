@@ -1431,13 +1431,15 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         if (good) {
             gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
             gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
+            // (system-scope write-through stores: nothing of the block stays behind in this XCD's L2, no write-back is owed
+            // before the ticket -- the wait for their acknowledgement is the release)
+            const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hits, 0, a.k * 12u, 0x00020000);
             auto write_hit = [&](u64 mine, uint32_t rank, uint32_t cb) {
-                gsim_hit h;
-                h.row = ~static_cast<uint32_t>(mine) + fa.row_base;
-                h.score = key_score(static_cast<uint32_t>(mine >> 32));
-                h.common = static_cast<uint16_t>(cb >> 16);
-                h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
-                hits[rank] = h;
+                const uint32_t w0 = ~static_cast<uint32_t>(mine) + fa.row_base;
+                const uint32_t w1 = __float_as_uint(key_score(static_cast<uint32_t>(mine >> 32)));
+                const uint32_t w2 = (cb >> 16) | (cb << 16); // {common, popc_db}
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{w0, w1}, hrs, rank * 12u, 0, /*sc0 sc1*/ 17);
+                __builtin_amdgcn_raw_buffer_store_b32(w2, hrs, rank * 12u + 8u, 0, /*sc0 sc1*/ 17);
             };
             // (the bucket route keeps a 16-byte node per row of this selector in the unused end of the finalist array)
             const bool by_bucket = nfin > kFusedRankDirect && nfin + 2u * nmine + 2u <= static_cast<uint32_t>(kFusedFinalLds);
@@ -1587,8 +1589,14 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its hits have left the CU
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // one write-back for the workgroup (system scope)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The hits were stored write-through at system scope (sc0 sc1) and every wave has waited for their
+        // acknowledgements: they are in memory, there is nothing for a release fence to write back.  (Plain stores need
+        // the fence -- 16 of 600 k queries came back incomplete without it, DESIGN.md 7 (g) -- and it cost 1.3 us per
+        // query.  GSIM_FUSED_FLAGS=1024 puts it back.)
+        if (fa.xflags & 1024u) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         // the ticket also carries "this selector saw the query fail" (bit 16 up): the closer learns it without another
         // round trip (a workgroup that set QueryState::redo while publishing did so before the grid-wide wait: every
         // selector read it after the wait and is not `good`)
@@ -1600,15 +1608,20 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t redo = ((sh.ticket >> 16) != 0 || !good) ? 1u : 0u;
     if (redo && tid == 0) atomicOr(&st->redo, kRedoSeen); // (the gated classic kernels behind an enqueue-only launch read it)
     if (tid == 0) {
-        gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(fa.result);
-        hdr->count = redo ? 0u : (nfin < a.k ? nfin : a.k);
-        hdr->flags = redo ? 2u : 0u;
-        hdr->approx = a.cutoff > 0.0f ? __hip_atomic_load(&st->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nrows;
+        { // the header, write-through as the hits
+            const u64 approx = a.cutoff > 0.0f ? __hip_atomic_load(&st->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nrows;
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(fa.result, 0, 16, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{redo ? 0u : (nfin < a.k ? nfin : a.k), redo ? 2u : 0u, static_cast<uint32_t>(approx), static_cast<uint32_t>(approx >> 32)},
+                                                   rrs, 0, 0, /*sc0 sc1*/ 17);
+        }
         if (fa.done_flag) {
-            // the block is complete (every selector fenced its hits before its ticket): tell the host NOW, tidy up after
+            // the block is complete (every selector waited for its hits before its ticket, the header is out once its
+            // acknowledgement is in): tell the host NOW, tidy up after
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fa.xflags & 1024u) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __hip_atomic_store(fa.done_flag, fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         // re-zero the per-query state for the next launch (stream-ordered behind this one)
