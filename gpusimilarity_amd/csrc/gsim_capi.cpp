@@ -455,9 +455,13 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.tickets = s.d_summ + 4096;
         f.result = out;
         f.row_base = row_base;
-        f.done_flag = caller_syncs ? s.h_done + pipe_slot : nullptr;
-        f.epoch = ++s.epoch;
-        if (s.epoch == 0) f.epoch = ++s.epoch; // 0 is the flag's initial value
+        // Synchronous callers poll the result block's own header: the closing workgroup stores {count, flags | epoch << 8,
+        // approx} in ONE 16-byte write when the hits are out (a separate completion word meant waiting for the header's
+        // acknowledgement over PCIe first: ~1.3 us per query); finish_query_sync clears the epoch bits again.
+        f.done_flag = caller_syncs ? s.h_done + pipe_slot : nullptr; // (non-null = "the caller polls the header")
+        f.epoch = ++s.epoch & 0xFFFFFFu;
+        if (f.epoch == 0) f.epoch = ++s.epoch & 0xFFFFFFu; // 0: what a clean header holds
+        if (caller_syncs) static_cast<gsim_result_header*>(out)->flags = 0;
         static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
         if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
         f.dbg = s.d_dbg;
@@ -586,24 +590,25 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
 {
     if (!s.slot_fused[pipe_slot]) return wait_stream(s.stream);
     s.slot_fused[pipe_slot] = false;
-    volatile uint32_t* flag = s.h_done + pipe_slot;
+    volatile uint32_t* flag = &static_cast<gsim_result_header*>(out)->flags; // (flags | epoch << 8: one 16-byte store with the rest of the header)
     const uint32_t want = s.slot_epoch[pipe_slot];
     bool done = false;
     for (uint64_t spins = 0;; spins++) {
-        if (*flag == want) {
+        if ((*flag >> 8) == want) {
             done = true;
             break;
         }
-        if ((spins & 0x3FFu) == 0x3FFu) { // now and then: did the launch fail or end without the flag?
+        if ((spins & 0x3FFu) == 0x3FFu) { // now and then: did the launch fail or end without the header?
             const hipError_t e = hipStreamQuery(s.stream);
             if (e == hipSuccess) {
-                done = *flag == want;
+                done = (*flag >> 8) == want;
                 break;
             }
             if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (done) *flag &= 0xFFu; // the header as every other route leaves it
     const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
     if (s.d_dbg && done) { // phase profile of this query (instrumented runs only)
         const size_t nwg = s.fgeo.nwaves / 4;

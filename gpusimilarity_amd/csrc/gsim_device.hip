@@ -1611,18 +1611,12 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         { // the header, write-through as the hits
             const u64 approx = a.cutoff > 0.0f ? __hip_atomic_load(&st->kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.nrows;
             const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(fa.result, 0, 16, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{redo ? 0u : (nfin < a.k ? nfin : a.k), redo ? 2u : 0u, static_cast<uint32_t>(approx), static_cast<uint32_t>(approx >> 32)},
+            // The block is complete (every selector waited for its hits before its ticket): for a synchronous caller the
+            // header carries the query's epoch -- the host polls it, one 16-byte write tells it everything -- and the
+            // tidying up below happens behind the caller's back.
+            const uint32_t flags = (redo ? 2u : 0u) | (fa.done_flag ? fa.epoch << 8 : 0u);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{redo ? 0u : (nfin < a.k ? nfin : a.k), flags, static_cast<uint32_t>(approx), static_cast<uint32_t>(approx >> 32)},
                                                    rrs, 0, 0, /*sc0 sc1*/ 17);
-        }
-        if (fa.done_flag) {
-            // the block is complete (every selector waited for its hits before its ticket, the header is out once its
-            // acknowledgement is in): tell the host NOW, tidy up after
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (fa.xflags & 1024u) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __hip_atomic_store(fa.done_flag, fa.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         // re-zero the per-query state for the next launch (stream-ordered behind this one)
         st->ncand_sum += __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
