@@ -543,6 +543,11 @@ struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
 };
 
 static_assert(sizeof(FusedShared) <= 160 * 1024, "FusedShared exceeds the LDS of a CU");
+// the packed words of the select phase
+static_assert(kFusedSelectors <= 256 && kFusedRegion <= 8192, "item = region (8 bits) | first entry / 16 (9 bits) | entries - 1 (6 bits) | last (1 bit)");
+static_assert(kFusedRegion <= 0xFFFF, "rn = entries (16 bits) | bucket shift (5 bits) << 16 | exact order << 31");
+static_assert(kFusedFinalLds <= (1 << 14) && kFusedMineCap < (1 << 18), "slot of a finalist: 14 bits (| count << 14 in a node, | node << 14 in a queue entry)");
+static_assert(kFusedItems >= 4 * kFusedSelectors, "a round lists at most four items per region");
 
 __device__ __forceinline__ uint32_t agent_load(const uint32_t* p)
 {

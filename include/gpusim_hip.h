@@ -65,7 +65,9 @@ typedef struct {
  * gsim_merge_device: {gsim_result_header; gsim_hit hits[k];}. */
 typedef struct {
     uint32_t count;  /* number of valid hits (<= k)                         */
-    uint32_t flags;  /* bit 0: block produced by the general (large) path   */
+    uint32_t flags;  /* bit 0: block produced by the general (large) path; bit 1: the single launch handed the query back
+                        (internal: never set in a block a call returns); bits 8..31: zero in every returned block
+                        (the library's own pinned blocks carry the query's epoch there while it polls them) */
     uint64_t approx; /* "approximate matching results", see gsim_db_search  */
 } gsim_result_header;
 
