@@ -83,7 +83,7 @@ constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in
 constexpr int kFusedSelectors = 256;        // workgroups of the grid: every one of them ranks its share of the finalists
 constexpr uint32_t kFusedRegion = 4 * kFusedWaveCap; // published entries (16 B each) of one workgroup: its fixed region of the list
 constexpr uint32_t kFusedHeaderBytes = 16;  // per workgroup: {entries | sorted << 31, 0, its end-of-scan report (64-bit key)}
-constexpr uint32_t kFusedArriveWords = 17;  // arrival: 8 group counters (b % 8), 1 top counter, 8 generation words, 128 B apart
+constexpr uint32_t kFusedArriveWords = 25;  // arrival: 8 group counters (b % 8), 1 top counter, 8 generation words; closing: 8 group tickets -- 128 B apart
 
 struct FusedArgs {
     void* pub;            // device, nwg regions of kFusedRegion x 16 B {key, cb, 0}: what each workgroup publishes

@@ -1605,12 +1605,24 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         // the ticket also carries "this selector saw the query fail" (bit 16 up): the closer learns it without another
         // round trip (a workgroup that set QueryState::redo while publishing did so before the grid-wide wait: every
         // selector read it after the wait and is not `good`)
-        sh.ticket = atomicAdd(&st->sel_done, good ? 1u : 0x10001u);
+        // Two levels, as the arrival: 256 atomics on ONE word queue up behind each other (the last ticket came 3.3 us
+        // after the average selector was ready); a ticket per group b % 8 first, the group's last adds to the top.
+        const uint32_t x = blockIdx.x % 8u;
+        const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
+        const uint32_t tg = atomicAdd(&fa.arrive[(17u + x) * 32u], good ? 1u : 0x10001u);
+        uint32_t closing = 0, failed = 0;
+        if ((tg & 0xFFFFu) == group_size - 1u) {
+            const bool gfail = (tg >> 16) != 0 || !good;
+            const uint32_t tt = atomicAdd(&st->sel_done, gfail ? 0x10001u : 1u);
+            closing = (tt & 0xFFFFu) == ngroups - 1u ? 1u : 0u;
+            failed = ((tt >> 16) != 0 || gfail) ? 1u : 0u;
+        }
+        sh.ticket = closing | (failed << 1);
     }
     __syncthreads();
     GSIM_STAMP(7);
-    if ((sh.ticket & 0xFFFFu) != nsel - 1) return;
-    const uint32_t redo = ((sh.ticket >> 16) != 0 || !good) ? 1u : 0u;
+    if (!(sh.ticket & 1u)) return;
+    const uint32_t redo = ((sh.ticket & 2u) != 0 || !good) ? 1u : 0u;
     if (redo && tid == 0) atomicOr(&st->redo, kRedoSeen); // (the gated classic kernels behind an enqueue-only launch read it)
     if (tid == 0) {
         { // the header, write-through as the hits
