@@ -847,7 +847,7 @@ def test_matrix_core_pass_large_k_and_tiny_tables(W, n, nq, k):
     t.close()
 
 
-@pytest.mark.parametrize("W,n", [(32, 20_000_000), (64, 17_000_000)])
+@pytest.mark.parametrize("W,n", [(32, 20_000_000), (64, 17_000_000), (16, 24_000_000), (8, 30_000_000)])
 def test_matrix_core_pass_with_cutoff(W, n):
     """Batches with a cutoff on tables large enough for the matrix-core sample pass: a selective
     cutoff stays on the matrix cores with the rows at or above it counted on the exact path; a cutoff
@@ -891,6 +891,31 @@ def test_matrix_core_pass_with_cutoff(W, n):
             want, wap = O.search(qs[i], db, 100, np.float32(cutoff), nthreads=ORACLE_THREADS, **kw)
             assert int(approx[i]) == wap, "oracle W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], wap)
             assert_hits_equal(hits[i], want, "oracle W=%d cutoff=%g q=%d" % (W, cutoff, i))
+
+
+def test_matrix_core_dense_cutoff_full_batch():
+    """256 queries (eight query tiles: every wave its own) through the dense-cutoff variant, 2048-bit rows, Tversky as
+    BASELINE configs[4]: counts and hits equal the single-query pipeline's for every query, the oracle's for a few."""
+    W, n = 64, 16_500_000
+    t = capi.Table(W * 32)
+    t.generate(0x5EED0003, capi.SYNTH_SPARSE, 0, n, 0)
+    qs = np.stack([O.synth_rows(0x5EED0003, 0, O.query_row(i, n), 1, W)[0] for i in range(256)])
+    kw = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    cutoff = np.float32(0.06)
+    before = t.timing()["batches_dense_cutoff"]
+    hits, approx = t.search(qs, 50, cutoff, **kw)
+    assert t.timing()["batches_dense_cutoff"] > before
+    assert int(np.min(approx)) > n // 512  # (dense indeed)
+    for i in range(256):
+        one, ap1 = t.search(qs[i], 50, cutoff, **kw)
+        assert int(approx[i]) == int(ap1[0]), "q=%d approx %d vs %d" % (i, approx[i], ap1[0])
+        assert_hits_equal(hits[i], one[0], "q=%d" % i)
+    t.close()
+    db = _host_table(0x5EED0003, n, W)
+    for i in (0, 100, 255):
+        want, wap = O.search(qs[i], db, 50, cutoff, nthreads=ORACLE_THREADS, **kw)
+        assert int(approx[i]) == wap
+        assert_hits_equal(hits[i], want, "oracle q=%d" % i)
 
 
 def test_bench_contract_lines():
