@@ -126,7 +126,7 @@ struct Shard {
     void* d_pub = nullptr;      // single-launch path: the workgroups' published-candidate regions (128 KB each)
     void* d_hdr = nullptr;      // ... and their headers (64 B each)
     uint32_t* d_summ = nullptr; // single-launch path: per-wave checkpoint summaries (16 KB, zero between queries)
-    uint32_t* h_done = nullptr; // single-launch path: pinned words (one per pipeline slot) the kernel stores the query's epoch into
+    uint32_t* h_done = nullptr; // single-launch path: pinned words, one per pipeline slot (since round 3 only their address is used: "the caller polls the header")
     uint32_t epoch = 0;
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
     uint32_t slot_epoch[kPipe] = {}; // ... with this epoch

@@ -95,7 +95,7 @@ struct FusedArgs {
     uint32_t* tickets;    // device, kFusedCheckpoints x 9 counters 128 B apart (8 per-group + 1 top), zero between queries
     void* result;         // result block: device memory or device-visible pinned host memory
     uint32_t row_base;
-    uint32_t* done_flag;  // NULL, or device-visible pinned host word that receives `epoch` when the block is complete
+    uint32_t* done_flag;  // non-NULL: a synchronous caller polls the result header (in pinned host memory): its flags word carries `epoch` << 8
     uint32_t epoch;
     uint32_t wait_ticks;     // bound of the grid-wide wait (100 MHz ticks): a few scan times, see fused_kernel
     uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints

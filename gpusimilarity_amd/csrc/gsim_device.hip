@@ -463,23 +463,25 @@ template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_ker
 //      holds a smaller key, which only lowers the threshold.  The streaming waves never touch global memory for any
 //      of this (one in-order vmcnt: a store or atomic would drain their prefetch);
 //   3. a workgroup that has finished streaming drops what lies below the freshest in-loop threshold and publishes
-//      the rest into ITS OWN fixed region of the list -- no reservation, no exchange before it; in canonical order
-//      when there are few rows (the usual case: a local rank count) -- together with a 64-byte header: the count
-//      and its four waves' END-OF-SCAN reports (each wave's M-th best 64-bit key over all its rows).  Write-through
-//      stores, one wait, one arrival atomic (eight counters) that nobody waits for;
+//      the rest into ITS OWN fixed region of the list -- no reservation, no exchange before it -- in an order a reader
+//      can stop in: canonical order up to kFusedSortCap rows (a local rank count), bucket order above (a counting
+//      sort by score key >> shift, highest bucket first); its 16-byte header holds the count, the order, the shift
+//      and the workgroup's REPORT, its Mw-th best 64-bit key.  Write-through stores, one wait, a two-level arrival
+//      (a counter per group of workgroups, a top counter, one generation word per group);
 //   4. every workgroup then becomes a selector.  It waits until all have arrived -- the ONE grid-wide wait of the
-//      kernel (round 2 had two: an end-of-scan threshold exchange on small tables, then this one); bounded by a few
-//      scan times of wall clock: on a GPU shared with another queue part of the grid may not have started while the
-//      waiters hold their CUs, the query then goes to the four-kernel pipeline, which never waits -- and requests, in
-//      one round trip, every workgroup's header and the first 16 entries of every region.  From the 4 x #workgroups
-//      end-of-scan reports every selector derives the SAME final threshold (fused_final_threshold: the r-th largest
-//      report as a 64-bit key -- it carries the row index, so it also cuts through groups of equal scores), keeps the
-//      published rows at or above it in LDS (regions whose prefix is exhausted are read on: clustered rows, ties) and
-//      ranks the rows it owns (hash of the row) by counting larger keys -- the output slot of a hit is its rank, keys
-//      are unique -- writing the hits of rank < k straight into the result block;
-//   5. the last selector writes the header and, for the synchronous API, stores the query's epoch into a pinned host
-//      word the caller polls -- the hits (in pinned host memory) are complete when it changes, without waiting for
-//      the kernel's end-of-launch bookkeeping -- and then re-zeroes the per-query state.
+//      kernel; bounded by a few scan times of wall clock: on a GPU shared with another queue part of the grid may
+//      not have started while the waiters hold their CUs, the query then goes to the four-kernel pipeline, which
+//      never waits -- and requests, in one round trip, every workgroup's header and the first 16 entries of every
+//      region.  From the reports every selector derives the SAME final threshold (the r-th largest report as a
+//      64-bit key -- it carries the row index, so it also cuts through groups of equal scores), keeps the published
+//      rows at or above it in LDS (a list is read on, 64 entries at a time, until an entry proves the rest lies below
+//      the threshold) and ranks the rows it owns (hash of the row) -- by counting larger keys, or through a histogram
+//      of the finalists when there are many -- the output slot of a hit is its rank, keys are unique; the hits of
+//      rank < k go straight into the result block, written through at system scope;
+//   5. every selector waits for its stores' acknowledgements and takes a (two-level) ticket; the last one writes the
+//      header -- for the synchronous API with the query's epoch in the flags word: the caller polls the header of its
+//      pinned block, ONE 16-byte store is header and completion signal, no fence anywhere -- and then re-zeroes the
+//      per-query state behind the caller's back.
 //
 // Whatever the path cannot hold (a wave's store that stays full after compaction, more than 16 Ki finalists or 2 Ki
 // owned by one selector: extreme ties, rows in ascending score order) sets QueryState::redo and header flag 2; the
