@@ -67,5 +67,6 @@ while done < iters:
 tm = t.timing()
 if hb_by_case:
     print("handed back by (k, cutoff):", sorted(hb_by_case.items()))
-print("soak (%s rows): rows %d, %d queries in %.1f s, mismatches %d, handed back %d" % (os.environ.get("SOAK_KIND", "sparse"), n, done, time.time() - t0, bad, tm["handed_back"]))
+print("soak (%s rows): rows %d, %d queries in %.1f s, mismatches %d, handed back %d%s" % (os.environ.get("SOAK_KIND", "sparse"), n, done, time.time() - t0, bad, tm["handed_back"],
+      " (reasons, gsim_timing.handed_back_why: %d)" % tm["handed_back_why"] if tm["handed_back"] else ""))
 sys.exit(1 if bad else 0)
