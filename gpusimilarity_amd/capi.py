@@ -31,7 +31,8 @@ HEADER_DTYPE = np.dtype([("count", "<u4"), ("flags", "<u4"), ("approx", "<u8")])
 class GsimTiming(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("scan_ms_sum", C.c_double), ("select_ms_sum", C.c_double),
                 ("candidates_sum", C.c_uint64), ("finalists_sum", C.c_uint64), ("handed_back", C.c_uint64),
-                ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64), ("batches_dense_cutoff", C.c_uint64)]
+                ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64), ("batches_dense_cutoff", C.c_uint64),
+                ("collectives", C.c_uint64), ("gather_ms_sum", C.c_double), ("merge_ms_sum", C.c_double)]
 
 
 class GsimError(RuntimeError):
@@ -50,6 +51,7 @@ EXPORTS = [
     "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
     "gsim_merge_device_batch", "gsim_merge_host",
+    "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm",
     "gsim_db_enable_timing",
     "gsim_db_get_timing", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_last_error", "gsim_version",
 ]
@@ -106,6 +108,10 @@ def load():
                                                   C.c_float, vp]),
         "gsim_merge_device_batch": (C.c_int, [C.c_int, vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
         "gsim_merge_host": (C.c_int, [vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
+        "gsim_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+        "gsim_comm_destroy": (C.c_int, [vp]),
+        "gsim_comm_size": (C.c_int, [vp]),
+        "gsim_db_set_comm": (C.c_int, [vp, vp]),
         "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
@@ -287,6 +293,11 @@ class Table:
         check(self._L.gsim_db_search_batch_device(self._h, _u32(q), len(q), k, cutoff, metric, alpha, beta,
                                                   C.c_void_p(d_results_ptr)))
 
+    def set_comm(self, comm):
+        """Route multi-shard searches through `comm` (a :class:`Comm`; None: back to the host merge)."""
+        check(self._L.gsim_db_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm  # (keeps it alive)
+
     def enable_timing(self, enable=True):
         check(self._L.gsim_db_enable_timing(self._h, 1 if enable else 0))
 
@@ -294,6 +305,25 @@ class Table:
         t = GsimTiming()
         check(self._L.gsim_db_get_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in GsimTiming._fields_}
+
+
+class Comm:
+    """``gsim_comm``: the RCCL communicator of an in-process multi-device handle (ncclCommInitAll)."""
+
+    def __init__(self, devices):
+        self._L = load()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        check(self._L.gsim_comm_create(devs, len(devices), C.byref(h)))
+        self._h = h
+
+    def size(self) -> int:
+        return int(self._L.gsim_comm_size(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsim_comm_destroy(self._h)
+            self._h = None
 
 
 def fold_fingerprint(fp, fold_factor: int) -> np.ndarray:

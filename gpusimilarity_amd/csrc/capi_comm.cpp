@@ -1,0 +1,307 @@
+// capi_comm.cpp -- the collective route of an in-process multi-device handle: "per-GPU top-k merged via a small RCCL
+// gather over xGMI" without PyTorch.  FingerprintDB::search merges its storages' results on the host
+// (fingerprintdb_cuda.cu:356-380); with a communicator attached (gsim_db_set_comm) every shard leaves its result block in
+// its own device's HBM, ONE grouped ncclAllGather (12 016 B per device at k = 1000) brings all blocks to every device and
+// merge_kernel on the first shard's device writes the merged block into pinned host memory.  Same results bit for bit as
+// the host merge, which stays the default (profiles/r03_merge_cost.json: the host merge costs < 40 us and its inputs are
+// already in host memory; what the collective buys on a real 8-GPU node is for the hardware to say).
+#include "capi_internal.h"
+
+#include <rccl/rccl.h>
+
+struct gsim_comm {
+    std::vector<int> devices;       // logical device per rank, in the order of the handle's shards
+    std::vector<ncclComm_t> comms;  // one communicator per device (ncclCommInitAll); empty: loop-back
+    bool loopback = false;          // aliased devices (test hook): all ranks live on one physical GPU, which RCCL refuses;
+                                    // the gather is then device-to-device copies into the first rank's buffer
+};
+
+namespace gsim_host
+{
+
+namespace
+{
+
+int fail_nccl(ncclResult_t r, const char* what)
+{
+    g_last_error = std::string(what) + ": " + ncclGetErrorString(r);
+    return GSIM_ERR_HIP;
+}
+
+#define GSIM_NCCL(call)                                       \
+    do {                                                      \
+        ncclResult_t r__ = (call);                            \
+        if (r__ != ncclSuccess) return fail_nccl(r__, #call); \
+    } while (0)
+
+// every shard's gather buffer holds `per_shard` bytes for each shard of the handle
+int ensure_gather(gsim_db* db, size_t per_shard)
+{
+    const size_t need = per_shard * db->shards.size();
+    for (auto& s : db->shards) {
+        GSIM_HIP(set_device(s.device));
+        if (need > s.gather_bytes) {
+            if (s.d_gather) GSIM_HIP(hipFree(s.d_gather));
+            s.d_gather = nullptr;
+            s.gather_bytes = 0;
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_gather), need));
+            s.gather_bytes = need;
+        }
+        if (!s.gather_ev) GSIM_HIP(hipEventCreateWithFlags(&s.gather_ev, hipEventDisableTiming));
+    }
+    Shard& s0 = db->shards[0];
+    GSIM_HIP(set_device(s0.device));
+    for (auto& e : s0.cev)
+        if (!e) GSIM_HIP(hipEventCreate(&e));
+    return GSIM_OK;
+}
+
+// Slot i of every shard's buffer <- shard i's slot (an in-place all-gather over the shards' own streams, so that it is
+// ordered behind each shard's search kernels and before the merge on the first shard's stream).
+int all_gather(gsim_db* db, size_t per_shard)
+{
+    const gsim_comm* c = db->comm;
+    const size_t n = db->shards.size();
+    if (!c->loopback) {
+        GSIM_NCCL(ncclGroupStart());
+        for (size_t i = 0; i < n; i++) {
+            Shard& s = db->shards[i];
+            const ncclResult_t r = ncclAllGather(s.d_gather + i * per_shard, s.d_gather, per_shard, ncclChar, c->comms[i], s.stream);
+            if (r != ncclSuccess) {
+                (void) ncclGroupEnd();
+                return fail_nccl(r, "ncclAllGather");
+            }
+        }
+        GSIM_NCCL(ncclGroupEnd());
+        return GSIM_OK;
+    }
+    // loop-back: only the first shard's buffer is read afterwards
+    Shard& s0 = db->shards[0];
+    for (size_t i = 1; i < n; i++) {
+        Shard& s = db->shards[i];
+        GSIM_HIP(set_device(s.device));
+        GSIM_HIP(hipEventRecord(s.gather_ev, s.stream));
+        GSIM_HIP(set_device(s0.device));
+        GSIM_HIP(hipStreamWaitEvent(s0.stream, s.gather_ev, 0));
+        GSIM_HIP(hipMemcpyAsync(s0.d_gather + i * per_shard, s.d_gather + i * per_shard, per_shard, hipMemcpyDeviceToDevice, s0.stream));
+    }
+    return GSIM_OK;
+}
+
+// the shards other than the first: their part of the gather is done (the next query reuses the buffers)
+int wait_others(gsim_db* db)
+{
+    for (size_t i = 1; i < db->shards.size(); i++) {
+        Shard& s = db->shards[i];
+        GSIM_HIP(set_device(s.device));
+        const int rc = wait_stream(s.stream);
+        if (rc != GSIM_OK) return rc;
+    }
+    return GSIM_OK;
+}
+
+int fold_comm_timing(gsim_db* db)
+{
+    Shard& s0 = db->shards[0];
+    float g = 0.f, m = 0.f;
+    GSIM_HIP(hipEventElapsedTime(&g, s0.cev[0], s0.cev[1]));
+    GSIM_HIP(hipEventElapsedTime(&m, s0.cev[1], s0.cev[2]));
+    db->acc.gather_ms_sum += g;
+    db->acc.merge_ms_sum += m;
+    db->acc.collectives++;
+    return GSIM_OK;
+}
+
+} // namespace
+
+void free_comm_buffers(Shard& s)
+{
+    if (s.d_gather) (void) hipFree(s.d_gather);
+    if (s.d_merged) (void) hipFree(s.d_merged);
+    if (s.gather_ev) (void) hipEventDestroy(s.gather_ev);
+    for (auto e : s.cev)
+        if (e) (void) hipEventDestroy(e);
+}
+
+// One query on every shard -> blocks in HBM -> all-gather -> merge_kernel -> pinned host block (search_one's twin).
+int search_one_comm(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
+                    uint32_t* count, uint64_t* approx)
+{
+    const size_t n = db->shards.size();
+    const size_t blk = gsim_result_block_bytes(k);
+    int rc = ensure_gather(db, blk);
+    if (rc != GSIM_OK) return rc;
+    Shard& s0 = db->shards[0];
+    rc = ensure_result_capacity(s0, k);
+    if (rc != GSIM_OK) return rc;
+    for (size_t i = 0; i < n; i++) {
+        Shard& s = db->shards[i];
+        rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base + static_cast<uint32_t>(s.first_row),
+                           s.d_gather + i * blk, false);
+        if (rc != GSIM_OK) return rc;
+    }
+    GSIM_HIP(set_device(s0.device));
+    if (db->timing) GSIM_HIP(hipEventRecord(s0.cev[0], s0.stream));
+    rc = all_gather(db, blk);
+    if (rc != GSIM_OK) return rc;
+    GSIM_HIP(set_device(s0.device));
+    if (db->timing) GSIM_HIP(hipEventRecord(s0.cev[1], s0.stream));
+    GSIM_HIP(gsim::launch_merge_batch(s0.d_gather, static_cast<uint32_t>(n), 1, blk, k, s0.h_result, s0.stream)); // (zero-copy into pinned memory)
+    if (db->timing) GSIM_HIP(hipEventRecord(s0.cev[2], s0.stream));
+    rc = wait_stream(s0.stream);
+    if (rc != GSIM_OK) return rc;
+    rc = wait_others(db);
+    if (rc != GSIM_OK) return rc;
+    if (db->timing) {
+        rc = fold_comm_timing(db);
+        if (rc != GSIM_OK) return rc;
+    }
+    const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s0.h_result);
+    std::memcpy(hits, h + 1, sizeof(gsim_hit) * h->count);
+    *count = h->count;
+    if (approx) *approx = h->approx;
+    return GSIM_OK;
+}
+
+// nq queries through the shared table passes on every shard -> nq blocks per shard in HBM -> one all-gather per 256
+// queries -> merge_kernel for all of them -> one copy to the host (search_batched's twin).
+int search_batch_comm(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff, int metric, float alpha,
+                      float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    const size_t n = db->shards.size();
+    const size_t blk = gsim_result_block_bytes(k);
+    Shard& s0 = db->shards[0];
+    std::vector<unsigned char> host;
+    for (uint32_t base = 0; base < nq; base += kBatchMaxQ) {
+        const uint32_t nb = std::min<uint32_t>(kBatchMaxQ, nq - base);
+        const uint32_t* qb = queries + static_cast<size_t>(base) * db->W;
+        const size_t per = blk * nb;
+        int rc = ensure_gather(db, per);
+        if (rc != GSIM_OK) return rc;
+        GSIM_HIP(set_device(s0.device));
+        if (per > s0.merged_bytes) {
+            if (s0.d_merged) GSIM_HIP(hipFree(s0.d_merged));
+            s0.d_merged = nullptr;
+            s0.merged_bytes = 0;
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s0.d_merged), per));
+            s0.merged_bytes = per;
+        }
+        for (size_t i = 0; i < n; i++) { // all shards scan at once ...
+            Shard& s = db->shards[i];
+            rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, db->row_base + static_cast<uint32_t>(s.first_row),
+                               s.d_gather + i * per);
+            if (rc != GSIM_OK) return rc;
+        }
+        for (size_t i = 0; i < n; i++) { // ... and each says whether its pass could finish every query
+            Shard& s = db->shards[i];
+            GSIM_HIP(set_device(s.device));
+            rc = wait_stream(s.stream);
+            if (rc != GSIM_OK) return rc;
+            const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
+            if (s.h_bflags[0] & 16u) db->dense_batches++;
+            if ((s.h_bflags[0] & 24u) == 8u) { // a dense cutoff without a usable band: the VALU pass
+                rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, row_base, s.d_gather + i * per, false);
+                if (rc != GSIM_OK) return rc;
+                rc = wait_stream(s.stream);
+                if (rc != GSIM_OK) return rc;
+            }
+            if ((s.h_bflags[0] & 5u) != 0) { // heavy ties / candidate overflow: this shard's chunk through the single-query pipeline
+                for (uint32_t q = 0; q < nb; q++) {
+                    rc = enqueue_query(db, s, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta, row_base,
+                                       s.d_gather + i * per + q * blk, false);
+                    if (rc != GSIM_OK) return rc;
+                }
+            }
+        }
+        GSIM_HIP(set_device(s0.device));
+        if (db->timing) GSIM_HIP(hipEventRecord(s0.cev[0], s0.stream));
+        rc = all_gather(db, per);
+        if (rc != GSIM_OK) return rc;
+        GSIM_HIP(set_device(s0.device));
+        if (db->timing) GSIM_HIP(hipEventRecord(s0.cev[1], s0.stream));
+        GSIM_HIP(gsim::launch_merge_batch(s0.d_gather, static_cast<uint32_t>(n), nb, blk, k, s0.d_merged, s0.stream));
+        if (db->timing) GSIM_HIP(hipEventRecord(s0.cev[2], s0.stream));
+        host.resize(per);
+        GSIM_HIP(hipMemcpyAsync(host.data(), s0.d_merged, per, hipMemcpyDeviceToHost, s0.stream));
+        rc = wait_stream(s0.stream);
+        if (rc != GSIM_OK) return rc;
+        rc = wait_others(db);
+        if (rc != GSIM_OK) return rc;
+        if (db->timing) {
+            rc = fold_comm_timing(db);
+            if (rc != GSIM_OK) return rc;
+        }
+        for (uint32_t q = 0; q < nb; q++) {
+            const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(host.data() + q * blk);
+            std::memcpy(hits + static_cast<size_t>(base + q) * kout, h + 1, sizeof(gsim_hit) * h->count);
+            counts[base + q] = h->count;
+            if (approx) approx[base + q] = h->approx;
+        }
+    }
+    return GSIM_OK;
+}
+
+} // namespace gsim_host
+
+using namespace gsim_host;
+
+extern "C" {
+
+int gsim_comm_create(const int* devices, int ndevices, gsim_comm** out)
+{
+    if (!devices || !out || ndevices < 1) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (ndev == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");
+    for (int i = 0; i < ndevices; i++) {
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+        for (int j = 0; j < i; j++)
+            if (devices[j] == devices[i]) return fail(GSIM_ERR_INVALID, "a device appears twice in the communicator");
+    }
+    gsim_comm* c = new (std::nothrow) gsim_comm;
+    if (!c) return fail(GSIM_ERR_NOMEM, "out of host memory");
+    c->devices.assign(devices, devices + ndevices);
+    if (alias_devices() && ndevices > 1) {
+        c->loopback = true; // (all logical devices are physical GPU 0: RCCL refuses two ranks on one device)
+    } else {
+        std::vector<int> phys(ndevices);
+        for (int i = 0; i < ndevices; i++) phys[i] = phys_device(devices[i]);
+        c->comms.resize(static_cast<size_t>(ndevices));
+        const ncclResult_t r = ncclCommInitAll(c->comms.data(), ndevices, phys.data());
+        if (r != ncclSuccess) {
+            delete c;
+            return fail_nccl(r, "ncclCommInitAll");
+        }
+    }
+    *out = c;
+    return GSIM_OK;
+}
+
+int gsim_comm_destroy(gsim_comm* comm)
+{
+    if (!comm) return GSIM_OK;
+    for (auto c : comm->comms) (void) ncclCommDestroy(c);
+    delete comm;
+    return GSIM_OK;
+}
+
+int gsim_comm_size(const gsim_comm* comm)
+{
+    return comm ? static_cast<int>(comm->devices.size()) : 0;
+}
+
+int gsim_db_set_comm(gsim_db* db, gsim_comm* comm)
+{
+    if (!db || !db->finalized) return fail(GSIM_ERR_STATE, "table not finalized");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    if (comm) {
+        if (db->fold > 1) return fail(GSIM_ERR_STATE, "folded tables merge on the host (their re-score needs every storage's candidates there)");
+        if (comm->devices.size() != db->shards.size()) return fail(GSIM_ERR_INVALID, "the communicator's size differs from the handle's shard count");
+        for (size_t i = 0; i < db->shards.size(); i++)
+            if (comm->devices[i] != db->shards[i].device) return fail(GSIM_ERR_INVALID, "the communicator's devices differ from the shards' devices");
+    }
+    db->comm = comm;
+    return GSIM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,426 @@
+// capi_query.cpp -- the single-query path of the C ABI: the per-query launch sequence on a shard (single launch, or
+// sample -> scan -> compact -> select), completion, the shard fan-out + host merge of FingerprintDB::search
+// (fingerprintdb_cuda.cu:341-381), gsim_db_search / _each / _device.
+#include "capi_internal.h"
+
+namespace gsim_host
+{
+
+// Scratch of the four-kernel pipeline (per-wave candidate segments + finalists: the worst case is
+// every row a candidate, 24 B per row).  The single-launch path keeps its candidates in LDS and
+// needs none of it, so it is only allocated when a query takes the classic pipeline: k above
+// kFusedMaxK, widths without a specialised scan, or a query the single-launch path handed back
+// (heavy ties, adversarial row orders).
+int ensure_classic_scratch(Shard& s)
+{
+    if (s.classic_ready) return GSIM_OK;
+    GSIM_HIP(set_device(s.device));
+    const uint64_t slots = static_cast<uint64_t>(s.geo.nwaves) * s.geo.seg_cap;
+    GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
+    GSIM_HIP(hipMalloc(&s.d_cand_cb, static_cast<size_t>(slots) * 4));
+    GSIM_HIP(hipMalloc(&s.d_seg_count, static_cast<size_t>(s.geo.nwaves) * 4));
+    s.final_cap = next_pow2_u32(slots);
+    GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
+    GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
+    s.classic_ready = true;
+    return GSIM_OK;
+}
+
+int ensure_result_capacity(Shard& s, uint32_t k)
+{
+    const size_t need = gsim_result_block_bytes(k);
+    if (need > s.result_bytes) {
+        GSIM_HIP(set_device(s.device));
+        if (s.d_result) GSIM_HIP(hipFree(s.d_result));
+        s.d_result = nullptr;
+        GSIM_HIP(hipMalloc(&s.d_result, need));
+        s.result_bytes = need;
+    }
+    if (need > s.h_result_bytes) {
+        if (s.h_result) GSIM_HIP(hipHostFree(s.h_result));
+        s.h_result = nullptr;
+        GSIM_HIP(hipHostMalloc(&s.h_result, need, kHostPolled));
+        s.h_result_bytes = need;
+    }
+    return GSIM_OK;
+}
+
+bool fused_applies(const Shard& s, uint32_t k)
+{
+    static const int enabled = env_int("GSIM_FUSED", 1);
+    static const long long max_rows = std::getenv("GSIM_FUSED_MAX_ROWS") ? std::atoll(std::getenv("GSIM_FUSED_MAX_ROWS")) : -1;
+    if (!enabled || k == 0 || k > gsim::kFusedMaxK || s.nrows == 0 || !gsim::fused_supported(s.fgeo)) return false;
+    // thresholds need >= k summary keys; without them every row is published (tiny tables only)
+    if ((gsim::fused_summary_keys(s.fgeo.nwaves, k) == 0 || gsim::fused_final_keys(s.fgeo.nwaves / 4, k) == 0) && s.nrows > 8192) return false;
+    return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
+}
+
+namespace
+{
+// Enqueue one query on one shard; the result block ends up at `out`, which is
+// device memory or device-visible pinned host memory (zero-copy).
+//
+// Single-launch path (fused_applies): ONE kernel does scan + publish + select.  Synchronous
+// callers (caller_syncs) get the query's epoch stored into s.h_done when the block is complete
+// and check header flag 2 ("handed back": re-run with mode kClassic).  Enqueue-only callers
+// (the RCCL path) get the four classic kernels enqueued behind it, gated on QueryState::redo:
+// they return at once unless the single launch handed the query back.
+//
+// Classic path: sample -> scan -> compact -> select.  The query is read by the kernels straight
+// from a pinned ring slot (no upload op) and the last kernel re-zeroes the per-query state (no
+// memset op).  Nothing here synchronises with the host, whatever k.
+int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                       float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode, uint32_t pipe_slot)
+{
+    GSIM_HIP(set_device(s.device));
+    if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
+        GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, ncand_sum), s.stream));
+        GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
+        s.state_dirty = false;
+    }
+    bool fused = mode == kAuto && fused_applies(s, k);
+    if (fused && caller_syncs && s.fused_skip) {
+        s.fused_skip--;
+        fused = false;
+    }
+    const bool classic = !fused || !caller_syncs;
+    if (classic) {
+        const int rc = ensure_classic_scratch(s);
+        if (rc != GSIM_OK) return rc;
+    }
+    const uint32_t slot = s.q_next++ % kQueryRing;
+    uint32_t* hq = s.h_query + static_cast<size_t>(slot) * s.W;
+    if (s.q_pending[slot]) { // only set by asynchronous searches
+        GSIM_HIP(hipEventSynchronize(s.q_ev[slot]));
+        s.q_pending[slot] = false;
+    }
+    std::memcpy(hq, query, static_cast<size_t>(s.W) * 4); // `query` is already folded for a folded table
+
+    gsim::ScanArgs a{};
+    a.rows = s.d_rows;
+    a.nrows = s.nrows;
+    a.W = s.W;
+    a.query = hq; // hipHostMalloc memory: device-visible at the same address
+    a.query_dev = s.d_query;
+    a.qpop = popcount_words(query, s.W);
+    a.k = k;
+    a.cutoff = cutoff;
+    a.metric = metric;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.cand = s.d_cand;
+    a.cand_cb = s.d_cand_cb;
+    a.seg_count = s.d_seg_count;
+    a.state = s.d_state;
+    a.gate = nullptr;
+    if (s.geo.lanes_per_row == 0 || s.nrows == 0) {
+        // generic-width scan reads the query per word: give it a device copy
+        GSIM_HIP(hipMemcpyAsync(s.d_query, hq, static_cast<size_t>(s.W) * 4, hipMemcpyHostToDevice, s.stream));
+        a.query = s.d_query;
+    }
+
+    hipEvent_t* ev = nullptr;
+    if (db->timing && s.ev_used < kTimingRing) {
+        if (s.ev.size() < static_cast<size_t>(3 * (s.ev_used + 1))) {
+            for (int i = 0; i < 3; i++) {
+                hipEvent_t e;
+                GSIM_HIP(hipEventCreate(&e));
+                s.ev.push_back(e);
+            }
+        }
+        ev = &s.ev[3 * s.ev_used];
+    }
+    if (caller_syncs) s.slot_fused[pipe_slot] = false;
+    if (fused) {
+        gsim::FusedArgs f{};
+        f.pub = s.d_pub;
+        f.hdr = s.d_hdr;
+        f.arrive = s.d_summ + 4096 + kTicketWords;
+        f.summ = s.d_summ;
+        f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k);
+        f.final_keys = gsim::fused_final_keys(s.fgeo.nwaves / 4, k);
+        f.tickets = s.d_summ + 4096;
+        f.result = out;
+        f.row_base = row_base;
+        // Synchronous callers poll the result block's own header: the closing workgroup stores {count, flags | epoch << 8,
+        // approx} in ONE 16-byte write when the hits are out (a separate completion word meant waiting for the header's
+        // acknowledgement over PCIe first: ~1.3 us per query); finish_query_sync clears the epoch bits again.
+        f.done_flag = caller_syncs ? s.h_done + pipe_slot : nullptr; // (non-null = "the caller polls the header")
+        f.epoch = ++s.epoch & 0xFFFFFFu;
+        if (f.epoch == 0) f.epoch = ++s.epoch & 0xFFFFFFu; // 0: what a clean header holds
+        if (caller_syncs) static_cast<gsim_result_header*>(out)->flags = 0;
+        static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
+        if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
+        f.dbg = s.d_dbg;
+        // grid-wide waits give up after 2 ms + four scan times at 4 TB/s (only reached when the GPU is shared)
+        f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
+        static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
+        f.xflags = static_cast<uint32_t>(xflags);
+        if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+        GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
+        if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
+        if (caller_syncs) {
+            s.slot_fused[pipe_slot] = true;
+            s.slot_epoch[pipe_slot] = f.epoch;
+            if (ev) {
+                GSIM_HIP(hipEventRecord(ev[2], s.stream));
+                s.ev_used++;
+            }
+            return GSIM_OK;
+        }
+        a.gate = &s.d_state->redo; // the classic kernels behind it run only if it handed the query back
+    }
+    if (s.nrows > 0 && s.sample_chunks > 0)
+        GSIM_HIP(gsim::launch_sample(a, s.geo, static_cast<uint32_t>(s.sample_chunks), s.stream));
+    if (ev && !fused) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+    if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
+    if (!caller_syncs) { // the ring slot is free once the scan has run
+        GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream));
+        s.q_pending[slot] = true;
+    }
+    if (ev && !fused) GSIM_HIP(hipEventRecord(ev[1], s.stream));
+    if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
+    if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
+        GSIM_HIP(gsim::launch_select(a, s.d_final, s.d_final_cb, s.final_cap, row_base, out, s.stream));
+    } else {
+        // large k: the k-th largest finalist key by a radix select on the device (the finalist count never reaches the
+        // host: nothing here waits), the keys at or above it gathered and sorted in global memory (sized by k)
+        const uint32_t np2 = next_pow2_u32(k);
+        if (np2 > s.large_cap) {
+            if (s.d_large) GSIM_HIP(hipFree(s.d_large));
+            s.d_large = nullptr;
+            s.large_cap = 0;
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_large), static_cast<size_t>(np2) * 8));
+            s.large_cap = np2;
+        }
+        if (!s.d_lk) {
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_lk), sizeof(gsim::LargeKState)));
+            GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
+        }
+        GSIM_HIP(hipMemsetAsync(s.d_large, 0, static_cast<size_t>(np2) * 8, s.stream));
+        GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, s.stream));
+        GSIM_HIP(gsim::launch_bitonic_global(s.d_large, np2, s.stream));
+        GSIM_HIP(gsim::launch_emit_hits(a, s.d_large, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
+        GSIM_HIP(gsim::launch_reset_state(s.d_state, s.d_lk, s.stream));
+    }
+    if (ev) {
+        GSIM_HIP(hipEventRecord(ev[2], s.stream));
+        s.ev_used++;
+    }
+    return GSIM_OK;
+}
+} // namespace
+
+int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                  float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode, uint32_t pipe_slot)
+{
+    const int rc = enqueue_query_impl(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, caller_syncs, mode, pipe_slot);
+    if (rc != GSIM_OK) s.state_dirty = true;
+    return rc;
+}
+
+// Wait for a stream: poll for a short while (a query takes ~2 ms and the blocking
+// wait's interrupt wake-up costs 10-20 us), then block.
+int wait_stream(hipStream_t st)
+{
+    for (int i = 0; i < 200000; i++) {
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return GSIM_OK;
+        if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
+    }
+    GSIM_HIP(hipStreamSynchronize(st));
+    return GSIM_OK;
+}
+
+// Wait for the result block of the last synchronous enqueue on `s` (it was given s.h_result or any
+// pinned block `out`).  The single-launch path signals through the pinned epoch word -- the block
+// is complete when it changes, a few microseconds before the stream reports the kernel retired;
+// a query it handed back (header flag 2) is re-run by the classic kernels here.
+int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                      float beta, uint32_t row_base, void* out, uint32_t pipe_slot)
+{
+    if (!s.slot_fused[pipe_slot]) return wait_stream(s.stream);
+    s.slot_fused[pipe_slot] = false;
+    volatile uint32_t* flag = &static_cast<gsim_result_header*>(out)->flags; // (flags | epoch << 8: one 16-byte store with the rest of the header)
+    const uint32_t want = s.slot_epoch[pipe_slot];
+    bool done = false;
+    for (uint64_t spins = 0;; spins++) {
+        if ((*flag >> 8) == want) {
+            done = true;
+            break;
+        }
+        if ((spins & 0x3FFu) == 0x3FFu) { // now and then: did the launch fail or end without the header?
+            const hipError_t e = hipStreamQuery(s.stream);
+            if (e == hipSuccess) {
+                done = (*flag >> 8) == want;
+                break;
+            }
+            if (e != hipErrorNotReady) return fail_hip(e, "hipStreamQuery");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (done) *flag &= 0xFFu; // the header as every other route leaves it
+    const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
+    if (s.d_dbg && done) dump_fused_phases(s); // phase profile of this query (instrumented runs only)
+    if (done && !(h->flags & 2u)) {
+        s.redo_streak = 0;
+        return GSIM_OK;
+    }
+    if (done) {
+        s.redo_streak = s.redo_streak < 6 ? s.redo_streak + 1 : 6;
+        if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
+    }
+    if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
+    // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
+    int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
+    if (rc != GSIM_OK) return rc;
+    return wait_stream(s.stream);
+}
+
+// One query through the single-query pipeline on every shard, host merge across shards
+// (FingerprintDB::search, fingerprintdb_cuda.cu:341-381).
+int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha, float beta,
+               gsim_hit* hits, uint32_t* count, uint64_t* approx, std::vector<gsim_hit>& merged)
+{
+    const size_t nsh = db->shards.size();
+    if (db->comm) return search_one_comm(db, query, k, cutoff, metric, alpha, beta, hits, count, approx);
+    for (auto& s : db->shards) {
+        int rc = ensure_result_capacity(s, k);
+        if (rc != GSIM_OK) return rc;
+        // the select kernel writes the block straight into pinned host memory
+        rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta,
+                           db->row_base + static_cast<uint32_t>(s.first_row), s.h_result, true);
+        if (rc != GSIM_OK) return rc;
+    }
+    uint64_t ap = 0;
+    merged.clear();
+    std::vector<size_t> ends;
+    for (auto& s : db->shards) {
+        GSIM_HIP(set_device(s.device));
+        int rc = finish_query_sync(db, s, query, k, cutoff, metric, alpha, beta,
+                                   db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
+        if (rc != GSIM_OK) return rc;
+        const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
+        const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+        ap += h->approx;
+        if (nsh == 1) {
+            std::memcpy(hits, hh, sizeof(gsim_hit) * h->count);
+            *count = h->count;
+        } else {
+            merged.insert(merged.end(), hh, hh + h->count);
+            ends.push_back(merged.size());
+        }
+    }
+    if (nsh > 1) *count = merge_canonical_lists(merged, ends, k, hits); // fingerprintdb_cuda.cu:363-380
+    if (approx) *approx = ap;
+    return GSIM_OK;
+}
+
+// gsim_db_search_each on a single-shard handle: the queries still run strictly one after the other on the GPU (one
+// stream, one per-query state), but up to kPipe of them are enqueued ahead of the one the host is waiting for, each with
+// its own pinned result block and completion word -- the next kernel starts when the previous one retires instead of
+// after a host round trip (flag seen, hits copied, next launch: ~8 us per query).
+int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff,
+                          int metric, float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    GSIM_HIP(set_device(s.device));
+    const size_t blk = gsim_result_block_bytes(k);
+    if (blk > s.h_pipe_block) {
+        if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
+        s.h_pipe = nullptr;
+        s.h_pipe_block = 0;
+        GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, kHostPolled));
+        s.h_pipe_block = blk;
+    }
+    const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
+    uint32_t issued = 0;
+    for (uint32_t done = 0; done < nq; done++) {
+        for (; issued < nq && issued - done < static_cast<uint32_t>(kPipe); issued++) {
+            const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta, row_base,
+                                         s.h_pipe + (issued % kPipe) * s.h_pipe_block, true, kAuto, issued % kPipe);
+            if (rc != GSIM_OK) return rc;
+        }
+        void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
+        const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta, row_base,
+                                         out, done % kPipe);
+        if (rc != GSIM_OK) return rc;
+        const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
+        std::memcpy(hits + static_cast<size_t>(done) * kout, h + 1, sizeof(gsim_hit) * h->count);
+        counts[done] = h->count;
+        if (approx) approx[done] = h->approx;
+    }
+    return GSIM_OK;
+}
+
+int check_search_args(gsim_db* db, const uint32_t* queries, int metric)
+{
+    if (!db || !queries) return fail(GSIM_ERR_INVALID, "NULL argument");
+    if (!db->finalized) return fail(GSIM_ERR_STATE, "table not finalized (no rows on a GPU)");
+    if (metric != GSIM_METRIC_TANIMOTO && metric != GSIM_METRIC_TVERSKY) return fail(GSIM_ERR_INVALID, "unknown metric");
+    return GSIM_OK;
+}
+
+} // namespace gsim_host
+
+using namespace gsim_host;
+
+extern "C" {
+
+int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t kout, float cutoff, int metric,
+                   float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    int rc = check_search_args(db, queries, metric);
+    if (rc != GSIM_OK) return rc;
+    if ((!hits && kout && nq) || (!counts && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    // kout is the stride of the caller's hits array; the search itself never asks for more hits than the
+    // table has rows (result blocks, pinned buffers and the select's capacity scale with k: a wild count
+    // from a client must not size them)
+    const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(kout, db->nrows));
+    const size_t nsh = db->shards.size();
+    std::vector<gsim_hit> merged;
+    if (db->fold > 1) {
+        if (metric != GSIM_METRIC_TANIMOTO) return fail(GSIM_ERR_INVALID, "folded tables support Tanimoto only");
+        return search_folded(db, queries, nq, kout, cutoff, hits, counts, approx);
+    }
+    const bool batched = !g_force_each && nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 &&
+                         gsim::batch_supported(db->W) && env_int("GSIM_BATCH", 1) != 0;
+    if (batched)
+        return db->comm ? search_batch_comm(db, queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx)
+                        : search_batched(db, queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
+    static const int pipelined = env_int("GSIM_EACH_PIPELINE", 1);
+    if (g_force_each && pipelined && nsh == 1 && !db->comm && nq > 1 && k > 0 && db->shards[0].nrows > 0 && !db->shards[0].d_dbg &&
+        !std::getenv("GSIM_FUSED_DEBUG"))
+        return search_each_pipelined(db, db->shards[0], queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
+    for (uint32_t q = 0; q < nq; q++) {
+        const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
+        rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout, &counts[q],
+                        approx ? &approx[q] : nullptr, merged);
+        if (rc != GSIM_OK) return rc;
+    }
+    return GSIM_OK;
+}
+
+int gsim_db_search_each(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+                        float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+{
+    g_force_each = true;
+    const int rc = gsim_db_search(db, queries, nq, k, cutoff, metric, alpha, beta, hits, counts, approx);
+    g_force_each = false;
+    return rc;
+}
+
+int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
+                          float beta, void* d_result)
+{
+    int rc = check_search_args(db, query, metric);
+    if (rc != GSIM_OK) return rc;
+    if (!d_result) return fail(GSIM_ERR_INVALID, "d_result is NULL");
+    if (db->shards.size() != 1) return fail(GSIM_ERR_STATE, "search_device needs a single-shard handle");
+    if (db->fold > 1) return fail(GSIM_ERR_STATE, "search_device does not support folded tables");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    Shard& s = db->shards[0];
+    return enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, db->row_base, d_result, false);
+}
+
+} // extern "C"

@@ -1,5 +1,5 @@
-// gsim_device.h -- launch interface between the C-ABI host code (gsim_capi.cpp)
-// and the gfx950 kernels (gsim_device.hip).  Internal; not part of the ABI.
+// gsim_device.h -- launch interface between the C-ABI host code (capi_*.cpp)
+// and the gfx950 kernels (gsim_*.hip).  Internal; not part of the ABI.
 #pragma once
 
 #include <hip/hip_runtime_api.h>

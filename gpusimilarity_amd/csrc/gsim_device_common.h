@@ -1,4 +1,4 @@
-// gsim_device_common.h -- device helpers shared by the kernels in gsim_device.hip and
+// gsim_device_common.h -- device helpers shared by the kernels in gsim_scan.hip, gsim_fused.hip, gsim_select.hip and
 // gsim_batch.hip: candidate keys, coarse bins, the score arithmetic, wave64 cross-lane
 // helpers, threshold search.  Internal.
 #pragma once

@@ -1,37 +1,5 @@
-// gsim_device.hip -- gfx950 (MI355X / CDNA4) kernels of the fingerprint scan engine.
-//
-// Replaces the Thrust pipeline of the reference's FingerprintDB::search_storage
-// (fingerprintdb_cuda.cu:228-339: sequence / transform(TanimotoFunctor) /
-// remove_if / sort_by_key over ALL rows).  Two routes, same results bit for bit:
-//
-// Single-launch path (fused_kernel; k <= kFusedMaxK = 8192, the usual case): ONE persistent
-//   launch streams the table, keeps candidates in LDS, exchanges per-wave top-M score
-//   summaries to raise a table-wide score threshold, publishes the survivors into
-//   per-workgroup regions and lets every workgroup rank its share of them -- one grid-wide
-//   wait, no histogram, no per-row scratch in global memory.  See the comment above fused_kernel.
-//
-// Four-kernel pipeline (the general route: any k, any width, heavy ties, adversarial
-//   row orders; also what the single launch hands a query back to):
-//   K0 sample_kernel   scores a strided sample, histograms it, publishes a starting
-//                      threshold bin for the scan.
-//   K1 scan_kernel     one streaming pass over the table, 16 B per lane coalesced
-//                      loads (a wave64 load instruction = 1 KiB of consecutive
-//                      rows), AND+v_bcnt_u32_b32 popcounts, DPP reduction across
-//                      the lanes of a row, the reference's f32 divide, cutoff, and
-//                      an in-scan streaming top-k filter: the workgroups share a
-//                      table-wide coarse score histogram (device atomics) and a
-//                      monotone threshold bin derived from it; only rows at or above
-//                      it are written out (candidates, 12 B each, per-wave segments)
-//                      -- no per-row score array exists.
-//   K2 compact_kernel  finds the coarse bin of the k-th best score from the now
-//                      complete histogram and keeps the candidates at or above it.
-//   K3 select_kernel   32 workgroups: every finalist's output slot is its rank (the
-//                      number of larger unique 64-bit keys), counted from LDS; more
-//                      than kSelectCap finalists: one workgroup runs an MSD radix
-//                      select; k > kSelectCap: global-memory bitonic sort.
-//
-// This is HBM-bound bit arithmetic: no MFMA anywhere (the work is AND + popcount,
-// not a contraction).  Wave size is hard-wired to 64.
+// gsim_fused.hip -- the single-launch path: scan, publish, select and the result block in ONE gfx950 kernel
+// (k <= kFusedMaxK on the specialised widths; replaces fingerprintdb_cuda.cu:228-339 for the usual query).
 #include "gsim_device.h"
 
 #include <hip/hip_runtime.h>
@@ -41,403 +9,12 @@
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
-#include "gsim_synth.h"
+#include "gsim_scan_inl.h"
 
 namespace gsim
 {
 namespace
 {
-
-// ---------------------------------------------------------------------------
-// K1: the scan
-// ---------------------------------------------------------------------------
-
-// Streaming top-k filter.
-//
-// Every workgroup keeps, in LDS, a histogram `hist` of the coarse bins of the rows
-// it has EMITTED (written out as candidates).  From time to time a wave pushes the
-// not-yet-pushed part of it into the table-wide histogram `ghist` (global memory,
-// device-scope atomics), re-reads `ghist` and derives a threshold bin: the largest
-// bin B with at least k counted rows at or above it.  The threshold is published
-// with atomicMax (`gtau`) and every wave of every workgroup picks it up on its next
-// chunk.  A row is emitted only if bin(score) >= the wave's current threshold.
-//
-// Why this is exact: `ghist` only ever counts distinct rows of the table that have
-// really been scanned, so "k counted rows at or above B" implies that the table's
-// k-th best score lies in a bin >= B; a row in a lower bin scores strictly less than
-// k other rows and cannot be in the top-k.  Everything is monotone (counts and
-// thresholds only grow), so there are no barriers and no ordering requirements:
-// a stale (lower) threshold only emits more than necessary, a histogram read while
-// others add to it only under-counts.  On a random table the number of emitted rows
-// falls from N to roughly k * ln(N / k) + (#workgroups * first push).
-struct BlockFilter {
-    uint32_t hist[kScanBins];    // rows emitted by this workgroup, per coarse bin
-    uint32_t flushed[kScanBins]; // part of hist already added to ghist
-    uint32_t tau;                // workgroup's copy of the threshold bin (monotone)
-    uint32_t nemit;              // candidates emitted by the workgroup so far
-    uint32_t trigger;            // nemit value at which the next push / re-read happens
-    uint32_t lock;               // one pusher at a time
-    // Per-wave staging of emitted candidates.  Candidates go to LDS (ds_write, lgkmcnt) and
-    // reach global memory in bursts of >= 64: a global store inside the streaming loop would be
-    // waited for by the loop's next s_waitcnt vmcnt(0) (gfx950 has one counter for loads and
-    // stores) -- measured at ~0.36 us per emitting iteration.
-    u64 stage_key[kScanBlock / 64][kStage];
-    uint32_t stage_cb[kScanBlock / 64][kStage];
-};
-
-// first push after this many emitted rows per workgroup (then geometrically)
-constexpr uint32_t kFirstPush = 64;
-
-// Per-wave view of the filter (members wave-uniform except `kept`).
-struct WaveFilter {
-    static constexpr bool kFused = false;
-    __device__ __forceinline__ void checkpoint(uint32_t, int) {}
-    BlockFilter* sh;
-    QueryState* st;
-    u64* seg;         // this wave's private candidate segment (keys)
-    uint32_t* seg_cb; // ... and the popcounts the score came from (common << 16 | popc_db)
-    u64* stg_key;     // this wave's LDS staging area
-    uint32_t* stg_cb;
-    uint32_t k, tau, step, cursor, staged, kept;
-    float cutoff;
-    bool has_cutoff;
-
-    __device__ __forceinline__ void init(BlockFilter* b, QueryState* state, u64* s, uint32_t* scb, uint32_t kk,
-                                         float cut)
-    {
-        sh = b;
-        stg_key = b->stage_key[threadIdx.x >> 6];
-        stg_cb = b->stage_cb[threadIdx.x >> 6];
-        staged = 0;
-        st = state;
-        seg = s;
-        seg_cb = scb;
-        k = kk;
-        cutoff = cut;
-        has_cutoff = cut > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
-        tau = kk ? state->gtau : static_cast<uint32_t>(kScanBins); // gtau: 0, or set by sample_kernel
-#if defined(GSIM_ABLATE) && GSIM_ABLATE >= 11
-        tau = GSIM_FIXED_TAU; // ablations 11-13: fixed threshold bin, no pushes; 14: fixed start, then adaptive
-#endif
-        step = kk / 8 > 32 ? kk / 8 : 32;
-        cursor = 0;
-        kept = 0;
-    }
-
-    // device-coherent read of the table-wide threshold (issued a chunk ahead of its use)
-    __device__ __forceinline__ uint32_t load_gtau() const
-    {
-        return __hip_atomic_load(&st->gtau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    // pick up a threshold raised by another wave (same workgroup: LDS; any workgroup: g)
-    __device__ __forceinline__ void refresh(uint32_t g, int lane)
-    {
-        const uint32_t t = __hip_atomic_load(&sh->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        tau = t > tau ? t : tau;
-        if (g > tau) { // raised by another workgroup: hand it to the other waves of this one through LDS
-            tau = g;
-            if (lane == 0) atomicMax(&sh->tau, g);
-        }
-    }
-
-    // Push this workgroup's new counts into ghist, derive the threshold from ghist.
-    __device__ __forceinline__ void push_and_rethreshold(int lane)
-    {
-        constexpr int PER = kScanBins / 64;
-        uint32_t locked = 0;
-        if (lane == 0) locked = atomicExch(&sh->lock, 1u);
-        locked = __builtin_amdgcn_readfirstlane(locked);
-        if (locked == 0) {
-#pragma unroll
-            for (int i = 0; i < PER; i++) {
-                const uint32_t b = static_cast<uint32_t>(lane * PER + i);
-                const uint32_t h = __hip_atomic_load(&sh->hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint32_t fl = sh->flushed[b];
-                if (b >= tau && h > fl) {
-                    atomicAdd(&st->ghist[b], h - fl);
-                    sh->flushed[b] = h;
-                }
-            }
-            if (lane == 0) __hip_atomic_store(&sh->lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        // threshold from the table-wide histogram: device-coherent (sc1) 16-byte buffer
-        // loads, 4 per lane -- 1024 separate 4-byte sc1 loads cost ~20 us per push
-        uint32_t h[PER];
-        uint32_t s = 0;
-        {
-            const __amdgpu_buffer_rsrc_t rsrc =
-                __builtin_amdgcn_make_buffer_rsrc(st->ghist, 0, kScanBins * 4, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < PER / 4; i++) {
-                const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * PER * 4 + i * 16, 0, /*sc1*/ 16);
-                h[4 * i + 0] = v4.x;
-                h[4 * i + 1] = v4.y;
-                h[4 * i + 2] = v4.z;
-                h[4 * i + 3] = v4.w;
-                s += v4.x + v4.y + v4.z + v4.w;
-            }
-        }
-        uint32_t bin_k, cnt;
-        threshold_from_counts<PER>(h, s, k, lane, bin_k, cnt);
-        if (cnt >= k) {
-            if (lane == 0) {
-                atomicMax(&st->gtau, bin_k);
-                atomicMax(&sh->tau, bin_k);
-            }
-            tau = bin_k > tau ? bin_k : tau;
-        }
-    }
-
-    // staged candidates -> this wave's global segment, coalesced
-    __device__ __forceinline__ void flush_stage(int lane)
-    {
-        for (uint32_t i = lane; i < staged; i += 64) {
-            seg[cursor + i] = stg_key[i];
-            seg_cb[cursor + i] = stg_cb[i];
-        }
-        cursor += staged;
-        staged = 0;
-    }
-
-    // One row per lane (or an inactive lane).
-    __device__ __forceinline__ void offer(bool active, uint32_t row, float raw_score, uint32_t cb, int lane)
-    {
-        const float s = apply_cutoff(raw_score, cutoff);
-        const bool keep = active && (!has_cutoff || s != 0.0f);
-        kept += keep ? 1u : 0u;
-        const uint32_t bin = coarse_bin(s);
-        const bool cand = keep && bin >= tau;
-        const u64 m = __ballot(cand);
-#if defined(GSIM_ABLATE) && GSIM_ABLATE == 4
-        asm volatile("" ::"s"(m)); // ablation 4: the filter's fast path only (no emission code)
-        return;
-#endif
-        if (m != 0) {
-            if (cand) {
-                const uint32_t slot = staged + lane_rank(m);
-                stg_key[slot] = make_key(s, row);
-                stg_cb[slot] = cb;
-#if !(defined(GSIM_ABLATE) && (GSIM_ABLATE == 5 || GSIM_ABLATE == 11))
-                atomicAdd(&sh->hist[bin], 1u); // ds_add_u32
-#endif
-            }
-            const uint32_t n = static_cast<uint32_t>(__popcll(m));
-            staged += n;
-            if (staged > 64) flush_stage(lane);
-#if defined(GSIM_ABLATE) && (GSIM_ABLATE == 5 || GSIM_ABLATE == 6 || GSIM_ABLATE == 11 || GSIM_ABLATE == 12)
-            return;
-#endif
-            uint32_t old = 0;
-            if (lane == 0) old = atomicAdd(&sh->nemit, n);
-            old = __builtin_amdgcn_readfirstlane(old);
-            const uint32_t trig = __hip_atomic_load(&sh->trigger, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#if defined(GSIM_ABLATE) && (GSIM_ABLATE == 7 || GSIM_ABLATE == 13)
-            asm volatile("" ::"s"(old), "s"(trig));
-            return;
-#endif
-            if (old < trig && old + n >= trig) { // exactly one wave crosses a given trigger
-                push_and_rethreshold(lane);
-                if (lane == 0) {
-                    // next push after 50 % more emitted rows (at least `step`): a handful of pushes per
-                    // workgroup and query; the emission rate falls as the threshold rises
-                    const uint32_t now = __hip_atomic_load(&sh->nemit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const uint32_t inc = now / 2 > step ? now / 2 : step;
-                    __hip_atomic_store(&sh->trigger, now + inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-    }
-
-    __device__ __forceinline__ void finish(uint32_t w, const ScanArgs& a, int lane)
-    {
-        if (staged) flush_stage(lane);
-        if (lane == 0) {
-            a.seg_count[w] = cursor;
-            if (cursor) atomicAdd(&a.state->ncand, static_cast<u64>(cursor));
-        }
-        if (has_cutoff) {
-            const uint32_t tot = wave_sum(kept);
-            if (lane == 0 && tot) atomicAdd(&a.state->kept, static_cast<u64>(tot));
-        }
-    }
-};
-
-__device__ __forceinline__ void block_filter_init(BlockFilter* sh, uint32_t k, uint32_t tau0)
-{
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) {
-        sh->hist[i] = 0;
-        sh->flushed[i] = 0;
-    }
-    if (threadIdx.x == 0) {
-        sh->tau = k ? tau0 : static_cast<uint32_t>(kScanBins);
-        sh->nemit = 0;
-        sh->trigger = k ? (k < kFirstPush ? k : kFirstPush) : 0xFFFFFFFFu;
-        sh->lock = 0;
-    }
-    __syncthreads();
-}
-
-// After every wave of the workgroup is done: whatever has not been pushed yet goes
-// into the table-wide histogram, for the bins at or above the final threshold.
-// ghist is then exact for every bin >= the largest threshold any wave used, which is
-// all K2 needs (see compact_kernel).
-__device__ __forceinline__ void block_filter_flush(BlockFilter* sh, const ScanArgs& a)
-{
-    __syncthreads();
-    const uint32_t tau = sh->tau;
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) {
-        const uint32_t h = sh->hist[i], fl = sh->flushed[i];
-        if (static_cast<uint32_t>(i) >= tau && h > fl) atomicAdd(&a.state->ghist[i], h - fl);
-    }
-}
-
-__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
-{
-    // read once: keep it out of the caches' way (+13 % on tables far larger than the caches; default-policy loads
-    // for tables that fit the 256 MB Infinity Cache were tried on repeated queries over 1 M rows: no gain)
-    return __builtin_nontemporal_load(p);
-}
-
-// LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads per lane per chunk.
-// A chunk is CH = U * 64 / LPR consecutive rows = U KiB of the table; wave w takes
-// chunks w, w + nwaves, ...  The loads of the next chunk are issued before the
-// current one is reduced (register double buffer): 2U KiB in flight per wave.
-// The loop body over full chunks is branch-free up to the (rare) emit path, so the
-// compiler's s_waitcnt placement leaves the prefetch in flight during the reduce;
-// the table's last, partial chunk is handled once, outside the loop.
-template <int LPR, int U, bool FULL, typename Filter>
-__device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q, u64 row0, const ScanArgs& a,
-                                             Filter& f, int lane)
-{
-    constexpr int RPL = 64 / LPR;
-    constexpr int ROUNDS = (U + LPR - 1) / LPR;
-    const int sub = lane % LPR;
-    const int grp = lane / LPR;
-#if defined(GSIM_ABLATE) && GSIM_ABLATE == 1
-    // ablation 1: loads only (one XOR per dword keeps them alive)
-    u32x4 x = d[0];
-#pragma unroll
-    for (int j = 1; j < U; j++) x ^= d[j];
-    asm volatile("" ::"v"(x.x ^ x.y ^ x.z ^ x.w ^ q.x));
-    (void) row0; (void) a; (void) f; (void) grp; (void) sub;
-    return;
-#endif
-    uint32_t v[U];
-#pragma unroll
-    for (int j = 0; j < U; j++) {
-        // v_and + v_bcnt_u32_b32 (popcount with accumulate)
-        const uint32_t cc =
-            __popc(d[j].x & q.x) + __popc(d[j].y & q.y) + __popc(d[j].z & q.z) + __popc(d[j].w & q.w);
-        const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
-        v[j] = group_sum<LPR>((cc << 16) + bb); // both sums < 2^16 (fp_bits <= 32768)
-    }
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        // lane (grp, sub) takes the row of load j = r*LPR + sub
-        uint32_t val = 0;
-#pragma unroll
-        for (int jj = 0; jj < U; jj++) {
-            if (jj / LPR == r) val = (sub == jj % LPR) ? v[jj] : val;
-        }
-#if defined(GSIM_ABLATE) && GSIM_ABLATE == 2
-        asm volatile("" ::"v"(val)); // ablation 2: + popcounts and the DPP reduction
-        (void) row0; (void) a; (void) f; (void) grp;
-        continue;
-#endif
-        const int j = r * LPR + sub;
-        const u64 row = row0 + static_cast<u64>(j * RPL + grp);
-        const bool active = (j < U) && (FULL || row < a.nrows);
-        const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
-#if defined(GSIM_ABLATE) && GSIM_ABLATE == 3
-        asm volatile("" ::"v"(s), "v"(active)); // ablation 3: + the score
-        (void) f;
-        continue;
-#endif
-        f.offer(active, static_cast<uint32_t>(row), s, val, lane);
-    }
-}
-
-// The streaming loop of one wavefront: chunks w, w + nwaves, ... of the table through filter f.
-template <int LPR, int U, typename Filter>
-__device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry& g, Filter& f, const u32x4& q, uint32_t w,
-                                          int lane)
-{
-    constexpr int RPL = 64 / LPR; // rows per load instruction
-    constexpr int CH = U * RPL;   // rows per chunk
-    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
-    uint32_t gt = 0; // table-wide threshold, loaded ahead of its use
-    uint32_t trip = 0;
-    const uint32_t wib = w % (kScanBlock / 64);
-
-    const u64 nfull = a.nrows / CH; // chunks with all CH rows present
-    if (w < nfull) {
-        const u64 last = w + (nfull - 1 - w) / g.nwaves * g.nwaves; // this wave's last full chunk
-        u32x4 nxt[U];
-        {
-            const u32x4* p = db + static_cast<u64>(w) * (CH * LPR) + lane;
-#pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
-        }
-        for (u64 c = w;; c += g.nwaves) {
-            u32x4 d[U];
-#pragma unroll
-            for (int j = 0; j < U; j++) d[j] = nxt[j];
-            // prefetch; on the final trip it re-reads the last chunk (no branch in the body)
-            const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last;
-            const u32x4* p = db + cn * (CH * LPR) + lane;
-#pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
-            f.refresh(gt, lane);
-            // The workgroup polls the table-wide threshold every 8th chunk while it moves fast
-            // (first 64 chunks), then every 32nd, then every 128th; the waves take turns so that
-            // no single wave pays for all polls.  A poll is one more entry in the loop's vmcnt
-            // queue: its latency is exposed whenever it exceeds the prefetch's (~1 us each).
-            // (Single-launch path: every chunk of the first 32, in turns -- a small table is over
-            // after 16 trips and its first threshold arrives around the 10th.)
-            {
-                const uint32_t period = (Filter::kFused && trip < 32u) ? 1u : (trip < 64u ? 8u : (trip < 512u ? 32u : 128u));
-                if ((trip & (period - 1u)) == 0 && ((trip / period) & (kScanBlock / 64 - 1)) == wib) gt = f.load_gtau();
-                trip++;
-            }
-            reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
-            if (Filter::kFused) f.checkpoint(trip, lane);
-            if (c == last) break;
-        }
-    }
-    if (nfull < g.nchunks && w == nfull % g.nwaves) { // the table's partial last chunk
-        const u64 row0 = nfull * CH;
-        const u32x4* p = db + row0 * LPR + lane;
-        const int grp = lane / LPR;
-        u32x4 d[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-            const u64 row = row0 + static_cast<u64>(j * RPL + grp);
-            d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
-        }
-        f.refresh(f.load_gtau(), lane);
-        reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
-    }
-}
-
-template <int LPR, int U> __global__ __launch_bounds__(kScanBlock) void scan_kernel(ScanArgs a, ScanGeometry g)
-{
-    __shared__ BlockFilter s_filter;
-    if (a.gate && *a.gate == 0) return; // enqueued as the fallback of the single-launch path, which succeeded
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    block_filter_init(&s_filter, a.k, a.state->gtau);
-
-    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
-    if (w == 0 && lane < LPR && a.query_dev != a.query) reinterpret_cast<u32x4*>(a.query_dev)[lane] = q;
-
-    WaveFilter f;
-    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
-           a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
-    scan_rows<LPR, U>(a, g, f, q, w, lane);
-    f.finish(w, a, lane);
-    block_filter_flush(&s_filter, a);
-}
 
 // ---------------------------------------------------------------------------
 // The single-launch path: scan, publish, select and the result block in ONE kernel
@@ -1663,988 +1240,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
 #undef GSIM_STAMP
 }
 
-// K0 sample_kernel: a valid starting threshold for the scan.
-//
-// The scan's filter starts from "emit everything" and needs a few exchanges through
-// the table-wide histogram before it prunes; with every workgroup in that state at
-// once, the start-up costs ~60 us.  This kernel scores a strided sample of the table
-// (nsample chunks, evenly spaced), histograms ALL sampled rows (no emission), and its
-// last workgroup publishes tau0 = the largest bin with >= k sampled rows at or above
-// it.  The sample is a subset of the table, so tau0 is a valid lower bound of the
-// table's k-th best bin.  The histogram is zeroed again: the scan re-reads the
-// sampled rows (<0.3 % extra traffic) and counts them itself.
-struct SampleFilter {
-    uint32_t* hist; // workgroup's LDS histogram
-    float cutoff;
-    bool has_cutoff;
-    __device__ __forceinline__ void offer(bool active, uint32_t, float raw_score, uint32_t, int)
-    {
-        const float s = apply_cutoff(raw_score, cutoff);
-        if (active && (!has_cutoff || s != 0.0f)) atomicAdd(&hist[coarse_bin(s)], 1u);
-    }
-};
-
-// The end of a sample kernel: the workgroup's histogram into the table-wide one; the last workgroup turns that into
-// tau0 and clears it.
-__device__ __forceinline__ void sample_publish(const ScanArgs& a, uint32_t* s_hist, uint32_t& s_last, int lane)
-{
-    __syncthreads();
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock)
-        if (s_hist[i]) atomicAdd(&a.state->ghist[i], s_hist[i]);
-    // ticket: the last workgroup turns the histogram into tau0 and clears it
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&a.state->done, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x < 64) {
-        constexpr int PER = kScanBins / 64;
-        uint32_t h[PER];
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            h[i] = __hip_atomic_load(&a.state->ghist[lane * PER + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s += h[i];
-        }
-        uint32_t bin_k, cnt;
-        threshold_from_counts<PER>(h, s, a.k, lane, bin_k, cnt);
-        if (lane == 0) {
-            a.state->gtau = (a.k && cnt >= a.k) ? bin_k : 0u;
-            a.state->done = 0;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) a.state->ghist[i] = 0;
-}
-
-template <int LPR, int U>
-__global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t nsample, u64 stride_chunks)
-{
-    __shared__ uint32_t s_hist[kScanBins];
-    __shared__ uint32_t s_last;
-    if (a.gate && *a.gate == 0) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
-    __syncthreads();
-    constexpr int CH = U * (64 / LPR);
-    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
-    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
-    SampleFilter f;
-    f.hist = s_hist;
-    f.cutoff = a.cutoff;
-    f.has_cutoff = a.cutoff > 0.0f;
-    const uint32_t nw = gridDim.x * (kScanBlock / 64);
-    for (uint32_t i = w; i < nsample; i += nw) {
-        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
-        const u32x4* p = db + c * (CH * LPR) + lane;
-        u32x4 d[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) d[j] = p[j * 64]; // plain loads: the scan re-reads these lines
-        reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
-    }
-    sample_publish(a, s_hist, s_last, lane);
-}
-
-// Any fingerprint width (W words, not a power-of-two number of 16-byte lanes).  The R rows of a wave's chunk
-// (ScanGeometry::chunk_rows: 64, fewer for very wide rows) are R W consecutive words, a multiple of 16 bytes at a
-// 16-byte boundary: the wave copies them verbatim into its LDS region with 16-byte global_load_lds (no registers, one
-// address computation per 16 bytes), then every lane reads back ITS row -- 16 bytes per read when the rows are
-// 16-byte multiples.  (One row per lane straight from global memory -- the reference's access pattern,
-// fingerprintdb_cuda.cu:98 -- touches 64 different 128-byte lines per load instruction: 0.18-0.32 of the HBM peak.)
-constexpr uint32_t kGenericLdsBytes = 96 * 1024; // dynamic LDS: the query + four wave regions
-
-__host__ __device__ inline uint32_t generic_query_words(uint32_t W) { return (W + 3u) & ~3u; }
-__host__ __device__ inline uint32_t generic_lds_bytes(uint32_t W, uint32_t R) { return (generic_query_words(W) + (kScanBlock / 64) * R * W) * 4u; }
-
-struct GenericChunk {
-    const uint32_t* db;
-    uint32_t* srow;       // this wave's LDS region: R x W words
-    const uint32_t* sq;   // the query in LDS
-    uint32_t W, R;
-    u64 total_words;
-
-    __device__ __forceinline__ void init(const ScanArgs& a, uint32_t R_, uint32_t* s_words, uint32_t wv)
-    {
-        db = reinterpret_cast<const uint32_t*>(a.rows);
-        W = a.W, R = R_;
-        sq = s_words;
-        srow = s_words + generic_query_words(W) + wv * R * W;
-        total_words = a.nrows * W;
-        for (uint32_t i = threadIdx.x; i < W; i += kScanBlock) s_words[i] = a.query[i]; // (a workgroup barrier follows in the caller)
-    }
-    // chunk c -> LDS; returns when it is there
-    __device__ __forceinline__ void load(u64 c, int lane) const
-    {
-        const uint32_t units = R * W / 4u; // 16-byte units per chunk
-        const u64 base = c * (static_cast<u64>(R) * W);
-        for (uint32_t u0 = 0; u0 < units; u0 += 64u) {
-            const uint32_t u = u0 + static_cast<uint32_t>(lane);
-            const u64 gi = base + 4ull * u;
-            if (u < units && gi + 4u <= total_words) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (db + gi),
-                                                 (__attribute__((address_space(3))) void*) (srow + 4u * u0), 16, 0, 0);
-            } else if (u < units) { // the table's last words (and what lies behind them in the last chunk)
-#pragma unroll
-                for (uint32_t t = 0; t < 4; t++) srow[4u * u + t] = gi + t < total_words ? db[gi + t] : 0u;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the words are in LDS
-        __builtin_amdgcn_wave_barrier();
-    }
-    // popc(row & query), popc(row) of this lane's row of the chunk in LDS
-    __device__ __forceinline__ void count(int lane, uint32_t& cc, uint32_t& bb) const
-    {
-        const uint32_t* mine = srow + (static_cast<uint32_t>(lane) < R ? static_cast<uint32_t>(lane) : 0u) * W;
-        cc = 0, bb = 0;
-        if (W % 4u == 0) { // rows are 16-byte multiples: ds_read_b128
-            const u32x4* m4 = reinterpret_cast<const u32x4*>(mine);
-            const u32x4* q4 = reinterpret_cast<const u32x4*>(sq);
-            for (uint32_t j = 0; j < W / 4u; j++) {
-                const u32x4 x = m4[j], q = q4[j];
-                cc = bcnt_acc(x.x & q.x, bcnt_acc(x.y & q.y, bcnt_acc(x.z & q.z, bcnt_acc(x.w & q.w, cc))));
-                bb = bcnt_acc(x.x, bcnt_acc(x.y, bcnt_acc(x.z, bcnt_acc(x.w, bb))));
-            }
-        } else {
-            uint32_t j = 0;
-            for (; j + 4 <= W; j += 4) {
-                uint32_t xr[4], qr[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    xr[u] = mine[j + u];
-                    qr[u] = sq[j + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    cc = bcnt_acc(xr[u] & qr[u], cc);
-                    bb = bcnt_acc(xr[u], bb);
-                }
-            }
-            for (; j < W; j++) {
-                const uint32_t xr = mine[j];
-                cc = bcnt_acc(xr & sq[j], cc);
-                bb = bcnt_acc(xr, bb);
-            }
-        }
-        __builtin_amdgcn_wave_barrier(); // the next chunk's words overwrite the region
-    }
-};
-
-__global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, ScanGeometry g)
-{
-    __shared__ BlockFilter s_filter;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[]; // [query, padded to 4 words][4 waves x R rows x W words]
-    if (a.gate && *a.gate == 0) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t w = blockIdx.x * (kScanBlock / 64) + wv;
-    GenericChunk ch;
-    ch.init(a, g.chunk_rows, s_words, wv);
-    block_filter_init(&s_filter, a.k, a.state->gtau); // (ends with a workgroup barrier: the query is in place)
-    WaveFilter f;
-    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
-           a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
-    for (u64 c = w; c < g.nchunks; c += g.nwaves) {
-        ch.load(c, lane);
-        uint32_t cc, bb;
-        ch.count(lane, cc, bb);
-        const u64 row = c * ch.R + lane;
-        const bool active = static_cast<uint32_t>(lane) < ch.R && row < a.nrows;
-        f.refresh((c / g.nwaves) % 8 == 0 ? f.load_gtau() : 0u, lane);
-        const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc);
-        f.offer(active, static_cast<uint32_t>(row), s, (cc << 16) + bb, lane);
-    }
-    f.finish(w, a, lane);
-    block_filter_flush(&s_filter, a);
-}
-
-// K0 for the generic widths: as sample_kernel, chunks through GenericChunk
-__global__ __launch_bounds__(kScanBlock) void sample_generic_kernel(ScanArgs a, uint32_t R, uint32_t nsample, u64 stride_chunks)
-{
-    __shared__ uint32_t s_hist[kScanBins];
-    __shared__ uint32_t s_last;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];
-    if (a.gate && *a.gate == 0) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t w = blockIdx.x * (kScanBlock / 64) + wv;
-    GenericChunk ch;
-    ch.init(a, R, s_words, wv);
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
-    __syncthreads();
-    SampleFilter f;
-    f.hist = s_hist;
-    f.cutoff = a.cutoff;
-    f.has_cutoff = a.cutoff > 0.0f;
-    const uint32_t nw = gridDim.x * (kScanBlock / 64);
-    for (uint32_t i = w; i < nsample; i += nw) {
-        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
-        ch.load(c, lane);
-        uint32_t cc, bb;
-        ch.count(lane, cc, bb);
-        f.offer(static_cast<uint32_t>(lane) < R, 0u, score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc), 0u, lane);
-    }
-    sample_publish(a, s_hist, s_last, lane);
-}
-
-// ---------------------------------------------------------------------------
-// K2: compaction at the k-th best coarse bin
-// ---------------------------------------------------------------------------
-//
-// After the scan, ghist[b] is the exact number of table rows in bin b for every
-// b >= T, T = the largest threshold any wave used, and an under-count below T.  The
-// table's k-th best bin B* is >= T (every threshold is a lower bound for it), so the
-// largest B with sum_{b>=B} ghist[b] >= k is exactly B*; every top-k row has
-// bin >= B* >= the threshold its wave compared it with and was therefore emitted.
-constexpr int kCompactStage = 1024; // finalists staged in LDS per workgroup
-
-// One wavefront per candidate segment, several loads in flight per lane.  The
-// survivors of a workgroup are staged in LDS and appended to `finalists` with ONE
-// global atomic per workgroup (a single hot word only sustains ~90 returning
-// atomics per microsecond); entries beyond the staging area (heavy ties) are
-// appended directly.
-__global__ __launch_bounds__(kScanBlock) void compact_kernel(ScanArgs a, ScanGeometry g, u64* finalists,
-                                                             uint32_t* finalists_cb, uint32_t cap)
-{
-    __shared__ u64 s_stage[kCompactStage];
-    __shared__ uint32_t s_stage_cb[kCompactStage];
-    __shared__ uint32_t s_n, s_base;
-    if (a.gate && *a.gate == 0) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint32_t n = a.k ? a.seg_count[w] : 0;
-    if (n != 0) {
-        uint32_t bstar, cnt;
-        find_threshold(a.state->ghist, a.k, lane, bstar, cnt);
-        const u64* seg = a.cand + static_cast<u64>(w) * g.seg_cap;
-        const uint32_t* seg_cb = a.cand_cb + static_cast<u64>(w) * g.seg_cap;
-        constexpr int UN = 4; // independent loads in flight per lane
-        constexpr uint32_t STAGE = kCompactStage;
-        for (uint32_t base = 0; base < n; base += 64 * UN) {
-            u64 key[UN];
-            uint32_t cb[UN];
-#pragma unroll
-            for (int u = 0; u < UN; u++) {
-                const uint32_t i = base + u * 64 + lane;
-                key[u] = i < n ? seg[i] : 0ull;
-                cb[u] = i < n ? seg_cb[i] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; u++) {
-                const uint32_t i = base + u * 64 + lane;
-                const bool ok = i < n && coarse_bin(key_score(static_cast<uint32_t>(key[u] >> 32))) >= bstar;
-                const u64 m = __ballot(ok);
-                if (m != 0) {
-                    const uint32_t cntw = static_cast<uint32_t>(__popcll(m));
-                    uint32_t pos = 0;
-                    if (lane == 0) pos = atomicAdd(&s_n, cntw);
-                    pos = __builtin_amdgcn_readfirstlane(pos);
-                    const uint32_t e = pos + lane_rank(m); // slot in the workgroup's reservation order
-                    if (pos + cntw <= STAGE) {
-                        if (ok) {
-                            s_stage[e] = key[u];
-                            s_stage_cb[e] = cb[u];
-                        }
-                    } else {
-                        const uint32_t first_over = pos > STAGE ? pos : STAGE;
-                        uint32_t gpos = 0;
-                        if (lane == 0) gpos = atomicAdd(&a.state->nfinal, pos + cntw - first_over);
-                        gpos = __builtin_amdgcn_readfirstlane(gpos);
-                        if (ok) {
-                            if (e < STAGE) {
-                                s_stage[e] = key[u];
-                                s_stage_cb[e] = cb[u];
-                            } else {
-                                const uint32_t idx = gpos + (e - first_over);
-                                if (idx < cap) {
-                                    finalists[idx] = key[u];
-                                    finalists_cb[idx] = cb[u];
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t reserved = s_n;
-    const uint32_t staged = reserved < static_cast<uint32_t>(kCompactStage) ? reserved
-                                                                             : static_cast<uint32_t>(kCompactStage);
-    if (staged == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&a.state->nfinal, staged);
-    __syncthreads();
-    const uint32_t gbase = s_base;
-    for (uint32_t i = threadIdx.x; i < staged; i += kScanBlock) {
-        if (gbase + i < cap) {
-            finalists[gbase + i] = s_stage[i];
-            finalists_cb[gbase + i] = s_stage_cb[i];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K3: exact select + sort of the finalists, result emission
-// ---------------------------------------------------------------------------
-
-__device__ __forceinline__ void emit_hit(const ScanArgs& a, u64 key, uint32_t row_base, gsim_hit* out)
-{
-    const uint32_t row = ~static_cast<uint32_t>(key);
-    const float s = key_score(static_cast<uint32_t>(key >> 32));
-    const uint32_t* r = reinterpret_cast<const uint32_t*>(a.rows) + static_cast<u64>(row) * a.W;
-    uint32_t cc = 0, bb = 0;
-    if ((a.W & 3u) == 0) { // 16-byte loads, all issued before the first use
-        const uint4* r4 = reinterpret_cast<const uint4*>(r);
-        const uint4* q4 = reinterpret_cast<const uint4*>(a.query_dev);
-        const uint32_t n4 = a.W >> 2;
-#pragma unroll 8
-        for (uint32_t i = 0; i < n4; i++) {
-            const uint4 x = r4[i], y = q4[i];
-            cc += __popc(x.x & y.x) + __popc(x.y & y.y) + __popc(x.z & y.z) + __popc(x.w & y.w);
-            bb += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
-        }
-    } else {
-        for (uint32_t i = 0; i < a.W; i++) {
-            const uint32_t x = r[i];
-            cc += __popc(x & a.query_dev[i]);
-            bb += __popc(x);
-        }
-    }
-    gsim_hit h;
-    h.row = row + row_base;
-    h.score = s;
-    h.common = static_cast<uint16_t>(cc);
-    h.popc_db = static_cast<uint16_t>(bb);
-    *out = h;
-}
-
-__device__ __forceinline__ u64 approx_count(const ScanArgs& a)
-{
-    // fingerprintdb_cuda.cu:263-277: survivors when cutoff > 0, else all rows
-    return a.cutoff > 0.0f ? a.state->kept : a.nrows;
-}
-
-constexpr int kSelectThreads = 256;
-constexpr int kSelectBlocks = kSelectCap / kSelectThreads;
-
-// keys[0..n) in LDS, n a power of two: bitonic sort, descending.
-__device__ __forceinline__ void bitonic_desc_lds(u64* keys, uint32_t n, int tid, int nthreads)
-{
-    for (uint32_t size = 2; size <= n; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (uint32_t t = tid; t < n / 2; t += nthreads) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const u64 x = keys[lo], y = keys[hi];
-                if ((x < y) == desc) {
-                    keys[lo] = y;
-                    keys[hi] = x;
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// Dynamic LDS layout of select_kernel: kSelectCap keys, then a 256-bin digit
-// histogram and control words (heavy-tie path only).
-constexpr size_t kSelectLds = static_cast<size_t>(kSelectCap) * sizeof(u64) + 256 * sizeof(uint32_t) + 16;
-
-// Heavy ties (more than kSelectCap finalists): one workgroup runs an MSD radix
-// select over the unique 64-bit keys to find the k-th largest key T, gathers the
-// exactly-k keys >= T into LDS, sorts them and re-derives the popcounts from the
-// table.  k <= kSelectCap.
-__device__ void select_heavy(const ScanArgs& a, const u64* finalists, uint32_t m2, uint32_t row_base, u64* keys,
-                             uint32_t* dhist, uint32_t* ctl, gsim_result_header* hdr, gsim_hit* hits)
-{
-    const int tid = threadIdx.x;
-    u64 prefix = 0;
-    if (tid == 0) ctl[1] = a.k;
-    for (int pass = 0; pass < 8; pass++) {
-        const int shift = 56 - 8 * pass;
-        dhist[tid] = 0; // kSelectThreads == 256 bins
-        __syncthreads();
-        for (uint32_t i = tid; i < m2; i += kSelectThreads) {
-            const u64 key = finalists[i];
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&dhist[(key >> shift) & 0xFF], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t remaining = ctl[1], acc = 0;
-            int d = 255;
-            for (; d > 0; d--) {
-                if (acc + dhist[d] >= remaining) break;
-                acc += dhist[d];
-            }
-            ctl[0] = static_cast<uint32_t>(d);
-            ctl[1] = remaining - acc;
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | ctl[0];
-        __syncthreads();
-    }
-    // prefix is the k-th largest key; keys are unique -> exactly k keys >= it
-    if (tid == 0) ctl[2] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < m2; i += kSelectThreads) {
-        const u64 key = finalists[i];
-        if (key >= prefix) {
-            const uint32_t pos = atomicAdd(&ctl[2], 1u);
-            if (pos < static_cast<uint32_t>(kSelectCap)) keys[pos] = key;
-        }
-    }
-    __syncthreads();
-    const uint32_t nsel = ctl[2] < static_cast<uint32_t>(kSelectCap) ? ctl[2] : static_cast<uint32_t>(kSelectCap);
-    uint32_t n = 1;
-    while (n < nsel) n <<= 1;
-    for (uint32_t i = nsel + tid; i < n; i += kSelectThreads) keys[i] = 0ull;
-    bitonic_desc_lds(keys, n, tid, kSelectThreads);
-    const uint32_t nout = nsel < a.k ? nsel : a.k;
-    for (uint32_t i = tid; i < nout; i += kSelectThreads) emit_hit(a, keys[i], row_base, hits + i);
-    if (tid == 0) {
-        hdr->count = nout;
-        hdr->flags = 1u;
-        hdr->approx = approx_count(a);
-    }
-}
-
-// K3.  kSelectBlocks workgroups.  Usual case (finalists <= kSelectCap): every
-// finalist's output position is its rank = the number of finalists with a larger
-// key (keys are unique); each workgroup holds all keys in LDS and ranks 256 of
-// them by a broadcast-read counting loop -- no sort, no data movement, the hit
-// (row, score, common, popc_db) goes straight from registers to its slot.  The
-// result block may live in device memory or in pinned host memory (zero-copy).
-// The last workgroup to finish folds the query's counters into the running
-// totals and re-zeroes the per-query state for the next query.
-__global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, const u64* finalists,
-                                                                const uint32_t* finalists_cb, uint32_t cap,
-                                                                uint32_t row_base, void* d_result)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
-    uint32_t* dhist = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kSelectCap) * sizeof(u64));
-    uint32_t* ctl = dhist + 256; // [0] digit, [1] remaining, [2] gather cursor, [3] last-workgroup flag
-    const int tid = threadIdx.x;
-    if (a.gate && *a.gate == 0) return; // every workgroup reads the gate before the last one can clear it (ticket below)
-    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
-    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
-    uint32_t m2 = a.k ? a.state->nfinal : 0;
-    if (m2 > cap) m2 = cap; // cannot happen: cap covers every candidate slot
-    if (m2 <= static_cast<uint32_t>(kSelectCap)) {
-        const uint32_t first = blockIdx.x * kSelectThreads;
-        if (first < m2) {
-            const uint32_t npad = (m2 + 1u) & ~1u;
-            for (uint32_t i = tid; i < npad; i += kSelectThreads) keys[i] = i < m2 ? finalists[i] : 0ull;
-            __syncthreads();
-            const uint32_t i = first + tid;
-            if (i < m2) {
-                const u64 mine = keys[i];
-                const uint32_t cb = finalists_cb[i]; // issued before the counting loop
-                uint32_t rank = 0;
-                const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);
-#pragma unroll 4
-                for (uint32_t j = 0; j < npad / 2; j++) { // ds_read_b128 broadcast: two keys per read
-                    const ulonglong2 kk = k2[j];
-                    rank += (kk.x > mine) ? 1u : 0u;
-                    rank += (kk.y > mine) ? 1u : 0u;
-                }
-                if (rank < a.k) {
-                    gsim_hit h;
-                    h.row = ~static_cast<uint32_t>(mine) + row_base;
-                    h.score = key_score(static_cast<uint32_t>(mine >> 32));
-                    h.common = static_cast<uint16_t>(cb >> 16);
-                    h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
-                    hits[rank] = h;
-                }
-            }
-        }
-        if (blockIdx.x == 0 && tid == 0) {
-            hdr->count = m2 < a.k ? m2 : a.k;
-            hdr->flags = 0;
-            hdr->approx = approx_count(a);
-        }
-    } else if (blockIdx.x == 0) {
-        select_heavy(a, finalists, m2, row_base, keys, dhist, ctl, hdr, hits);
-    }
-    // ticket: the last workgroup resets the state (all others are done reading it)
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) ctl[3] = (atomicAdd(&a.state->done, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (ctl[3]) {
-        if (tid == 0) {
-            a.state->ncand_sum += a.state->ncand;
-            a.state->nfinal_sum += a.state->nfinal;
-            a.state->queries += 1;
-            a.state->kept = 0;
-            a.state->ncand = 0;
-            a.state->nfinal = 0;
-            a.state->done = 0;
-            a.state->gtau = 0;
-            a.state->redo = 0;
-        }
-        for (int i = tid; i < kScanBins; i += kSelectThreads) a.state->ghist[i] = 0;
-    }
-}
-
-__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeKState* lk)
-{
-    if (threadIdx.x == 0 && lk) {
-        lk->prefix = 0;
-        lk->remaining = 0;
-        lk->ticket = 0;
-        lk->count = 0;
-        lk->all = 0;
-    }
-    if (threadIdx.x == 0) {
-        st->ncand_sum += st->ncand;
-        st->nfinal_sum += st->nfinal;
-        st->queries += 1;
-        st->kept = 0;
-        st->ncand = 0;
-        st->nfinal = 0;
-        st->done = 0;
-        st->gtau = 0;
-        st->redo = 0;
-    }
-    for (int i = threadIdx.x; i < kScanBins; i += 256) st->ghist[i] = 0;
-}
-
-// ---------------------------------------------------------------------------
-// large-k path (k > kSelectCap): bitonic sort of ALL finalists in global memory
-// (multi-launch), then emission of the first k.  Exact for any input.
-// ---------------------------------------------------------------------------
-
-// The k-th largest finalist key by an MSD radix descent, one launch per byte, the finalist count read ON THE DEVICE:
-// nothing of the large-k path is sized by the host from a value it would have to wait for.  Pass p histograms byte
-// (7 - p) of the keys that match the prefix found so far (LDS histogram per workgroup, one global atomic per non-empty
-// bin); the last workgroup (ticket) picks the digit that holds the wanted rank, extends the prefix and clears the
-// histogram.  Fewer finalists than k: `all` is set and every finalist is taken.
-__global__ __launch_bounds__(256) void largek_pass_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, int pass)
-{
-    __shared__ uint32_t s_h[256];
-    __shared__ uint32_t s_last;
-    const int tid = threadIdx.x;
-    uint32_t nfinal = a.state->nfinal;
-    if (nfinal > cap) nfinal = cap;
-    if (pass > 0 && lk->all) return;
-    const int shift = 56 - 8 * pass;
-    const u64 prefix = lk->prefix;
-    const uint32_t want = pass == 0 ? a.k : lk->remaining;
-    s_h[tid] = 0;
-    __syncthreads();
-    for (uint32_t i = blockIdx.x * 256 + tid; i < nfinal; i += gridDim.x * 256) {
-        const u64 key = finalists[i];
-        if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_h[(key >> shift) & 0xFFu], 1u);
-    }
-    __syncthreads();
-    if (s_h[tid]) atomicAdd(&lk->hist[tid], s_h[tid]);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&lk->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (tid < 64) {
-        uint32_t h[4];
-        uint32_t s4 = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            h[i] = __hip_atomic_load(&lk->hist[tid * 4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s4 += h[i];
-        }
-        uint32_t bin, cnt;
-        threshold_from_counts<4>(h, s4, want, tid, bin, cnt);
-        if (tid == 0) {
-            if (cnt < want) { // (pass 0 only: fewer finalists than k)
-                lk->all = 1;
-                lk->prefix = 0;
-            } else {
-                const uint32_t pop = __hip_atomic_load(&lk->hist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lk->prefix = (prefix << 8) | bin;
-                lk->remaining = want - (cnt - pop);
-            }
-            lk->ticket = 0;
-        }
-    }
-    __syncthreads();
-    lk->hist[tid] = 0;
-}
-
-// the keys at or above the k-th largest (exactly min(k, #finalists) of them: keys are unique) -> out[0 ..)
-__global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, u64* out,
-                                                            uint32_t out_cap)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t nfinal = a.state->nfinal;
-    if (nfinal > cap) nfinal = cap;
-    const u64 kth = lk->all ? 0ull : lk->prefix;
-    const uint32_t n64 = (nfinal + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n64; i += gridDim.x * 256) {
-        const u64 key = i < nfinal ? finalists[i] : 0ull;
-        const bool take = i < nfinal && key >= kth;
-        const u64 m = __ballot(take);
-        if (m == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&lk->count, static_cast<uint32_t>(__popcll(m)));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const uint32_t pos = base + lane_rank(m);
-        if (take && pos < out_cap) out[pos] = key;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// folded tables: the candidates' re-score with the full fingerprints, on the device
-// ---------------------------------------------------------------------------
-// fingerprintdb_cuda.cu:307-331: the R = k F (int)log2(2F) best FOLDED scores of a storage are re-scored with the full
-// fingerprints (tanimoto_similarity_cpu, :387-399), stably sorted by the new score (top_results_bubble_sort: strict '>',
-// so ties keep the order of the folded list) and the first min(k, R) kept up to the first one below the cutoff.  The
-// reference does this on the host (slide 19 lists it as future GPU work); here the full rows are resident as well
-// (288 GB hold both) and three small launches do it: re-score into keys (score key << 32 | ~position), a bitonic sort
-// of the <= 64 Ki keys, emission.  A NaN score (0 / 0: two empty fingerprints) is not ordered by '>': it raises a flag
-// and the host path, which has the literal bubble sort for that case, answers the query.
-__global__ __launch_bounds__(256) void fold_rescore_kernel(const void* folded_block, const uint32_t* full_rows, const uint32_t* full_query,
-                                                           uint32_t W, uint32_t qpop, u64* keys, uint32_t* cbs, uint32_t npad,
-                                                           uint32_t* nan_flag)
-{
-    const gsim_result_header* hdr = reinterpret_cast<const gsim_result_header*>(folded_block);
-    const gsim_hit* cand = reinterpret_cast<const gsim_hit*>(hdr + 1);
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= npad) return;
-    if (j >= hdr->count) {
-        keys[j] = 0ull; // padding of the sort: below every real key
-        return;
-    }
-    const uint32_t* r = full_rows + static_cast<u64>(cand[j].row) * W;
-    uint32_t cc = 0, bb = 0;
-    for (uint32_t i = 0; i < W; i++) {
-        const uint32_t x = r[i];
-        cc += __popc(x & full_query[i]);
-        bb += __popc(x);
-    }
-    const float s = score_of(GSIM_METRIC_TANIMOTO, 0.f, 0.f, qpop, bb, cc);
-    if (s != s) atomicOr(nan_flag, 1u);
-    keys[j] = (static_cast<u64>(order_key(s)) << 32) | static_cast<u64>(~j);
-    cbs[j] = (cc << 16) | bb;
-}
-
-__global__ __launch_bounds__(256) void fold_emit_kernel(const void* folded_block, const u64* sorted_keys, const uint32_t* cbs, uint32_t k,
-                                                        float cutoff, uint32_t row_base, void* out_block)
-{
-    const gsim_result_header* fh = reinterpret_cast<const gsim_result_header*>(folded_block);
-    const gsim_hit* cand = reinterpret_cast<const gsim_hit*>(fh + 1);
-    gsim_result_header* oh = reinterpret_cast<gsim_result_header*>(out_block);
-    gsim_hit* out = reinterpret_cast<gsim_hit*>(oh + 1);
-    const uint32_t keep = fh->count < k ? fh->count : k;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    // the list is in descending score order: "up to the first one below the cutoff" = the entries at or above it
-    if (i < keep) {
-        const u64 key = sorted_keys[i];
-        const float s = key_score(static_cast<uint32_t>(key >> 32));
-        if (!(s < cutoff)) {
-            const uint32_t j = ~static_cast<uint32_t>(key);
-            const uint32_t cb = cbs[j];
-            gsim_hit h;
-            h.row = cand[j].row + row_base;
-            h.score = s;
-            h.common = static_cast<uint16_t>(cb >> 16);
-            h.popc_db = static_cast<uint16_t>(cb & 0xFFFFu);
-            out[i] = h;
-        }
-    }
-    if (i == 0) { // the count: how many of the first `keep` are at or above the cutoff (they form a prefix)
-        uint32_t lo = 0, hi = keep;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (!(key_score(static_cast<uint32_t>(sorted_keys[mid] >> 32)) < cutoff)) lo = mid + 1;
-            else hi = mid;
-        }
-        oh->count = lo;
-        oh->flags = fh->flags;
-        oh->approx = fh->approx;
-    }
-}
-
-__global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64 to)
-{
-    const u64 i = from + static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < to) keys[i] = 0;
-}
-
-__global__ __launch_bounds__(256) void bitonic_step_kernel(u64* keys, uint32_t n, uint32_t size, uint32_t stride)
-{
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n / 2) return;
-    const uint32_t lo = 2 * t - (t & (stride - 1));
-    const uint32_t hi = lo + stride;
-    const bool desc = (lo & size) == 0;
-    const u64 x = keys[lo], y = keys[hi];
-    if ((x < y) == desc) {
-        keys[lo] = y;
-        keys[hi] = x;
-    }
-}
-
-__global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, const LargeKState* lk,
-                                                        uint32_t row_base, u64 approx_if_no_cutoff, uint32_t flags,
-                                                        void* d_result)
-{
-    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
-    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
-    const uint32_t nkeys = lk->count < a.k ? lk->count : a.k;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nkeys) emit_hit(a, sorted_keys[i], row_base, hits + i);
-    if (i == 0) {
-        hdr->count = nkeys;
-        hdr->flags = flags;
-        hdr->approx = a.cutoff > 0.0f ? a.state->kept : approx_if_no_cutoff;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// merge of per-shard result blocks (fingerprintdb_cuda.cu:363-380)
-// ---------------------------------------------------------------------------
-
-__device__ __forceinline__ const gsim_result_header* block_hdr(const void* blocks, size_t block_bytes, uint32_t i)
-{
-    return reinterpret_cast<const gsim_result_header*>(reinterpret_cast<const unsigned char*>(blocks) +
-                                                       static_cast<size_t>(i) * block_bytes);
-}
-
-// Every list is in canonical order and keys are unique across lists, so the
-// output position of an element is the number of elements that precede it:
-// its own index plus, for every other list, a binary search.
-// blockIdx.y = query: its lists are the blocks q, q + nq, q + 2 nq, ... of the gathered buffer
-// (rank-major, as an all-gather of per-rank [nq] block arrays leaves them).
-__global__ __launch_bounds__(256) void merge_kernel(const void* all_blocks, uint32_t nblocks, uint32_t nq,
-                                                    size_t block_bytes, uint32_t k, void* d_results)
-{
-    const uint32_t q = blockIdx.y;
-    const void* blocks = static_cast<const unsigned char*>(all_blocks) + static_cast<size_t>(q) * block_bytes;
-    const size_t list_stride = static_cast<size_t>(nq) * block_bytes;
-    gsim_result_header* ohdr =
-        reinterpret_cast<gsim_result_header*>(static_cast<unsigned char*>(d_results) + static_cast<size_t>(q) * block_bytes);
-    gsim_hit* out = reinterpret_cast<gsim_hit*>(ohdr + 1);
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {
-        u64 approx = 0, total = 0;
-        uint32_t flags = 0;
-        for (uint32_t i = 0; i < nblocks; i++) {
-            const gsim_result_header* h = block_hdr(blocks, list_stride, i);
-            approx += h->approx;
-            total += h->count;
-            flags |= h->flags;
-        }
-        ohdr->count = total < k ? static_cast<uint32_t>(total) : k;
-        ohdr->flags = flags;
-        ohdr->approx = approx;
-    }
-    const uint32_t li = t / k, e = t % k;
-    if (li >= nblocks) return;
-    const gsim_result_header* mh = block_hdr(blocks, list_stride, li);
-    if (e >= mh->count) return;
-    const gsim_hit* mine = reinterpret_cast<const gsim_hit*>(mh + 1);
-    const gsim_hit me = mine[e];
-    const u64 mykey = make_key(me.score, me.row);
-    uint32_t rank = e;
-    for (uint32_t j = 0; j < nblocks; j++) {
-        if (j == li) continue;
-        const gsim_result_header* h = block_hdr(blocks, list_stride, j);
-        const gsim_hit* lst = reinterpret_cast<const gsim_hit*>(h + 1);
-        uint32_t lo = 0, hi = h->count; // first index whose key < mykey
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (make_key(lst[mid].score, lst[mid].row) > mykey) lo = mid + 1;
-            else hi = mid;
-        }
-        rank += lo;
-    }
-    if (rank < k) out[rank] = me;
-}
-
-// ---------------------------------------------------------------------------
-// synthetic table generator (twin of oracle gso_synth_word)
-// ---------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void generate_kernel(uint32_t* rows, u64 seed, int kind, u64 first_row,
-                                                       u64 nwords, uint32_t W)
-{
-    const u64 stride = static_cast<u64>(gridDim.x) * blockDim.x;
-    for (u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x; i < nwords; i += stride)
-        rows[i] = synth_word_iid(seed, kind == GSIM_SYNTH_DENSE, first_row * W + i);
-}
-
-// GSIM_SYNTH_MORGAN (gsim_synth.h): a row is made whole, by one thread, in LDS; the workgroup's rows
-// then leave with coalesced stores.  R rows per workgroup (host: kMorganLdsWords / W, at most 256).
-constexpr uint32_t kMorganLdsWords = 12288;
-
-__global__ __launch_bounds__(256) void generate_morgan_kernel(uint32_t* rows, u64 seed, u64 first_row, u64 nrows,
-                                                              uint32_t W, uint32_t R)
-{
-    __shared__ uint32_t s_rows[kMorganLdsWords];
-    for (u64 r0 = static_cast<u64>(blockIdx.x) * R; r0 < nrows; r0 += static_cast<u64>(gridDim.x) * R) {
-        const uint32_t n = static_cast<uint32_t>(nrows - r0 < R ? nrows - r0 : R);
-        if (threadIdx.x < n) synth_row_morgan(s_rows + threadIdx.x * W, seed, first_row + r0 + threadIdx.x, W);
-        __syncthreads();
-        uint32_t* dst = rows + r0 * W;
-        for (uint32_t i = threadIdx.x; i < n * W; i += 256) dst[i] = s_rows[i];
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void score_table_kernel(int metric, float alpha, float beta, uint32_t a,
-                                                          uint32_t max_b, uint32_t max_c, float* out)
-{
-    const u64 n = static_cast<u64>(max_b + 1) * (max_c + 1);
-    const u64 i = static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = static_cast<uint32_t>(i / (max_b + 1)), b = static_cast<uint32_t>(i % (max_b + 1));
-    out[i] = score_of(metric, alpha, beta, a, b, c);
-}
-
-template <int LPR, int U> hipError_t launch_scan_t(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
-{
-    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    hipLaunchKernelGGL((scan_kernel<LPR, U>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
-    return hipGetLastError();
-}
-
 } // namespace
-
-// ---------------------------------------------------------------------------
-// host-side launchers
-// ---------------------------------------------------------------------------
-
-// hipFuncAttributeMaxDynamicSharedMemorySize, set once per device and kernel (whether the runtime keeps the attribute
-// per function or per device is its business; a multi-device handle launches the same kernel on several devices).
-struct DynLdsOnce {
-    std::atomic<bool> done[64] = {};
-    hipError_t ensure(const void* fn, size_t bytes)
-    {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
-        return hipSuccess;
-    }
-};
-
-static bool is_pow2(uint32_t x)
-{
-    return x && !(x & (x - 1));
-}
-
-ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll)
-{
-    ScanGeometry g{};
-    const uint32_t lpr = (W % 4 == 0 && is_pow2(W / 4) && W / 4 <= 64) ? W / 4 : 0;
-    g.lanes_per_row = lpr;
-    if (lpr) {
-        if (unroll != 4 && unroll != 8 && unroll != 16) unroll = 8;
-        g.unroll = static_cast<uint32_t>(unroll);
-        g.chunk_rows = g.unroll * (64 / lpr);
-    } else {
-        // generic widths: the four waves' chunks live in LDS (scan_generic_kernel), fewer rows per chunk when they are wide
-        g.unroll = 1;
-        g.chunk_rows = 64;
-        while (g.chunk_rows > 4 && generic_lds_bytes(W, g.chunk_rows) > kGenericLdsBytes) g.chunk_rows /= 2;
-        // a wave has one chunk in flight and computes between loads: as many workgroups per CU as the LDS holds (up to four)
-        const uint32_t lds = generic_lds_bytes(W, g.chunk_rows) + static_cast<uint32_t>(sizeof(BlockFilter));
-        const int per_cu = std::max(1, std::min(4, static_cast<int>(150u * 1024u / lds)));
-        waves_per_cu = std::max(waves_per_cu, per_cu * (kScanBlock / 64));
-    }
-    g.nchunks = (nrows + g.chunk_rows - 1) / g.chunk_rows;
-    uint64_t nw = static_cast<uint64_t>(num_cus) * static_cast<uint64_t>(waves_per_cu);
-    if (nw > g.nchunks) nw = g.nchunks;
-    if (nw < 1) nw = 1;
-    const uint32_t wpb = kScanBlock / 64;
-    nw = (nw + wpb - 1) / wpb * wpb;
-    g.nwaves = static_cast<uint32_t>(nw);
-    const uint64_t per = (g.nchunks + g.nwaves - 1) / g.nwaves;
-    g.seg_cap = static_cast<uint32_t>((per ? per : 1) * g.chunk_rows);
-    return g;
-}
-
-template <int LPR, int U>
-hipError_t launch_sample_t(const ScanArgs& a, uint32_t nsample, uint64_t stride, uint32_t nblocks, hipStream_t s)
-{
-    hipLaunchKernelGGL((sample_kernel<LPR, U>), dim3(nblocks), dim3(kScanBlock), 0, s, a, nsample, stride);
-    return hipGetLastError();
-}
-
-// Starting threshold from a strided sample (large tables only).
-hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s)
-{
-    if (a.k == 0 || chunks_per_wave == 0) return hipSuccess;
-    const uint64_t nfull = a.nrows / g.chunk_rows;
-    // never sample more than 1/8 of the table; under one chunk per wave the scan's own warm-up is cheaper
-    const uint64_t fit = nfull / (8ull * g.nwaves);
-    if (fit < chunks_per_wave) chunks_per_wave = static_cast<uint32_t>(fit);
-    if (chunks_per_wave == 0) return hipSuccess;
-    const uint64_t want = static_cast<uint64_t>(g.nwaves) * chunks_per_wave;
-    const uint64_t stride = nfull / want;
-    const uint32_t nsample = static_cast<uint32_t>(want);
-    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    if (g.lanes_per_row == 0) {
-        const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
-        static DynLdsOnce once;
-        const hipError_t e = once.ensure(reinterpret_cast<const void*>(sample_generic_kernel), kGenericLdsBytes);
-        if (e != hipSuccess) return e;
-        if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(sample_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g.chunk_rows, nsample, stride);
-        return hipGetLastError();
-    }
-#define GSIM_CASE(L, UU) \
-    if (g.lanes_per_row == L && g.unroll == UU) return launch_sample_t<L, UU>(a, nsample, stride, nblocks, s);
-    GSIM_CASE(8, 8)
-    GSIM_CASE(8, 4)
-    GSIM_CASE(8, 16)
-    GSIM_CASE(16, 8)
-    GSIM_CASE(16, 4)
-    GSIM_CASE(16, 16)
-    GSIM_CASE(1, 8)
-    GSIM_CASE(2, 8)
-    GSIM_CASE(4, 8)
-    GSIM_CASE(32, 8)
-    GSIM_CASE(64, 8)
-#undef GSIM_CASE
-    return hipSuccess;
-}
-
-hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
-{
-#define GSIM_CASE(L, UU) \
-    if (g.lanes_per_row == L && g.unroll == UU) return launch_scan_t<L, UU>(a, g, s);
-    GSIM_CASE(8, 8)
-    GSIM_CASE(8, 4)
-    GSIM_CASE(8, 16)
-    GSIM_CASE(16, 8)
-    GSIM_CASE(16, 4)
-    GSIM_CASE(16, 16)
-    GSIM_CASE(1, 8)
-    GSIM_CASE(2, 8)
-    GSIM_CASE(4, 8)
-    GSIM_CASE(32, 8)
-    GSIM_CASE(64, 8)
-#undef GSIM_CASE
-    if (g.lanes_per_row != 0) return hipErrorInvalidValue;
-    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    static DynLdsOnce once;
-    const hipError_t e = once.ensure(reinterpret_cast<const void*>(scan_generic_kernel), kGenericLdsBytes);
-    if (e != hipSuccess) return e;
-    const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
-    if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(scan_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g);
-    return hipGetLastError();
-}
 
 template <int LPR, int U>
 hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
@@ -2705,126 +1301,6 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
     GSIM_CASE(64)
 #undef GSIM_CASE
     return hipErrorInvalidValue;
-}
-
-hipError_t launch_compact(const ScanArgs& a, const ScanGeometry& g, unsigned long long* finalists,
-                          uint32_t* finalists_cb, uint32_t finalists_cap, hipStream_t s)
-{
-    const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    hipLaunchKernelGGL(compact_kernel, dim3(nblocks), dim3(kScanBlock), 0, s, a, g, finalists, finalists_cb,
-                       finalists_cap);
-    return hipGetLastError();
-}
-
-hipError_t launch_select(const ScanArgs& a, const unsigned long long* finalists, const uint32_t* finalists_cb,
-                         uint32_t finalists_cap, uint32_t row_base, void* d_result, hipStream_t s)
-{
-    static DynLdsOnce once;
-    const hipError_t e = once.ensure(reinterpret_cast<const void*>(select_kernel), kSelectLds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(select_kernel, dim3(kSelectBlocks), dim3(kSelectThreads), kSelectLds, s, a, finalists,
-                       finalists_cb, finalists_cap, row_base, d_result);
-    return hipGetLastError();
-}
-
-hipError_t launch_fold_rescore(const void* folded_block, const uint32_t* full_rows, const uint32_t* full_query, uint32_t W, uint32_t qpop,
-                               unsigned long long* keys, uint32_t* cbs, uint32_t npad, uint32_t* nan_flag, uint32_t k, float cutoff,
-                               uint32_t row_base, void* out_block, hipStream_t s)
-{
-    hipLaunchKernelGGL(fold_rescore_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, folded_block, full_rows, full_query, W, qpop, keys, cbs,
-                       npad, nan_flag);
-    hipError_t e = launch_bitonic_global(keys, npad, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fold_emit_kernel, dim3((k + 255) / 256 ? (k + 255) / 256 : 1), dim3(256), 0, s, folded_block, keys, cbs, k, cutoff, row_base,
-                       out_block);
-    return hipGetLastError();
-}
-
-hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s)
-{
-    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(256), 0, s, state, lk);
-    return hipGetLastError();
-}
-
-// k > kSelectCap: the k-th largest finalist key by eight radix passes, then the keys at or above it into `out`
-// (out_cap >= k entries; the caller zero-fills it and sorts it afterwards).  Nothing here is sized by the finalist count.
-hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
-                                unsigned long long* out, uint32_t out_cap, hipStream_t s)
-{
-    for (int pass = 0; pass < 8; pass++)
-        hipLaunchKernelGGL(largek_pass_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, pass);
-    hipLaunchKernelGGL(largek_gather_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, out, out_cap);
-    return hipGetLastError();
-}
-
-hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s)
-{
-    if (n_pow2 < 2) return hipSuccess;
-    const uint32_t nb = (n_pow2 / 2 + 255) / 256;
-    for (uint32_t size = 2; size <= n_pow2 && size != 0; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            hipLaunchKernelGGL(bitonic_step_kernel, dim3(nb), dim3(256), 0, s, keys, n_pow2, size, stride);
-        }
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s)
-{
-    if (to <= from) return hipSuccess;
-    const uint64_t nb = (to - from + 255) / 256;
-    hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, keys, from, to);
-    return hipGetLastError();
-}
-
-hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, const LargeKState* lk,
-                            uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result,
-                            hipStream_t s)
-{
-    const uint32_t nb = a.k ? (a.k + 255) / 256 : 1; // (the kernel emits min(k, gathered) hits)
-    hipLaunchKernelGGL(emit_hits_kernel, dim3(nb), dim3(256), 0, s, a, sorted_keys, lk, row_base,
-                       approx_if_no_cutoff, flags, d_result);
-    return hipGetLastError();
-}
-
-hipError_t launch_merge_batch(const void* d_blocks, uint32_t nblocks, uint32_t nq, size_t block_bytes, uint32_t k,
-                              void* d_results, hipStream_t s)
-{
-    const uint64_t nthreads = static_cast<uint64_t>(nblocks) * (k ? k : 1);
-    const uint32_t nb = static_cast<uint32_t>((nthreads + 255) / 256);
-    hipLaunchKernelGGL(merge_kernel, dim3(nb ? nb : 1, nq), dim3(256), 0, s, d_blocks, nblocks, nq, block_bytes,
-                       k ? k : 1, d_results);
-    return hipGetLastError();
-}
-
-hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows, uint32_t W,
-                           hipStream_t s)
-{
-    const uint64_t nwords = nrows * W;
-    if (nwords == 0) return hipSuccess;
-    if (kind == GSIM_SYNTH_MORGAN) {
-        if (W > kMorganLdsWords) return hipErrorInvalidValue;
-        const uint32_t R = std::min<uint32_t>(256u, kMorganLdsWords / W);
-        uint64_t nb = (nrows + R - 1) / R;
-        if (nb > 65536) nb = 65536;
-        hipLaunchKernelGGL(generate_morgan_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s,
-                           reinterpret_cast<uint32_t*>(rows), seed, first_row, nrows, W, R);
-        return hipGetLastError();
-    }
-    uint64_t nb = (nwords + 255) / 256;
-    if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(generate_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s,
-                       reinterpret_cast<uint32_t*>(rows), seed, kind, first_row, nwords, W);
-    return hipGetLastError();
-}
-
-hipError_t launch_score_table(int metric, float alpha, float beta, uint32_t a, uint32_t max_b, uint32_t max_c,
-                              float* d_out, hipStream_t s)
-{
-    const uint64_t n = static_cast<uint64_t>(max_b + 1) * (max_c + 1);
-    const uint32_t nb = static_cast<uint32_t>((n + 255) / 256);
-    hipLaunchKernelGGL(score_table_kernel, dim3(nb), dim3(256), 0, s, metric, alpha, beta, a, max_b, max_c, d_out);
-    return hipGetLastError();
 }
 
 } // namespace gsim

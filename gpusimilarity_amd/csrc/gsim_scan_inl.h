@@ -1,0 +1,142 @@
+// gsim_scan_inl.h -- the streaming loop of one wavefront over the packed-uint32 table, shared by the kernels that scan
+// it (scan_kernel, sample_kernel: gsim_scan.hip; fused_kernel: gsim_fused.hip).  Replaces the reference's thread-per-row
+// TanimotoFunctor (fingerprintdb_cuda.cu:76-104).  Internal; device code only.
+#pragma once
+
+#include <atomic>
+
+#include "gsim_device_common.h"
+
+namespace gsim
+{
+namespace
+{
+
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p)
+{
+    // read once: keep it out of the caches' way (+13 % on tables far larger than the caches; default-policy loads
+    // for tables that fit the 256 MB Infinity Cache were tried on repeated queries over 1 M rows: no gain)
+    return __builtin_nontemporal_load(p);
+}
+
+// LPR = 16-byte lanes per fingerprint (fp_bits / 128), U = loads per lane per chunk.
+// A chunk is CH = U * 64 / LPR consecutive rows = U KiB of the table; wave w takes
+// chunks w, w + nwaves, ...  The loads of the next chunk are issued before the
+// current one is reduced (register double buffer): 2U KiB in flight per wave.
+// The loop body over full chunks is branch-free up to the (rare) emit path, so the
+// compiler's s_waitcnt placement leaves the prefetch in flight during the reduce;
+// the table's last, partial chunk is handled once, outside the loop.
+template <int LPR, int U, bool FULL, typename Filter>
+__device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q, u64 row0, const ScanArgs& a,
+                                             Filter& f, int lane)
+{
+    constexpr int RPL = 64 / LPR;
+    constexpr int ROUNDS = (U + LPR - 1) / LPR;
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+    uint32_t v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        // v_and + v_bcnt_u32_b32 (popcount with accumulate)
+        const uint32_t cc =
+            __popc(d[j].x & q.x) + __popc(d[j].y & q.y) + __popc(d[j].z & q.z) + __popc(d[j].w & q.w);
+        const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
+        v[j] = group_sum<LPR>((cc << 16) + bb); // both sums < 2^16 (fp_bits <= 32768)
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        // lane (grp, sub) takes the row of load j = r*LPR + sub
+        uint32_t val = 0;
+#pragma unroll
+        for (int jj = 0; jj < U; jj++) {
+            if (jj / LPR == r) val = (sub == jj % LPR) ? v[jj] : val;
+        }
+        const int j = r * LPR + sub;
+        const u64 row = row0 + static_cast<u64>(j * RPL + grp);
+        const bool active = (j < U) && (FULL || row < a.nrows);
+        const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
+        f.offer(active, static_cast<uint32_t>(row), s, val, lane);
+    }
+}
+
+// The streaming loop of one wavefront: chunks w, w + nwaves, ... of the table through filter f.
+template <int LPR, int U, typename Filter>
+__device__ __forceinline__ void scan_rows(const ScanArgs& a, const ScanGeometry& g, Filter& f, const u32x4& q, uint32_t w,
+                                          int lane)
+{
+    constexpr int RPL = 64 / LPR; // rows per load instruction
+    constexpr int CH = U * RPL;   // rows per chunk
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    uint32_t gt = 0; // table-wide threshold, loaded ahead of its use
+    uint32_t trip = 0;
+    const uint32_t wib = w % (kScanBlock / 64);
+
+    const u64 nfull = a.nrows / CH; // chunks with all CH rows present
+    if (w < nfull) {
+        const u64 last = w + (nfull - 1 - w) / g.nwaves * g.nwaves; // this wave's last full chunk
+        u32x4 nxt[U];
+        {
+            const u32x4* p = db + static_cast<u64>(w) * (CH * LPR) + lane;
+#pragma unroll
+            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
+        }
+        for (u64 c = w;; c += g.nwaves) {
+            u32x4 d[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) d[j] = nxt[j];
+            // prefetch; on the final trip it re-reads the last chunk (no branch in the body)
+            const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last;
+            const u32x4* p = db + cn * (CH * LPR) + lane;
+#pragma unroll
+            for (int j = 0; j < U; j++) nxt[j] = stream_load(p + j * 64);
+            f.refresh(gt, lane);
+            // The workgroup polls the table-wide threshold every 8th chunk while it moves fast
+            // (first 64 chunks), then every 32nd, then every 128th; the waves take turns so that
+            // no single wave pays for all polls.  A poll is one more entry in the loop's vmcnt
+            // queue: its latency is exposed whenever it exceeds the prefetch's (~1 us each).
+            // (Single-launch path: every chunk of the first 32, in turns -- a small table is over
+            // after 16 trips and its first threshold arrives around the 10th.)
+            {
+                const uint32_t period = (Filter::kFused && trip < 32u) ? 1u : (trip < 64u ? 8u : (trip < 512u ? 32u : 128u));
+                if ((trip & (period - 1u)) == 0 && ((trip / period) & (kScanBlock / 64 - 1)) == wib) gt = f.load_gtau();
+                trip++;
+            }
+            reduce_chunk<LPR, U, true>(d, q, c * CH, a, f, lane);
+            if (Filter::kFused) f.checkpoint(trip, lane);
+            if (c == last) break;
+        }
+    }
+    if (nfull < g.nchunks && w == nfull % g.nwaves) { // the table's partial last chunk
+        const u64 row0 = nfull * CH;
+        const u32x4* p = db + row0 * LPR + lane;
+        const int grp = lane / LPR;
+        u32x4 d[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const u64 row = row0 + static_cast<u64>(j * RPL + grp);
+            d[j] = row < a.nrows ? stream_load(p + j * 64) : u32x4{0, 0, 0, 0};
+        }
+        f.refresh(f.load_gtau(), lane);
+        reduce_chunk<LPR, U, false>(d, q, row0, a, f, lane);
+    }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per device and kernel (whether the runtime keeps the attribute
+// per function or per device is its business; a multi-device handle launches the same kernel on several devices).
+struct DynLdsOnce {
+    std::atomic<bool> done[64] = {};
+    hipError_t ensure(const void* fn, size_t bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64 && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
+        return hipSuccess;
+    }
+};
+
+} // namespace
+} // namespace gsim

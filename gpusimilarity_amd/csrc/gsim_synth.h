@@ -1,6 +1,6 @@
 // gsim_synth.h -- the counter-based synthetic fingerprint generators, as plain host + device
-// functions: generate_kernel / generate_morgan_kernel (gsim_device.hip) fill a table in HBM with
-// them, gsim_synth_row (gsim_capi.cpp) hands single rows to host callers (benchmark queries are
+// functions: generate_kernel / generate_morgan_kernel (gsim_select.hip) fill a table in HBM with
+// them, gsim_synth_row (capi_lifecycle.cpp) hands single rows to host callers (benchmark queries are
 // rows of the table).  Integer arithmetic only, so host and device agree bit for bit; the test
 // oracle has its own restatement (oracle/gsim_oracle.c gso_synth_*) and the parity tests compare
 // the three.

@@ -89,6 +89,9 @@ typedef struct {
                                    selector holds, 16 more of them owned by one selector than its list holds           */
     uint64_t batches_dense_cutoff; /* multi-query passes, since the handle was created, whose cutoff kept so many rows that the
                                       matrix-core pass counted them from its accumulators (gsim_prefilter.h cutoff_band)      */
+    uint64_t collectives;          /* searches (single queries or <= 256-query batches) merged through gsim_db_set_comm's route */
+    double gather_ms_sum;          /* ... their all-gather: last shard kernel enqueued on the first shard's stream -> blocks gathered */
+    double merge_ms_sum;           /* ... their merge_kernel                                                                  */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */
@@ -242,6 +245,23 @@ int gsim_merge_device_batch(int device, void* hip_stream, const void* d_blocks,
  * logic): std::sort + truncate exactly as fingerprintdb_cuda.cu:363-380. */
 int gsim_merge_host(const void* blocks, uint32_t nblocks, size_t block_bytes, uint32_t k,
                     void* result);
+
+/* ---- in-process collective: per-GPU top-k merged via an RCCL all-gather ---- */
+/* FingerprintDB::search runs one host thread per storage and merges their results on the host
+ * (fingerprintdb_cuda.cu:356-380); gsim_db_search on a multi-device handle does the same by default.  With a
+ * communicator attached, every shard's kernels leave their result block in their own device's HBM, ONE grouped
+ * ncclAllGather over the shards' streams (RCCL over xGMI; 16 + 12 k bytes per device) brings the blocks to every
+ * device and a merge kernel on the first shard's device writes the merged block into pinned host memory -- no
+ * PyTorch, no second process.  Results are identical to the host merge's, bit for bit. */
+typedef struct gsim_comm gsim_comm;
+/* ncclCommInitAll over `devices` (distinct device indices, in the order of the handle's shards:
+ * gsim_db_finalize(db, device, n) places shard i on device + i). */
+int gsim_comm_create(const int* devices, int ndevices, gsim_comm** out);
+int gsim_comm_destroy(gsim_comm* comm); /* detach it from every handle first (gsim_db_set_comm(db, NULL)) */
+int gsim_comm_size(const gsim_comm* comm);
+/* Route gsim_db_search / gsim_db_search_each of this handle through the communicator (NULL: back to the host
+ * merge).  The communicator's devices must be the shards' devices, in order.  Not for folded tables. */
+int gsim_db_set_comm(gsim_db* db, gsim_comm* comm);
 
 /* ---- instrumentation ------------------------------------------------------ */
 int gsim_db_enable_timing(gsim_db* db, int enable); /* resets the accumulators */

@@ -1,5 +1,5 @@
 """The in-process multi-device path on a one-GPU box: GSIM_TEST_ALIAS_DEVICES=4 makes the library
-present four logical devices on GPU 0 (a test hook, csrc/gsim_capi.cpp alias_devices), so
+present four logical devices on GPU 0 (a test hook, csrc/capi_lifecycle.cpp alias_devices), so
 gsim_db_finalize(db, dev, n > 1), the per-shard fan-out + host merge of single queries, batches and
 folded tables (fingerprintdb_cuda.cu:356-380), gsim_next_device's round robin (:54-68) and
 `gpusimserver --gpus 4` all run and are compared with the oracle / the golden protocol frames."""
