@@ -262,7 +262,7 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
 
 
 def table_uses_fused(k, tm):
-    return k <= 4096 and os.environ.get("GSIM_FUSED", "1") != "0" and tm["handed_back"] < max(1, tm["queries"])
+    return k <= 8192 and os.environ.get("GSIM_FUSED", "1") != "0" and tm["handed_back"] < max(1, tm["queries"])
 
 
 def time_batches(ctx, table, total_rows, R, fp_bits, kind, k, Q, steps, warmup, sharded, cutoff=0.0):

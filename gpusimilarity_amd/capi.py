@@ -32,7 +32,8 @@ class GsimTiming(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("scan_ms_sum", C.c_double), ("select_ms_sum", C.c_double),
                 ("candidates_sum", C.c_uint64), ("finalists_sum", C.c_uint64), ("handed_back", C.c_uint64),
                 ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64), ("batches_dense_cutoff", C.c_uint64),
-                ("collectives", C.c_uint64), ("gather_ms_sum", C.c_double), ("merge_ms_sum", C.c_double)]
+                ("collectives", C.c_uint64), ("gather_ms_sum", C.c_double), ("merge_ms_sum", C.c_double),
+                ("blocks_rechecked", C.c_uint64), ("blocks_torn", C.c_uint64)]
 
 
 class GsimError(RuntimeError):
@@ -45,7 +46,7 @@ _lib = None
 
 EXPORTS = [
     "gsim_device_count", "gsim_device_free_bytes", "gsim_available_device_bytes", "gsim_next_device",
-    "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor",
+    "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor", "gsim_db_set_fold_full_on_device",
     "gsim_fold_fingerprint", "gsim_db_generate", "gsim_synth_row", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
     "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
@@ -84,6 +85,7 @@ def load():
         "gsim_db_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
         "gsim_db_set_fold_factor": (C.c_int, [vp, C.c_uint32]),
         "gsim_db_fold_factor": (C.c_uint32, [vp]),
+        "gsim_db_set_fold_full_on_device": (C.c_int, [vp, C.c_int]),
         "gsim_fold_fingerprint": (C.c_int, [u32p, C.c_uint32, C.c_uint32, u32p]),
         "gsim_db_generate": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
         "gsim_synth_row": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, u32p]),
@@ -192,6 +194,10 @@ class Table:
 
     def set_fold_factor(self, fold_factor: int):
         check(self._L.gsim_db_set_fold_factor(self._h, fold_factor))
+        return self
+
+    def set_fold_full_on_device(self, allow: bool):
+        check(self._L.gsim_db_set_fold_full_on_device(self._h, 1 if allow else 0))
         return self
 
     def fold_factor(self) -> int:

@@ -43,9 +43,9 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         GSIM_HIP(hipMalloc(&s.d_bfin_cb, static_cast<size_t>(kBatchMaxQ) * gsim::kSelectCap * 4));
         GSIM_HIP(hipMalloc(&s.d_bflags, 64));
         GSIM_HIP(hipMalloc(&s.d_brare, sizeof(gsim::BatchRare)));
-        GSIM_HIP(hipHostMalloc(&s.h_brare, sizeof(gsim::BatchRare), hipHostMallocDefault));
-        GSIM_HIP(hipHostMalloc(&s.h_bflags, 64, hipHostMallocDefault));
-        GSIM_HIP(hipHostMalloc(&s.h_bqueries, static_cast<size_t>(kBatchMaxQ) * (s.W + 1) * 4, hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(&s.h_brare, sizeof(gsim::BatchRare), kHostPinned));
+        GSIM_HIP(hipHostMalloc(&s.h_bflags, 64, kHostPinned));
+        GSIM_HIP(hipHostMalloc(&s.h_bqueries, static_cast<size_t>(kBatchMaxQ) * (s.W + 1) * 4, kHostPinned));
         s.bq_cap = kBatchMaxQ;
     }
     const size_t need = gsim_result_block_bytes(k) * kBatchMaxQ;
@@ -54,7 +54,7 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         if (s.d_bresult) GSIM_HIP(hipFree(s.d_bresult));
         s.h_bresult = nullptr;
         s.d_bresult = nullptr;
-        GSIM_HIP(hipHostMalloc(&s.h_bresult, need, hipHostMallocDefault));
+        GSIM_HIP(hipHostMalloc(&s.h_bresult, need, kHostPinned));
         GSIM_HIP(hipMalloc(&s.d_bresult, need));
         s.h_bresult_bytes = need;
     }

@@ -172,6 +172,8 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
         db->acc.handed_back_why |= s.h_state->redo_why & 31u; // (bit 5 = "a selector saw it fail": not a reason of its own)
     }
     db->acc.batches_dense_cutoff = db->dense_batches;
+    db->acc.blocks_rechecked = db->blocks_rechecked;
+    db->acc.blocks_torn = db->blocks_torn;
     *out = db->acc;
     return GSIM_OK;
 }

@@ -135,7 +135,7 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
                 GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_fq), static_cast<size_t>(W) * 4 + 64));
                 GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_key2), static_cast<size_t>(65536) * 8));
                 GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cb2), static_cast<size_t>(65536) * 4));
-                GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_fq), static_cast<size_t>(W) * 4 + 64, hipHostMallocDefault));
+                GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_fq), static_cast<size_t>(W) * 4 + 64, kHostPinned));
             }
             GSIM_HIP(hipStreamSynchronize(s.stream)); // (the pinned staging of the previous query's fingerprint is free)
             std::memcpy(s.h_fq, query, static_cast<size_t>(W) * 4);

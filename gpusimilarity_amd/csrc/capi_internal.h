@@ -53,7 +53,10 @@ hipError_t set_device(int logical);
 
 // Host memory the kernels write and the host reads WHILE the kernel still runs (completion words, result blocks): it has
 // to be coherent (fine-grained) whatever the runtime's default for pinned memory is (HIP_HOST_COHERENT).
-constexpr unsigned kHostPolled = hipHostMallocCoherent;
+// Portable: pinned for, and mapped into, EVERY device of the process -- a multi-device handle's kernels on GPU 1..7 read
+// queries from and write blocks into buffers that were allocated while another device was current.
+constexpr unsigned kHostPolled = hipHostMallocPortable | hipHostMallocCoherent;
+constexpr unsigned kHostPinned = hipHostMallocPortable; // staging the kernels read (queries) or copies go through
 constexpr int kTimingRing = 1024;
 // single-launch path: 4096 summary keys + the checkpoint tickets (kFusedCheckpoints x 9 counters, 128 B apart) + the
 // arrival counters (128 B apart)
@@ -180,10 +183,13 @@ struct gsim_db {
     std::vector<uint64_t> slice_first; // first row of every add_rows slice (reference: one storage each)
     uint32_t fold_requested = 1;       // gsim_db_set_fold_factor
     uint32_t fold = 1;                 // effective factor (divides W), fixed at finalize
+    bool fold_full_on_device = true;   // gsim_db_set_fold_full_on_device
     uint32_t row_base = 0;
     bool timing = false;
     gsim_timing acc{};
     unsigned long long dense_batches = 0; // multi-query passes whose dense cutoff the matrix-core pass counted itself
+    unsigned long long blocks_checked = 0, blocks_rechecked = 0, blocks_torn = 0; // single launch, synchronous callers: result blocks whose checksum
+                                                               // did not match at first sight / never did (re-run)
     gsim_comm* comm = nullptr; // gsim_db_set_comm: shard results meet through an RCCL all-gather + merge_kernel instead of on the host
     // One search at a time per handle (the reference serialises searches behind a function-static
     // mutex, fingerprintdb_cuda.cu:236): concurrent callers queue here.

@@ -122,19 +122,30 @@ int setup_shard(gsim_db* db, Shard& s)
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(s.W) * 4));
     GSIM_HIP(hipMalloc(&s.d_state, sizeof(gsim::QueryState)));
     GSIM_HIP(hipMemset(s.d_state, 0, sizeof(gsim::QueryState))); // the kernels keep it zero between queries
-    GSIM_HIP(hipMalloc(&s.d_pub, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
-    GSIM_HIP(hipMalloc(&s.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
+    // every workgroup of the single launch is a selector and there are at most kFusedSelectors: on a part with more CUs
+    // (or with GSIM_SCAN_WAVES_PER_CU > 4) the grid is clamped -- its waves take more chunks each -- instead of losing the path
+    const uint32_t fused_max_waves = static_cast<uint32_t>(gsim::kFusedSelectors) * (gsim::kScanBlock / 64);
+    if (s.fgeo.nwaves > fused_max_waves) s.fgeo.nwaves = fused_max_waves;
+    if (gsim::fused_supported(s.fgeo)) {
+        GSIM_HIP(hipMalloc(&s.d_pub, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
+        GSIM_HIP(hipMalloc(&s.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
+    } else {
+        static std::atomic<bool> said{false};
+        if (s.geo.lanes_per_row != 0 && !said.exchange(true))
+            std::fprintf(stderr, "gpusimilarity_amd: the single-launch path is off for this table's scan geometry (%u waves, unroll %u): "
+                                 "queries run on the four-kernel pipeline\n", s.fgeo.nwaves, s.fgeo.unroll);
+    }
     GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_summ), kSummBytes));
     GSIM_HIP(hipMemset(s.d_summ, 0, kSummBytes));
     GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_done), 64, kHostPolled));
     std::memset(s.h_done, 0, 64);
-    GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(s.W) * 4 * kQueryRing, hipHostMallocDefault));
+    GSIM_HIP(hipHostMalloc(&s.h_query, static_cast<size_t>(s.W) * 4 * kQueryRing, kHostPinned));
     for (int i = 0; i < kQueryRing; i++) {
         hipEvent_t e;
         GSIM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         s.q_ev.push_back(e);
     }
-    GSIM_HIP(hipHostMalloc(&s.h_state, sizeof(gsim::QueryState), hipHostMallocDefault));
+    GSIM_HIP(hipHostMalloc(&s.h_state, sizeof(gsim::QueryState), kHostPinned));
     return GSIM_OK;
 }
 
@@ -174,7 +185,7 @@ int upload_rows(void* d_dst, const void* h_src, size_t bytes, hipStream_t stream
     int rc = GSIM_OK;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipHostMalloc(&stage[i], kChunk, hipHostMallocDefault);
+        e = hipHostMalloc(&stage[i], kChunk, kHostPinned);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     }
     size_t off = 0;
@@ -325,6 +336,14 @@ uint32_t gsim_db_fold_factor(const gsim_db* db)
     return db ? db->fold : 0;
 }
 
+int gsim_db_set_fold_full_on_device(gsim_db* db, int allow)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    if (db->finalized) return fail(GSIM_ERR_STATE, "table already finalized");
+    db->fold_full_on_device = allow != 0;
+    return GSIM_OK;
+}
+
 int gsim_db_finalize(gsim_db* db, int device, int ndevices)
 {
     if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
@@ -372,20 +391,46 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
             if (bytes) GSIM_HIP(hipMemcpy(s.d_rows, folded.data(), bytes, hipMemcpyHostToDevice));
             int rc = setup_shard(db, s);
             if (rc != GSIM_OK) return rc;
-            // The full fingerprints as well, when the device has room for them (on a 288 GB MI355X it practically always
-            // has: folding is then a speed device, not a capacity one): the candidates are re-scored on the GPU.  Without
-            // them the re-score runs on the host, as in the reference (fingerprintdb_cuda.cu:307-331).
-            static const int full_on_device = env_int("GSIM_FOLD_FULL_ON_DEVICE", 1);
+        }
+        // The full fingerprints as well, when EVERY storage's fit next to the folded rows (on a 288 GB MI355X they
+        // practically always do: folding is then a speed device, not a capacity one): the candidates are re-scored on the
+        // GPU.  Decided only now, with all folded storages placed, and for all storages or none: search_folded re-scores
+        // on the device only when every shard holds its full rows, and when folding is capacity-driven (the placement plan
+        // picked a factor > 1 because the table does not fit) copies made storage by storage would take the memory the
+        // later storages' folded rows and the search scratch were budgeted for.  Per device: the full rows
+        // of its storages + 24 B per folded row (the four-kernel pipeline's scratch, allocated on first use) + 2 GB.
+        // Without them the re-score runs on the host, as in the reference (fingerprintdb_cuda.cu:307-331).
+        static const int full_on_device = env_int("GSIM_FOLD_FULL_ON_DEVICE", 1);
+        bool keep_full = full_on_device != 0 && db->fold_full_on_device && db->nrows > 0;
+        if (keep_full) {
+            std::vector<size_t> need(static_cast<size_t>(ndev), 0);
+            for (const auto& s : db->shards) need[static_cast<size_t>(s.device)] += static_cast<size_t>(s.nrows) * (static_cast<size_t>(db->W) * 4 + 24);
+            for (int d = 0; d < ndev && keep_full; d++) {
+                if (!need[static_cast<size_t>(d)]) continue;
+                size_t fr = 0;
+                keep_full = gsim_device_free_bytes(d, &fr) == GSIM_OK && fr > need[static_cast<size_t>(d)] + (size_t(2) << 30);
+            }
+        }
+        for (size_t i = 0; i < nsl && keep_full; i++) {
+            Shard& s = db->shards[i];
             const size_t full_bytes = static_cast<size_t>(s.nrows) * db->W * 4;
-            size_t fr = 0, tot = 0;
-            if (full_on_device && full_bytes && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > full_bytes + (size_t(2) << 30)) {
-                if (hipMalloc(reinterpret_cast<void**>(&s.d_full), full_bytes) == hipSuccess) {
-                    const int urc = upload_rows(s.d_full, db->host_rows.data() + s.first_row * db->W, full_bytes, nullptr);
-                    if (urc != GSIM_OK) return urc;
-                } else {
-                    (void) hipGetLastError();
-                    s.d_full = nullptr;
-                }
+            if (!full_bytes) continue;
+            GSIM_HIP(set_device(s.device));
+            if (hipMalloc(reinterpret_cast<void**>(&s.d_full), full_bytes) != hipSuccess) {
+                (void) hipGetLastError();
+                s.d_full = nullptr;
+                keep_full = false;
+                break;
+            }
+            const int urc = upload_rows(s.d_full, db->host_rows.data() + s.first_row * db->W, full_bytes, nullptr);
+            if (urc != GSIM_OK) return urc;
+        }
+        if (!keep_full) { // none rather than some: partial copies are never used
+            for (auto& s : db->shards) {
+                if (!s.d_full) continue;
+                (void) set_device(s.device);
+                (void) hipFree(s.d_full);
+                s.d_full = nullptr;
             }
         }
         db->finalized = true;

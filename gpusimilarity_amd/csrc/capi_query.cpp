@@ -74,7 +74,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
 {
     GSIM_HIP(set_device(s.device));
     if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
-        GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, ncand_sum), s.stream));
+        GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, redo_why), s.stream)); // (the per-query part)
+        if (s.d_lk) GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));   // (a large-k enqueue may have failed between its radix passes)
         GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
         s.state_dirty = false;
     }
@@ -259,14 +260,51 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (done) *flag &= 0xFFu; // the header as every other route leaves it
-    const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
+    gsim_result_header* h = static_cast<gsim_result_header*>(out);
+    bool torn = false;
+    if (done && !(*flag & 2u)) {
+        // The block validates itself: the closing workgroup put the sum of the words of all hits (+ epoch * kBlockCheckMul)
+        // into the upper half of approx.  The hits were stored write-through at system scope and every selector waited for
+        // their acknowledgements before its ticket, so they are in host memory when the header is -- on the platforms this
+        // was soaked on.  Whether an acknowledgement means host visibility is the platform's business: if the
+        // sums differ the hits are still on their way -- look again for a while, then let the stream drain; a block that
+        // stays wrong is re-run on the four-kernel pipeline (gsim_timing.blocks_rechecked / blocks_torn count both).
+        // (test hook, no production use: GSIM_TEST_TORN_EVERY=n makes every n-th block fail its check for good, so that the
+        // re-run of a torn block -- with later queries of the call already enqueued behind it -- is exercised)
+        static const int torn_every = env_int("GSIM_TEST_TORN_EVERY", 0);
+        const uint32_t spoil = (torn_every > 0 && ++db->blocks_checked % static_cast<unsigned>(torn_every) == 0) ? 1u : 0u;
+        auto block_ok = [&]() -> bool {
+            const uint32_t n = h->count <= k ? h->count : k;
+            const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(h + 1);
+            uint32_t sum = 0;
+            for (uint32_t i = 0; i < 3u * n; i++) sum += w[i];
+            return static_cast<uint32_t>(h->approx >> 32) == sum + want * gsim::kBlockCheckMul + spoil;
+        };
+        bool good = block_ok();
+        if (!good) {
+            db->blocks_rechecked++;
+            for (int spins = 0; spins < (spoil ? 2 : 20000) && !good; spins++) good = block_ok();
+            if (!good) {
+                (void) hipStreamSynchronize(s.stream);
+                std::atomic_thread_fence(std::memory_order_acquire);
+                good = block_ok();
+            }
+            if (!good) {
+                db->blocks_torn++;
+                torn = true; // (re-run below; the kernel itself closed the query and left the state clean)
+            }
+        }
+    }
+    if (done) {
+        *flag &= 0xFFu; // the header as every other route leaves it
+        h->approx &= 0xFFFFFFFFull;
+    }
     if (s.d_dbg && done) dump_fused_phases(s); // phase profile of this query (instrumented runs only)
-    if (done && !(h->flags & 2u)) {
+    if (done && !torn && !(h->flags & 2u)) {
         s.redo_streak = 0;
         return GSIM_OK;
     }
-    if (done) {
+    if (done && !torn) {
         s.redo_streak = s.redo_streak < 6 ? s.redo_streak + 1 : 6;
         if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
     }

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
+#include <cstddef>
 #include <stdint.h>
 
 namespace gsim
@@ -28,18 +29,30 @@ struct QueryState {
     uint32_t done;               // select-kernel workgroups that have finished (ticket)
     uint32_t gtau;               // table-wide threshold bin shared by all workgroups of the scan (monotone)
     uint32_t elected;            // single-launch path: highest in-loop checkpoint (1-based) whose threshold election has been held
+                                 // ({gtau, elected} are polled with ONE 64-bit load: static_assert below)
     uint32_t redo;               // single-launch path gave up (candidate overflow, heavy ties): the gated
                                  // classic kernels behind it run the query; their select kernel clears it
+    uint32_t pad0;
     // --- single-launch path (fused_kernel) ---
-    uint32_t sel_done;           // selector workgroups that have written their hits (ticket; bit 16 up: selectors that saw the query fail)
-    uint32_t redo_why;           // ... not reset per query: the union of the reasons (kRedo*) of every query handed back so far
-    uint32_t pad1[2];
-    // --- not reset per query: running totals for gsim_db_get_timing ---
-    unsigned long long ncand_sum;
+    unsigned long long sel_done; // top-level closing ticket: groups of selectors that have written their hits (bits 0..15), those
+                                 // that saw the query fail (bits 16..31), the sum of the words of all hits written (bits 32..63)
+    // --- not reset per query (the reset boundary is offsetof(redo_why)) ---
+    uint32_t redo_why;           // the union of the reasons (kRedo*) of every query handed back so far
+    uint32_t pad1;
+    unsigned long long ncand_sum; // running totals for gsim_db_get_timing
     unsigned long long nfinal_sum;
     unsigned long long queries;
     unsigned long long redo_sum; // queries the single-launch path handed back to the four-kernel pipeline
 };
+static_assert(offsetof(QueryState, gtau) % 8 == 0 && offsetof(QueryState, elected) == offsetof(QueryState, gtau) + 4,
+              "the single launch's poller reads {gtau, elected} with one 64-bit load");
+static_assert(offsetof(QueryState, sel_done) % 8 == 0, "64-bit atomic");
+
+// The single launch's closing word carries a checksum of the result block for synchronous callers: the sum (mod 2^32) of
+// the 32-bit words of every hit written, plus epoch * kBlockCheckMul, travels in the upper half of the header's approx
+// field (a shard holds < 2^31 rows, so the true upper half is zero) -- the host verifies it against the hits it reads
+// before it trusts the block, and clears it (capi_query.cpp finish_query_sync).
+constexpr uint32_t kBlockCheckMul = 0x9E3779B1u;
 
 // Why the single-launch path handed a query back (bits of QueryState::redo; the gated kernels only test for non-zero).
 constexpr uint32_t kRedoStore = 1;        // a wave met more rows at its threshold than its LDS store holds / a region overflowed

@@ -103,6 +103,7 @@ struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
     uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
     uint32_t wcount[kScanBlock / 64];
     uint32_t nfin, nmine, ok, ticket;
+    uint32_t cks, cks_total;        // selectors: sum of the words of the hits this workgroup wrote / of all hits (the closer)
     uint32_t nitems[4];             // selectors: items listed for round r at [r % 4]
     uint32_t hmin, hmax;            // publish: range of the workgroup's score keys
     uint32_t repbin;                // ... the bucket its report lies in (kFusedBins: none)
@@ -787,6 +788,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             sh.nitems[1] = 0;
             sh.repmin = 0ull; // (from here on: the finalists' summed distance from the threshold)
             sh.tauf = 0ull;
+            sh.cks = 0u;
         }
     }
     // (no acquire fence: everything read below was stored write-through and is read with sc1 loads, past the L1)
@@ -1002,6 +1004,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     __syncthreads();
     const uint32_t nfin = sh.nfin;
+    uint32_t cks = 0; // sum of the words of the hits this thread writes (the block's checksum, see kBlockCheckMul)
     uint32_t why = good ? 0u : kRedoSeen;
     if (good && nfin > static_cast<uint32_t>(kFusedFinalLds)) why = kRedoFinalists;
     good = good && nfin <= static_cast<uint32_t>(kFusedFinalLds);
@@ -1022,6 +1025,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 const uint32_t w0 = ~static_cast<uint32_t>(mine) + fa.row_base;
                 const uint32_t w1 = __float_as_uint(key_score(static_cast<uint32_t>(mine >> 32)));
                 const uint32_t w2 = (cb >> 16) | (cb << 16); // {common, popc_db}
+                cks += w0 + w1 + w2;
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2{w0, w1}, hrs, rank * 12u, 0, /*sc0 sc1*/ 17);
                 __builtin_amdgcn_raw_buffer_store_b32(w2, hrs, rank * 12u + 8u, 0, /*sc0 sc1*/ 17);
             };
@@ -1170,6 +1174,10 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (!good && tid == 0) atomicOr(&st->redo, why);
     // ---- 5. the last selector closes the query -----------------------------------------------
     GSIM_STAMP(6);
+    if (fa.done_flag) { // (wave-uniform; most threads wrote nothing)
+        const uint32_t wsum = wave_sum_dpp(cks);
+        if (lane == 0 && wsum) atomicAdd(&sh.cks, wsum);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave: its hits have left the CU
     __syncthreads();
     if (tid == 0) {
@@ -1188,13 +1196,19 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         // after the average selector was ready); a ticket per group b % 8 first, the group's last adds to the top.
         const uint32_t x = blockIdx.x % 8u;
         const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
-        const uint32_t tg = atomicAdd(&fa.arrive[(17u + x) * 32u], good ? 1u : 0x10001u);
+        // (64-bit tickets: count in bits 0..15, failures in 16..31, the checksum of the hits written so far in 32..63 -- one
+        // atomic carries all three, so the last holder knows the sum without another round trip)
+        const u64 mine64 = (static_cast<u64>(sh.cks) << 32) | (good ? 1ull : 0x10001ull);
+        const u64 tg = atomicAdd(reinterpret_cast<u64*>(&fa.arrive[(17u + x) * 32u]), mine64);
         uint32_t closing = 0, failed = 0;
-        if ((tg & 0xFFFFu) == group_size - 1u) {
-            const bool gfail = (tg >> 16) != 0 || !good;
-            const uint32_t tt = atomicAdd(&st->sel_done, gfail ? 0x10001u : 1u);
-            closing = (tt & 0xFFFFu) == ngroups - 1u ? 1u : 0u;
-            failed = ((tt >> 16) != 0 || gfail) ? 1u : 0u;
+        if ((static_cast<uint32_t>(tg) & 0xFFFFu) == group_size - 1u) {
+            const bool gfail = ((static_cast<uint32_t>(tg) >> 16) & 0xFFFFu) != 0 || !good;
+            const uint32_t gcks = static_cast<uint32_t>((tg + mine64) >> 32);
+            const u64 top64 = (static_cast<u64>(gcks) << 32) | (gfail ? 0x10001ull : 1ull);
+            const u64 tt = atomicAdd(&st->sel_done, top64);
+            closing = (static_cast<uint32_t>(tt) & 0xFFFFu) == ngroups - 1u ? 1u : 0u;
+            failed = (((static_cast<uint32_t>(tt) >> 16) & 0xFFFFu) != 0 || gfail) ? 1u : 0u;
+            sh.cks_total = static_cast<uint32_t>((tt + top64) >> 32);
         }
         sh.ticket = closing | (failed << 1);
     }
@@ -1211,7 +1225,9 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             // header carries the query's epoch -- the host polls it, one 16-byte write tells it everything -- and the
             // tidying up below happens behind the caller's back.
             const uint32_t flags = (redo ? 2u : 0u) | (fa.done_flag ? fa.epoch << 8 : 0u);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{redo ? 0u : (nfin < a.k ? nfin : a.k), flags, static_cast<uint32_t>(approx), static_cast<uint32_t>(approx >> 32)},
+            // (synchronous callers: the upper half of approx carries the block's checksum, see kBlockCheckMul)
+            const uint32_t w3 = fa.done_flag ? sh.cks_total + fa.epoch * kBlockCheckMul : static_cast<uint32_t>(approx >> 32);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{redo ? 0u : (nfin < a.k ? nfin : a.k), flags, static_cast<uint32_t>(approx), w3},
                                                    rrs, 0, 0, /*sc0 sc1*/ 17);
         }
         // re-zero the per-query state for the next launch (stream-ordered behind this one)
@@ -1224,13 +1240,16 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         __hip_atomic_store(&st->ncand, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->gtau, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&st->elected, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st->sel_done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // synchronous callers read the hand-back from the header (no gated kernels behind this launch): the next
         // launch, possibly already enqueued, starts clean
         if (fa.done_flag) __hip_atomic_store(&st->redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
-    if (tid < static_cast<int>(kFusedArriveWords)) fa.arrive[tid * 32] = 0;
+    if (tid < static_cast<int>(kFusedArriveWords)) { // (the closing tickets are 64-bit)
+        fa.arrive[tid * 32] = 0;
+        fa.arrive[tid * 32 + 1] = 0;
+    }
     { // the in-loop summaries: zero again for the next query (16-byte stores)
         uint4* sm = reinterpret_cast<uint4*>(fa.summ);
         const uint32_t n16 = (g.nwaves + 3) / 4;

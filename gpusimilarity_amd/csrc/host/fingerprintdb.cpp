@@ -122,7 +122,7 @@ FingerprintDB::~FingerprintDB()
     if (m_db) gsim_db_destroy(m_db);
 }
 
-void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices)
+void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices, bool full_on_device)
 {
     if (m_synthetic) { // generated in HBM, one device (the one get_next_gpu picks)
         (void) fold_factor;
@@ -134,6 +134,7 @@ void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices)
         return;
     }
     if (fold_factor > 1 && gsim_db_set_fold_factor(m_db, fold_factor) != GSIM_OK) throw_last("copyToGPU");
+    if (fold_factor > 1 && gsim_db_set_fold_full_on_device(m_db, full_on_device ? 1 : 0) != GSIM_OK) throw_last("copyToGPU");
     if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
     m_fold_factor = static_cast<int>(gsim_db_fold_factor(m_db));
     m_on_gpu = true;

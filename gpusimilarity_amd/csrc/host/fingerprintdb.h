@@ -45,7 +45,8 @@ class FingerprintDB
     // search() is the reference's approximate folded search (candidates re-scored with the
     // full fingerprints).  ndevices: 1 = one GPU (round-robin placement like
     // get_next_gpu), 0 = shard over all GPUs.
-    void copyToGPU(unsigned int fold_factor, int ndevices = 1);
+    // full_on_device: a folded table may also keep its full fingerprints in HBM for the re-score (gsim_db_set_fold_full_on_device)
+    void copyToGPU(unsigned int fold_factor, int ndevices = 1, bool full_on_device = true);
 
     unsigned int count() const { return static_cast<unsigned int>(m_total_count); }
     Fingerprint getFingerprint(unsigned int index) const; // :212-226

@@ -58,6 +58,7 @@ struct TableFacts {
 struct PlacementPlan {
     unsigned int fold_factor = 1;
     int ndevices = 1; // argument of FingerprintDB::copyToGPU
+    bool full_on_device = true; // folded tables: the full fingerprints may be kept in HBM as well (device re-score)
 };
 
 static PlacementPlan plan_placement(const std::vector<TableFacts>& tables, int gpu_bitcount, int requested,
@@ -115,6 +116,11 @@ static PlacementPlan plan_placement(const std::vector<TableFacts>& tables, int g
         if (arg_fold_factor < plan.fold_factor) throw std::invalid_argument("GPU bitset not sufficiently small to fit on GPU");
         plan.fold_factor = arg_fold_factor;
     }
+    // Folding to fit (total > capacity): the full fingerprints cannot be resident as well, and copies made database by
+    // database would take the memory the plan counted on for the later databases' folded rows.  Folding on request
+    // (--gpu_bitcount) with room for everything: each database may keep them (decided per table at finalize, all
+    // storages or none).
+    plan.full_on_device = plan.fold_factor > 1 && total + total / plan.fold_factor <= capacity;
     return plan;
 }
 
@@ -164,7 +170,7 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
     std::fprintf(stderr, "Putting graphics card data up.\n");
     if (plan.fold_factor > 1) std::fprintf(stderr, "Folding databases by at least %u to fit in gpu memory\n", plan.fold_factor);
     if (ndevices == 1 && plan.ndevices == 0) std::fprintf(stderr, "Sharding every database over all GPUs (no single GPU holds the largest)\n");
-    for (auto& kv : m_databases) kv.second->copyToGPU(plan.fold_factor, plan.ndevices);
+    for (auto& kv : m_databases) kv.second->copyToGPU(plan.fold_factor, plan.ndevices, plan.full_on_device);
     std::fprintf(stderr, "Finished putting graphics card data up.\n");
     std::fprintf(stderr, "Ready for searches.\n");
 }

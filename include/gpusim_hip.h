@@ -92,6 +92,9 @@ typedef struct {
     uint64_t collectives;          /* searches (single queries or <= 256-query batches) merged through gsim_db_set_comm's route */
     double gather_ms_sum;          /* ... their all-gather: last shard kernel enqueued on the first shard's stream -> blocks gathered */
     double merge_ms_sum;           /* ... their merge_kernel                                                                  */
+    uint64_t blocks_rechecked;     /* since the handle was created: result blocks of the single launch whose checksum did not match
+                                      the hits when the header arrived in host memory (the hits were still on their way) ...   */
+    uint64_t blocks_torn;          /* ... and those that never matched: the query was re-run on the four-kernel pipeline      */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */
@@ -133,6 +136,11 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices);
  * Not needed on MI355X for capacity (288 GB hold 2.25 G unfolded 1024-bit rows). */
 int gsim_db_set_fold_factor(gsim_db* db, uint32_t fold_factor);
 uint32_t gsim_db_fold_factor(const gsim_db* db);
+/* Folded tables: may gsim_db_finalize also place the storages' FULL fingerprints in HBM, so that the candidates are
+ * re-scored on the GPU instead of on the host?  1 (default): yes, when all of them fit next to the folded rows and the
+ * search scratch with 2 GB to spare, on every device -- all storages or none; 0: never (callers that fold because the
+ * tables do NOT fit and still have tables to place, e.g. a server loading several databases).  Before gsim_db_finalize. */
+int gsim_db_set_fold_full_on_device(gsim_db* db, int allow);
 /* FoldFingerprintFunctorCPU (calculation_functors.cpp:22-41) for one fingerprint of
  * `words` 32-bit words: out receives words / fold_factor words (host function). */
 int gsim_fold_fingerprint(const uint32_t* fingerprint, uint32_t words, uint32_t fold_factor,
@@ -210,7 +218,9 @@ size_t gsim_result_block_bytes(uint32_t k);
 /* One query, single-shard handle: leaves {header; hits[k]} in device memory at
  * d_result (gsim_result_block_bytes(k) bytes), enqueued on the handle's stream,
  * no host synchronisation for any k (k > 8192: a radix select on the device finds
- * the k-th best key, nothing is sized by a count the host would have to read).
+ * the k-th best key, nothing is sized by a count the host would have to read) --
+ * except that the FIRST call with a k above the largest one seen so far allocates
+ * its buffers (hipMalloc synchronises the device once).
  * query is host memory (fp_bits/32 words). */
 int gsim_db_search_device(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff,
                           int metric, float alpha, float beta, void* d_result);

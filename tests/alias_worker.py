@@ -34,9 +34,17 @@ def main():
     assert sorted(set(seen)) == list(range(ndev)) and seen[:ndev] == seen[ndev:], seen
     for kind, n, W in ((0, 300_001, 32), (2, 1_200_003, 32), (0, 150_000, 64), (2, 70_001, 28)):
         db = O.synth_rows(0x5AAD + n, kind, 0, n, W)
-        for ndevices in (0, 3):
+        # both merge routes: on the host (the reference's, the default) and through the C-ABI collective (gsim_comm:
+        # every shard's block stays in HBM, all-gather, merge_kernel -- on aliased devices the gather is a loop-back of
+        # device-to-device copies, RCCL refuses two ranks on one GPU)
+        for ndevices, route in ((0, "host"), (3, "host"), (0, "comm"), (3, "comm")):
             t = capi.Table(W * 32).add_rows(db).finalize(0, ndevices)
             assert t.shard_count() == (ndev if ndevices == 0 else ndevices)
+            if route == "comm":
+                comm = capi.Comm(list(range(t.shard_count())))
+                assert comm.size() == t.shard_count()
+                t.set_comm(comm)
+                t.enable_timing(True)
             qs = np.stack([db[O.query_row(i, n)] for i in range(70)])
             for qi, (k, cutoff) in enumerate(((1000, 0.0), (10, 0.0), (1000, 0.2), (4096, 0.0), (9000, 0.0), (100, 0.55))):
                 hits, approx = t.search(qs[qi], k, cutoff)
@@ -51,6 +59,16 @@ def main():
                 for i in range(0, len(qs), 9):
                     want, wap = O.search(qs[i], db, 100, 0.0, nthreads=8, **kw)
                     same(bufs[0][i, :bufs[1][i]], bufs[2][i], want, wap, ("each" if each else "batch", kind, n, W, ndevices, i))
+            if route == "comm":
+                tm = t.timing()
+                assert tm["collectives"] in (6 + 70 + 1, 6 + 70 + 70) and tm["gather_ms_sum"] > 0 and tm["merge_ms_sum"] > 0, tm
+                t.set_comm(None)  # back to the host merge: same answer
+                hits, approx = t.search(qs[0], 1000, 0.0)
+                want, wap = O.search(qs[0], db, 1000, 0.0, nthreads=8)
+                same(hits[0], approx[0], want, wap, ("host after comm", kind, n, W, ndevices))
+                t.close()
+                comm.close()
+                continue
             t.close()
     # a folded table of three storages: one shard per add_rows slice, placed round robin (:184-194)
     n, W = 90_000, 32
@@ -60,6 +78,11 @@ def main():
         t.add_rows(db[lo:hi])
     t.set_fold_factor(4).finalize(-1, 1)
     assert t.shard_count() == 3
+    try:  # folded tables merge on the host: their re-score needs every storage's candidates
+        t.set_comm(capi.Comm([0, 1, 2]))
+        raise AssertionError("a folded table accepted a communicator")
+    except capi.GsimError:
+        pass
     for qi in range(4):
         q = db[O.query_row(qi, n)]
         hits, approx = t.search(q, 50, 0.0)

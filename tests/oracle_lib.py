@@ -113,6 +113,25 @@ def synth_rows(seed, kind, first_row, nrows, W):
     return out
 
 
+def synth_rows_mt(seed, kind, first_row, nrows, W, nthreads=None):
+    """synth_rows on several host threads (ctypes releases the GIL): the tables of the full-size parity tests are
+    10^8 .. 10^9 rows; every thread first-touches the pages of its own slice."""
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(nthreads or (os.cpu_count() or 1), 256, (nrows + 65535) // 65536))
+    out = np.empty((nrows, W), dtype=np.uint32)
+    per = (nrows + nthreads - 1) // nthreads
+    L = lib()
+
+    def work(t):
+        lo, hi = t * per, min(nrows, (t + 1) * per)
+        if lo < hi:
+            L.gso_synth_rows(_ptr(out[lo:hi], C.c_uint32), seed, kind, first_row + lo, hi - lo, W)
+
+    with ThreadPoolExecutor(nthreads) as ex:
+        list(ex.map(work, range(nthreads)))
+    return out
+
+
 def query_row(q, nrows):
     return int(lib().gso_query_row(q, nrows))
 

@@ -22,6 +22,44 @@ def test_in_process_multi_device_shards_on_aliased_devices():
     assert b"alias worker ok" in out.stdout
 
 
+def test_c_abi_collective_world_one_rccl():
+    """gsim_comm_create on the lease's one GPU is a real ncclCommInitAll (world 1): gsim_db_search through the collective
+    route -- block in HBM, ncclAllGather in place, merge_kernel into pinned memory -- equals the host route and the oracle,
+    single queries and a 70-query batch.  (World > 1 needs more GPUs than a lease has; the gather's slot layout and the
+    merge run at world 3 and 4 in the alias worker above through the loop-back gather.)"""
+    import numpy as np
+    import oracle_lib as O
+    from gpusimilarity_amd import capi
+    n, W = 2_000_003, 32
+    db = O.synth_rows_mt(0xC011EC7, 2, 0, n, W)
+    t = capi.Table(W * 32).add_rows(db).finalize(0, 1)
+    comm = capi.Comm([0])
+    assert comm.size() == 1
+    t.set_comm(comm)
+    t.enable_timing(True)
+    qs = np.stack([db[O.query_row(i, n)] for i in range(70)])
+    for qi, (k, cutoff) in enumerate(((1000, 0.0), (10, 0.0), (1000, 0.25), (9000, 0.0))):
+        hits, approx = t.search(qs[qi], k, cutoff)
+        want, wap = O.search(qs[qi], db, k, cutoff, nthreads=8)
+        assert int(approx[0]) == wap and (hits[0]["row"] == want["row"]).all()
+        assert (hits[0]["score"].view(np.uint32) == want["score"].view(np.uint32)).all()
+        assert (hits[0]["common"] == want["common"]).all() and (hits[0]["popc_db"] == want["popc_db"]).all()
+    bh, bap = t.search(qs, 100, 0.0)
+    for i in (0, 33, 69):
+        want, wap = O.search(qs[i], db, 100, 0.0, nthreads=8)
+        assert int(bap[i]) == wap and (bh[i]["row"] == want["row"]).all()
+        assert (bh[i]["score"].view(np.uint32) == want["score"].view(np.uint32)).all()
+    tm = t.timing()
+    assert tm["collectives"] == 5, tm
+    t.set_comm(None)
+    t.close()
+    comm.close()
+    with pytest.raises(capi.GsimError):
+        capi.Comm([0, 0])  # a device twice
+    with pytest.raises(capi.GsimError):
+        capi.Comm([5])     # not present on a one-GPU lease
+
+
 @pytest.mark.parametrize("gpus", ["4", "0"])
 def test_server_shards_over_aliased_devices(gpus, monkeypatch, tmp_path):
     """`gpusimserver --gpus N`: every table sharded over N (0 = all) devices, replies byte-identical to the golden frames."""

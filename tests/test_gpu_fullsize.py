@@ -9,10 +9,14 @@
   gsim_db_search_batch_device on every handle, gsim_merge_device_batch, against one 800 M-row handle.
 * bench.py --gpus 8 with eight self-spawned ranks sharing cuda:0 (125 M rows each, gloo).
 
-The oracle cannot scan a billion rows in seconds: beyond the equality of the two routes, the
-returned rows are regenerated on the CPU and rescored by the oracle, and self hit / canonical
-order / prefix properties are checked.  (fingerprintdb_cuda.cu:356-380 is the reference's
-fan-out + merge; its slices are ~8.4 M rows, :111-126.)
+Round 4: the billion rows are ALSO generated on the host (the oracle's generator on all host
+threads, 128 GB) and every query's full top-k -- rows, score bits, popcounts, approx -- is compared
+with the oracle's scan of all 10^9 rows; one shard's own block (row_base != 0, the per-GPU shape of
+configs[3]) is compared with the oracle's scan of that shard's rows.  A host without ~140 GB of
+free memory falls back to the properties the earlier rounds checked (equality of the two routes,
+returned rows regenerated and rescored by the oracle, self hit / canonical order / prefix).
+(fingerprintdb_cuda.cu:356-380 is the reference's fan-out + merge; its slices are ~8.4 M rows,
+:111-126.)
 """
 import json
 import os
@@ -53,6 +57,23 @@ def rescored_by_oracle(hits, q, kind, W, metric=0, alpha=0.0, beta=0.0):
         assert bits(np.float32(L.gso_score_one(metric, alpha, beta, a, b, c))) == bits(h["score"])
 
 
+def host_free_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def assert_block_equal(got, want, ctx):
+    assert len(got) == len(want), "%s: %d hits, oracle %d" % (ctx, len(got), len(want))
+    assert (got["row"] == want["row"]).all(), ctx
+    assert (bits(got["score"]) == bits(want["score"])).all(), ctx
+    assert (got["common"] == want["common"]).all() and (got["popc_db"] == want["popc_db"]).all(), ctx
+
+
 def need_free(nbytes):
     free = capi.device_free_bytes(0)
     if free < nbytes:
@@ -68,12 +89,21 @@ def test_configs3_one_billion_rows_eight_shards_equal_one_handle(kind):
     queries = [capi.synth_row(SEED, kind, O.query_row(i, total), W * 32) for i in range(3)]
     queries.append(O.synth_rows(0x5EED0002, 0, 77, 1, W)[0])  # a fresh fingerprint, not a row of the table
     cases = [(q, kk, cut) for q in queries for kk, cut in ((k, 0.0),)] + [(queries[0], 10, 0.0), (queries[1], k, 0.3)]
+    # ---- the oracle's copy of the table and its answers over ALL rows
+    nt = os.cpu_count() or 1
+    host = None
+    if host_free_bytes() > total * W * 4 + 16 * GIB:
+        host = O.synth_rows_mt(SEED, kind, 0, total, W, nt)
+        oracle = [O.search(q, host, kk, cut, nthreads=nt) for q, kk, cut in cases]
     # ---- one handle holds the whole table
     whole = capi.Table(W * 32).generate(SEED, kind, 0, total, 0)
     want = []
-    for q, kk, cut in cases:
+    for i, (q, kk, cut) in enumerate(cases):
         h, ap = whole.search(q, kk, cut)
         want.append((h[0], int(ap[0])))
+        if host is not None:
+            assert int(ap[0]) == oracle[i][1], "case %d" % i
+            assert_block_equal(h[0], oracle[i][0], "1 B rows, one handle, case %d" % i)
     h0, ap0 = want[0]
     assert ap0 == total and len(h0) == k
     # self hit (a Morgan-shaped table holds exact duplicates: the query's row is ONE of the rows scoring 1.0)
@@ -108,11 +138,16 @@ def test_configs3_one_billion_rows_eight_shards_equal_one_handle(kind):
         # every shard's own block: rows inside its range, canonical order
         raw = gathered.cpu().numpy().tobytes()
         for g in range(G):
-            hg, _, _ = capi.parse_result_block(raw[g * blk:(g + 1) * blk], kk)
+            hg, apg, _ = capi.parse_result_block(raw[g * blk:(g + 1) * blk], kk)
             assert len(hg) == 0 or (int(hg["row"].min()) >= g * per and int(hg["row"].max()) < (g + 1) * per)
             assert canonical_sorted(hg)
+            if host is not None and g in (3, 7):  # a shard's own answer (row_base != 0) against the oracle on ITS rows
+                ws, wsap = O.search(q, host[g * per:(g + 1) * per], kk, cut, row_base=g * per, nthreads=nt)
+                assert apg == wsap
+                assert_block_equal(hg, ws, "shard %d of 8" % g)
     for t in shards:
         t.close()
+    del host
 
 
 def test_configs4_batches_over_eight_shards_equal_one_handle():
@@ -130,6 +165,15 @@ def test_configs4_batches_over_eight_shards_equal_one_handle():
         assert int(wh[i]["row"][0]) == O.query_row(i, total) and wh[i]["score"][0] == np.float32(1.0)
         assert canonical_sorted(wh[i])
     rescored_by_oracle(np.concatenate([wh[7][:24], wh[7][-24:]]), qs[7], kind, W, 1, np.float32(0.3), np.float32(0.7))
+    # three of the batch's queries against the oracle's scan of ALL 800 M rows (205 GB on the host)
+    if host_free_bytes() > total * W * 4 + 16 * GIB:
+        nt = os.cpu_count() or 1
+        host = O.synth_rows_mt(SEED, kind, 0, total, W, nt)
+        for i in (0, 131, 255):
+            ws, wsap = O.search(qs[i], host, k, 0.0, nthreads=nt, **kw)
+            assert int(wap[i]) == wsap
+            assert_block_equal(wh[i], ws, "800 M x 2048-bit, batch query %d" % i)
+        del host
     # the shared pass against the single-query path on the same handle
     one, _ = whole.search(qs[200], k, 0.0, **kw)
     assert (one[0]["row"] == wh[200]["row"]).all() and (bits(one[0]["score"]) == bits(wh[200]["score"])).all()

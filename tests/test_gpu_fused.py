@@ -215,3 +215,43 @@ def test_four_kernel_pipeline_still_covers_ordinary_queries():
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+def test_result_block_checksum_and_the_torn_block_rerun():
+    """The single launch's pinned result block validates itself: the closing workgroup stores the sum of the
+    words of all hits with the header, the host checks it before it trusts the block.  GSIM_TEST_TORN_EVERY=5 (a test
+    hook, child process) makes every fifth check fail for good: those queries are re-run on the four-kernel pipeline --
+    with later queries of the same call already enqueued behind them -- and every result still equals the oracle's."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_lib as O
+from gpusimilarity_amd import capi
+n, W = 700_001, 32
+db = O.synth_rows_mt(0x70A2, 0, 0, n, W)
+t = capi.Table(1024).add_rows(db).finalize(0, 1)
+qs = np.ascontiguousarray(np.stack([db[O.query_row(i, n)] for i in range(40)]))
+for k in (100, 1000):
+    bufs = t.make_search_buffers(len(qs), k)
+    t.search_each_into(qs, k, bufs)            # pipelined: eight in flight
+    for i in range(len(qs)):
+        want, wap = O.search(qs[i], db, k, 0.0, nthreads=8)
+        got = bufs[0][i, :bufs[1][i]]
+        assert int(bufs[2][i]) == wap and (got["row"] == want["row"]).all(), (k, i)
+        assert (got["score"].view(np.uint32) == want["score"].view(np.uint32)).all()
+        assert (got["common"] == want["common"]).all() and (got["popc_db"] == want["popc_db"]).all()
+    h, ap = t.search(qs[3], k, 0.0)             # one at a time
+    want, wap = O.search(qs[3], db, k, 0.0, nthreads=8)
+    assert (h[0]["row"] == want["row"]).all()
+tm = t.timing()
+print("torn", tm["blocks_torn"], "rechecked", tm["blocks_rechecked"])
+assert tm["blocks_torn"] == int(os.environ.get("WANT_TORN", "0")), tm
+t.close()
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    for hook, want_torn in (("5", 16), ("0", 0)):
+        env = dict(os.environ, GSIM_TEST_TORN_EVERY=hook, WANT_TORN=str(want_torn))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+        assert out.returncode == 0, out.stdout.decode()[-1500:] + out.stderr.decode()[-3000:]
