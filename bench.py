@@ -26,9 +26,11 @@ reference's own numbers are quoted on), and `cpu_baseline`: the reference's host
 import argparse
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -169,10 +171,61 @@ def cpu_baseline(fp_bits, k, kind):
 
 
 # ---------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel from the PMC counters (MI355X_MICROARCH.md "HBM" / "rocprofv3 PMC slots")
+# ---------------------------------------------------------------------------------------------
+
+def pmc_child(rows, fp_bits, kind, k):
+    """`bench.py --pmc-child`: the table, six single queries through the synchronous C ABI, nothing else -- the run
+    rocprofv3 counts (one counter pass per process: FETCH_SIZE and WRITE_SIZE do not fit one pass)."""
+    from gpusimilarity_amd import capi
+    t = capi.Table(fp_bits)
+    t.generate(DB_SEED, kind, 0, rows, 0)
+    bufs = t.make_search_buffers(1, k)
+    for i in range(6):
+        t.search_into(np.ascontiguousarray(synth_row(DB_SEED, kind, query_row(i, rows), fp_bits // 32)).reshape(1, -1), k, bufs)
+    t.close()
+
+
+def pmc_traffic(rows, fp_bits, kind_name, k, kernel_substr):
+    """-> (bytes read from HBM per launch, bytes written, note).  Separate `rocprofv3 --kernel-trace --pmc` passes of a
+    child of this script; FETCH_SIZE is reported in KiB and, on gfx950, counts a 16 B/lane streaming read at half its
+    bytes (128-B requests tallied at 64 B): doubled, as the guide prescribes.  WRITE_SIZE is uncalibrated (reported as is)."""
+    import csv
+    import glob
+    if shutil.which("rocprofv3") is None:
+        return None, None, "rocprofv3 is not on PATH"
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gsim_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--output-format", "csv", "--kernel-trace", "--pmc", counter, "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--rows-per-gpu", str(rows), "--fp-bits", str(fp_bits), "--kind", kind_name,
+                   "--k", str(k)]
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=600)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if p.returncode != 0 or not vals:
+                return None, None, "rocprofv3 --pmc %s failed (rc %d, %d launches seen): %s" % (
+                    counter, p.returncode, len(vals), p.stderr.decode("utf-8", "replace")[-300:])
+            res[counter] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch = res["FETCH_SIZE"][0] * 1024.0 * 2.0
+    write = res["WRITE_SIZE"][0] * 1024.0
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes of a child process (%d launches each); "
+            "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies the 128-B requests of a 16 B/lane streaming read at 64 B); "
+            "WRITE_SIZE [KiB] x 1024, uncalibrated" % res["FETCH_SIZE"][1])
+    return fetch, write, note
+
+
+# ---------------------------------------------------------------------------------------------
 # GPU runs
 # ---------------------------------------------------------------------------------------------
 
-def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps, sharded):
+def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps, sharded, barrier=True, first_row=0):
     """steps x qps single queries (after warmup x qps), barrier + synchronize on both sides, max over ranks."""
     import torch
     import torch.distributed as dist
@@ -180,11 +233,13 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
     W = fp_bits // 32
     nq = (warmup + steps) * qps
     distinct = min(nq, 64)  # distinct queries, cycled
-    queries = [synth_row(DB_SEED, kind, query_row(i, total_rows), W) for i in range(distinct)]
+    queries = [synth_row(DB_SEED, kind, first_row + query_row(i, total_rows), W) for i in range(distinct)]
     bufs = table.make_search_buffers(qps, k)
-    # two gather+merge objects on the one stream: while the host waits for query i's hits, query i + 1's local search,
-    # all-gather and merge are already enqueued behind it (each object has its own blocks and completion event)
-    pair = [ShardedSearch(table, k, ctx["dev"], stream=ctx["stream"]) for _ in range(2)] if sharded else None
+    # eight gather+merge objects on the one stream, as many as the N = 1 path keeps enqueued: while the host waits for
+    # query i's hits, the local search, all-gather and merge of queries i + 1 ... i + 7 are already enqueued behind it
+    # (each object has its own blocks and completion event)
+    depth = 8
+    pair = [ShardedSearch(table, k, ctx["dev"], stream=ctx["stream"]) for _ in range(depth)] if sharded else None
     ss = pair[0] if sharded else None
     last = [ss]
     steps_q = [np.ascontiguousarray(np.stack([queries[(s_ * qps + j) % distinct] for j in range(qps)])) for s_ in range(warmup + steps)]
@@ -197,15 +252,16 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
             # next one is launched when they are there; no Python between the queries
             table.search_each_into(steps_q[s_], k, bufs)
             return
-        pending = None
+        pending = []
         for j in range(qps):
-            cur = pair[j & 1]
+            cur = pair[j % depth]
+            if len(pending) == depth:
+                pending.pop(0).synchronize()  # a query is done when its k hits are in host memory
             cur.enqueue(steps_q[s_][j])  # local top-k -> all-gather (k*12+16 B per GPU) -> rank merge -> D2H
-            if pending is not None:
-                pending.synchronize()  # a query is done when its k hits are in host memory
-            pending = cur
-        pending.synchronize()
-        last[0] = pending
+            pending.append(cur)
+        for cur in pending:
+            cur.synchronize()
+        last[0] = pending[-1]
 
     for s_ in range(warmup):
         one_step(s_)
@@ -214,20 +270,23 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
             hits, approx, _ = last[0].result()
         else:
             hits, approx = bufs[0][qps - 1, :bufs[1][qps - 1]], int(bufs[2][qps - 1])
-        want_row = query_row((warmup * qps - 1) % distinct, total_rows)
+        want_row = first_row + query_row((warmup * qps - 1) % distinct, total_rows)
         # (Morgan-shaped tables hold exact duplicates: the query's own row is one of the rows scoring 1.0)
         assert len(hits) == min(k, total_rows) and hits["score"][0] == 1.0 and want_row in hits["row"][hits["score"] == 1.0], \
             "self hit missing: %r" % (hits[:3],)
         assert approx == total_rows
     table.enable_timing(True)
+    if sharded:
+        for o in pair:
+            o.enable_phase_timing(True)
     torch.cuda.synchronize()
-    if dist.is_initialized():
+    if dist.is_initialized() and barrier:
         dist.barrier()
     t0 = time.perf_counter()
     for s_ in range(warmup, warmup + steps):
         one_step(s_)
     torch.cuda.synchronize()
-    if dist.is_initialized():
+    if dist.is_initialized() and barrier:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if ctx["world"] > 1:
@@ -236,13 +295,38 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
         elapsed = float(t.item())
     tm = table.timing()
     table.enable_timing(False)
+    phases = None
+    if sharded:  # this rank's mean stream time per query and phase (HIP events around each step of ShardedSearch.enqueue)
+        ph = [o.phases() for o in pair if o.phases()]
+        ntot = sum(p_["n"] for p_ in ph)
+        if ntot:
+            phases = {key: sum(p_[key] * p_["n"] for p_ in ph) / ntot for key in ("search_ms", "gather_us", "merge_us", "d2h_us")}
+            phases["queries"] = ntot
+        for o in pair:
+            o.enable_phase_timing(False)
+    # SURVEY 8(d)'s latency: wall time from query-on-host to top-k-on-host, ONE query at a time through gsim_db_search
+    # (nothing enqueued ahead, unlike the timed region above), median and p95 of >= 200 calls
+    sync = None
+    if not sharded:
+        b1 = table.make_search_buffers(1, k)
+        lat = []
+        nlat = 200 if R * fp_bits <= 100_000_000 * 1024 else 50
+        for j in range(nlat + 20):
+            q1 = queries[j % distinct].reshape(1, -1)
+            t1 = time.perf_counter()
+            table.search_into(q1, k, b1)
+            if j >= 20:
+                lat.append(time.perf_counter() - t1)
+        lat.sort()
+        sync = {"calls": len(lat), "sync_ms_median": 1e3 * lat[len(lat) // 2], "sync_ms_p95": 1e3 * lat[int(len(lat) * 0.95)],
+                "sync_ms_min": 1e3 * lat[0]}
     n = max(1, tm["queries"])  # queries timed with HIP events (the first 1024 of the timed region)
     nall = max(1, steps * qps)  # queries the device-side totals cover (all of the timed region)
     kernel_ms = tm["scan_ms_sum"] / n
     algo = R * (fp_bits // 8)  # bytes per launch of the dominant kernel on one GPU
     achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     res = {
-        "seconds": elapsed, "queries": steps * qps, "ms_per_query": 1e3 * elapsed / (steps * qps),
+        "seconds": elapsed, "queries": steps * qps, "ms_per_query": 1e3 * elapsed / (steps * qps), "sync_latency": sync, "phases": phases,
         "fingerprints_per_s": total_rows * steps * qps / elapsed,
         "whole_path_hbm_frac": (total_rows * (fp_bits // 8) / (elapsed / (steps * qps))) / (HBM_PEAK_GBS * 1e9 * ctx["world"]),
         "roofline": {
@@ -250,8 +334,7 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
                       "scan_kernel<%d,8>" % (W // 4),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "traffic_note": "HBM bytes per launch from PMC counters are collected by separate rocprofv3 --pmc passes "
-                            "(profiles/); bench.py cannot run them",
+            "traffic_note": "not collected for this entry (the headline entry runs the rocprofv3 --pmc passes)",
             "kernel_ms_avg": kernel_ms, "other_kernels_ms_avg": tm["select_ms_sum"] / n,
             "algorithmic_bytes_per_launch": algo,
             "candidates_per_query": tm["candidates_sum"] / nall, "finalists_per_query": tm["finalists_sum"] / nall,
@@ -348,10 +431,15 @@ def main():
     ap.add_argument("--batch-queries", type=int, default=0,
                     help="BASELINE configs[4] instead of the headline run: Tversky(0.3, 0.7) batches of this many "
                          "queries per step (use with --fp-bits 2048); a step is one batch")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: the process rocprofv3 counts (pmc_traffic)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="run the N>1 code path (device result blocks, all-gather, device merge) even at N=1")
     args = ap.parse_args()
 
+    if args.pmc_child:
+        pmc_child(args.rows_per_gpu or 100_000_000, args.fp_bits, {"sparse": 0, "dense": 1, "morgan": 2}[args.kind], args.k)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))  # no launcher: start the ranks ourselves
 
@@ -441,19 +529,48 @@ def main():
 
     qps = max(1, args.queries_per_step)
     res, _ss = time_queries(ctx, table, total_rows, R, args.fp_bits, kind, k, args.steps, args.warmup, qps, sharded)
+    if sharded:
+        # what each rank's own phases cost (HIP events on its stream) and -- the N = 1 twin -- what the same shard answers
+        # alone through the synchronous single-GPU path: the 1 -> N curve then decomposes into scan / gather / merge / copy
+        table.set_stream(0)  # back to the handle's own stream
+        table.set_row_base(rank * R)
+        tw, _ = time_queries(dict(ctx, world=1), table, R, R, args.fp_bits, kind, k, 2, 1, min(qps, 64), False, barrier=False, first_row=rank * R)
+        mine = {"rank": rank, "phases_per_query": res["phases"],
+                "single_gpu_twin": {"rows": R, "ms_per_query": tw["ms_per_query"], "fingerprints_per_s": tw["fingerprints_per_s"],
+                                    "kernel_ms_avg": tw["roofline"]["kernel_ms_avg"]}}
+        per_rank = [mine]
+        if dist.is_initialized() and world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        collective["per_rank"] = per_rank
+        collective["queries_in_flight"] = 8
     table.close()
+    if world == 1 and not sharded and not args.no_pmc and res["roofline"]["kernel"].startswith("fused_kernel"):
+        try:
+            fetch, write, note = pmc_traffic(R, args.fp_bits, args.kind, k, "fused_kernel")
+        except Exception as e:  # a report, never a reason to lose the headline
+            fetch, write, note = None, None, "pmc passes failed: %r" % (e,)
+        res["roofline"]["traffic"] = fetch
+        res["roofline"]["traffic_written"] = write
+        res["roofline"]["traffic_note"] = note
+        if fetch:
+            res["roofline"]["traffic_over_algorithmic"] = fetch / res["roofline"]["algorithmic_bytes_per_launch"]
     headline_cfg = {
         "name": ("BASELINE configs[2]: 100M x 1024-bit, Tanimoto top-1000, 1 MI355X" if world == 1 and R == 100_000_000 and
                  args.fp_bits == 1024 and k == 1000 else "headline"),
         "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "ms_per_query": res["ms_per_query"],
         "ms_per_step": res["ms_per_query"] * qps, "value": res["fingerprints_per_s"], "unit": "fingerprints/s",
         "timed_region_s": res["seconds"], "whole_path_hbm_frac": res["whole_path_hbm_frac"], "roofline": res["roofline"]}
+    if res["sync_latency"]:
+        headline_cfg.update(res["sync_latency"])
     out = {
         "timed_region_s": res["seconds"],
         "metric": "fingerprints scanned/sec (1024-bit Tanimoto top-1000)",
         "value": res["fingerprints_per_s"], "unit": "fingerprints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_query"] * qps, "queries_per_step": qps, "ms_per_query": res["ms_per_query"],
+        "ms_per_query_note": "mean over the timed region, up to 8 queries enqueued ahead of the one being waited for; sync_ms_* = one "
+                             "gsim_db_search call at a time, query on the host -> hits on the host (SURVEY 8d's latency)",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {
@@ -469,14 +586,16 @@ def main():
             "query_execution": ("one query at a time on the GPU; gsim_db_search_each keeps up to 8 of the step's queries "
                                 "enqueued ahead (own result block each), no query shares a table pass with another"
                                 if not sharded else
-                                "one query at a time on every GPU: local search, all-gather, merge, D2H; the next query's are "
-                                "enqueued behind it while the host waits for this one's hits (two in flight; the N = 1 line keeps 8 "
-                                "and holds 100 M rows per GPU, this one %d M: compare per-GPU rates, not ms/query)" % (R // 1_000_000)),
+                                "one query at a time on every GPU: local search, all-gather, merge, D2H; up to 8 queries' steps are "
+                                "enqueued ahead of the one the host waits for, as at N = 1 (which holds 100 M rows per GPU, this line "
+                                "%d M: collective.per_rank has each rank's phase times and its shard's single-GPU twin)" % (R // 1_000_000)),
         },
         "whole_path_hbm_frac": res["whole_path_hbm_frac"],
         "roofline": res["roofline"],
         "collective": collective,
     }
+    if res["sync_latency"]:
+        out.update(res["sync_latency"])
     if world == 1 and not args.no_configs and not sharded:
         # the other single-GPU BASELINE configs, measured in this run, each with its own dominant-kernel roofline
         cfgs = []
@@ -489,6 +608,8 @@ def main():
                  "ms_per_step": r["ms_per_query"] * qps_, "queries_per_step": qps_, "value": r["fingerprints_per_s"],
                  "unit": "fingerprints/s", "timed_region_s": r["seconds"], "whole_path_hbm_frac": r["whole_path_hbm_frac"],
                  "roofline": r["roofline"]}
+            if r["sync_latency"]:
+                c.update(r["sync_latency"])
             if note:
                 c["note"] = note
             return c

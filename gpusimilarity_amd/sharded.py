@@ -70,6 +70,36 @@ class _Gather:
             self.table.set_stream(self.stream.cuda_stream)  # every later enqueue is ordered on self.stream
         self.kw = dict(search_kwargs or {})
         self.local_search = local if self.table is None else None
+        # optional per-phase timing (enable_phase_timing): HIP events on self.stream around the local search, the
+        # all-gather, the merge and the copy to the host -- read back when the result is waited for
+        self.phase_events = None
+        self.phase_ms = [0.0, 0.0, 0.0, 0.0]
+        self.phase_n = 0
+        self._phase_pending = False
+
+    def enable_phase_timing(self, on=True):
+        """Accumulate, per enqueue, the stream time of {local search, all-gather, merge, copy to host} (GPU only)."""
+        if on and self.on_gpu and self.phase_events is None:
+            self.phase_events = [self.torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        if not on:
+            self.phase_events = None
+        self.phase_ms = [0.0, 0.0, 0.0, 0.0]
+        self.phase_n = 0
+        self._phase_pending = False
+
+    def _mark(self, i):
+        if self.phase_events is not None:
+            self.phase_events[i].record(self.stream)
+            if i == 4:
+                self._phase_pending = True
+
+    def phases(self):
+        """Mean stream time per enqueue: {"search_ms", "gather_us", "merge_us", "d2h_us", "n"} (None: timing off)."""
+        if self.phase_events is None or self.phase_n == 0:
+            return None
+        n = self.phase_n
+        return {"search_ms": self.phase_ms[0] / n, "gather_us": 1e3 * self.phase_ms[1] / n, "merge_us": 1e3 * self.phase_ms[2] / n,
+                "d2h_us": 1e3 * self.phase_ms[3] / n, "n": n}
 
     def _stream_ctx(self):
         if self.on_gpu:
@@ -93,6 +123,12 @@ class _Gather:
         """Wait until the last enqueued result of this object is in host memory."""
         if self.on_gpu:
             self.done.synchronize()
+            if self._phase_pending:
+                ev = self.phase_events
+                for i in range(4):
+                    self.phase_ms[i] += ev[i].elapsed_time(ev[i + 1])
+                self.phase_n += 1
+                self._phase_pending = False
 
     def describe(self):
         """Facts about this rank's place in the group (bench.py puts them into its JSON line)."""
@@ -135,15 +171,20 @@ class ShardedSearch(_Gather):
         """Local search, all-gather, merge; on a GPU everything is ordered on self.stream and
         (with the nccl backend) nothing here waits for the host."""
         with self._stream_ctx():
+            self._mark(0)
             if self.table is not None:
                 self.table.search_device(query, self.k, self.local.data_ptr(), **self.kw)
             else:
                 self.local_search(query, self.k, self.local)
+            self._mark(1)
             self._all_gather(self.gathered, self.local, self.h_local, self.h_gathered)
+            self._mark(2)
             if self.on_gpu:
                 capi.merge_device(self.device.index or 0, self.stream.cuda_stream, self.gathered.data_ptr(),
                                   self.world, self.blk, self.k, self.merged.data_ptr())
+                self._mark(3)
                 self.host_out.copy_(self.merged, non_blocking=True)
+                self._mark(4)
                 self.done.record(self.stream)
             else:
                 out = capi.merge_host(self.gathered.numpy().tobytes(), self.world, self.blk, self.k)
@@ -191,17 +232,22 @@ class ShardedBatchSearch(_Gather):
         n = self.blk * nq
         with self._stream_ctx():
             local = self.local[:n]
+            self._mark(0)
             if self.table is not None:
                 self.table.search_batch_device(queries, self.k, local.data_ptr(), **self.kw)
             else:
                 self.local_search(queries, self.k, local)
+            self._mark(1)
             gathered = self.gathered[:n * self.world]
             self._all_gather(gathered, local, self.h_local[:n] if self.staged else None,
                              self.h_gathered[:n * self.world] if self.staged else None)
+            self._mark(2)
             if self.on_gpu:
                 capi.merge_device_batch(self.device.index or 0, self.stream.cuda_stream, gathered.data_ptr(),
                                         self.world, nq, self.blk, self.k, self.merged.data_ptr())
+                self._mark(3)
                 self.host_out[:n].copy_(self.merged[:n], non_blocking=True)
+                self._mark(4)
                 self.done.record(self.stream)
             else:
                 raw = gathered.numpy().tobytes()

@@ -959,3 +959,19 @@ def test_bench_contract_lines():
         assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "workload" in d["config"]
         assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["peak"] > 0
         assert d["collective"]["world"] == 1 and d["collective"]["ranks"][0]["rank"] == 0
+        if "--batch-queries" in extra:
+            continue
+        if "--force-sharded-path" in extra:
+            # the N > 1 line decomposes: this rank's phase times by HIP events, its shard's single-GPU twin
+            pr = d["collective"]["per_rank"][0]
+            assert set(pr["phases_per_query"]) >= {"search_ms", "gather_us", "merge_us", "d2h_us"} and pr["phases_per_query"]["search_ms"] > 0
+            assert pr["single_gpu_twin"]["ms_per_query"] > 0 and d["collective"]["queries_in_flight"] == 8
+        else:
+            # SURVEY 8(d)'s latency next to the pipelined mean, and the PMC traffic of the dominant kernel in the line itself
+            assert d["sync_ms_median"] > 0 and d["sync_ms_p95"] >= d["sync_ms_median"] and d["calls"] >= 50
+            import shutil
+            if shutil.which("rocprofv3"):
+                rf = d["roofline"]
+                assert rf["traffic"] is not None, rf["traffic_note"]
+                # (400 k rows = 51 MB: the table fits the 256 MB Infinity Cache, whose hits the counter includes; the bound is loose)
+                assert 0.5 * rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.5 * rf["algorithmic_bytes_per_launch"], rf
