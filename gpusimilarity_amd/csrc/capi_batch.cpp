@@ -17,8 +17,10 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         if (nw > nchunks) nw = nchunks ? nchunks : 1;
         nw = (nw + 3) / 4 * 4;
         s.bgeo.nwaves = static_cast<uint32_t>(nw);
-        // candidate slots per wave: the worst case (every pair a candidate) when that is small,
-        // else 64 Ki entries; a wave that needs more sets the overflow flag and the host falls back
+        // candidate slots per wave: the worst case (every pair a candidate) when that is small, else 4 Ki entries to start
+        // with (134 MB for a 256-CU grid; round 3 allocated the 64 Ki worst case up front: ~2.1 GB): a wave that needs more
+        // reports how many (flags[15]) and the host grows the segments -- up to 64 Ki -- and runs the batch again
+        // (run_batch); only beyond that do the queries fall back to the single-query path
         const uint64_t rows_per_wave = ((nchunks + nw - 1) / nw) * 64 + 256; // chunks are 64 x (1..4) rows
         uint64_t cap = rows_per_wave * gsim::kBQ;
         // a wave of the matrix-core pass meets 32 queries and every row of its workgroup
@@ -30,7 +32,11 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         const uint64_t lim = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP", 65536));
         if (cap > lim) cap = lim;
         if (cap < 256) cap = 256;
+        s.bseg_max = static_cast<uint32_t>(cap);
+        const uint64_t init = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP_INIT", 4096));
+        if (cap > init) cap = init < 256 ? 256 : init;
         s.bseg_cap = static_cast<uint32_t>(cap);
+        s.bseg_waves = static_cast<uint32_t>(nw);
         const size_t slots = static_cast<size_t>(nw) * cap;
         GSIM_HIP(hipMalloc(&s.d_bqueries, static_cast<size_t>(kBatchMaxQ) * s.W * 4));
         GSIM_HIP(hipMalloc(&s.d_bqpop, kBatchMaxQ * 4));
@@ -161,6 +167,79 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     return GSIM_OK;
 }
 
+// A candidate segment overflowed (flags bit 0; flags[15] = the most slots a wave asked for): larger segments, up to the
+// worst case the first allocation was spared.  false: already there.
+static int grow_batch_segments(Shard& s, uint32_t wanted, bool* grown)
+{
+    *grown = false;
+    if (s.bseg_cap >= s.bseg_max) return GSIM_OK;
+    uint64_t cap = s.bseg_cap;
+    const uint64_t target = static_cast<uint64_t>(wanted) + wanted / 4 + 64; // (thresholds move a little from run to run)
+    while (cap < target && cap < s.bseg_max) cap *= 2;
+    if (cap <= s.bseg_cap) cap = static_cast<uint64_t>(s.bseg_cap) * 2;
+    if (cap > s.bseg_max) cap = s.bseg_max;
+    GSIM_HIP(set_device(s.device));
+    GSIM_HIP(hipStreamSynchronize(s.stream));
+    GSIM_HIP(hipFree(s.d_bcand));
+    GSIM_HIP(hipFree(s.d_bcand_cb));
+    GSIM_HIP(hipFree(s.d_bcand_q));
+    s.d_bcand = nullptr, s.d_bcand_cb = nullptr, s.d_bcand_q = nullptr;
+    const size_t slots = static_cast<size_t>(s.bseg_waves) * cap;
+    GSIM_HIP(hipMalloc(&s.d_bcand, slots * 8));
+    GSIM_HIP(hipMalloc(&s.d_bcand_cb, slots * 4));
+    GSIM_HIP(hipMalloc(&s.d_bcand_q, slots * 4));
+    s.bseg_cap = static_cast<uint32_t>(cap);
+    *grown = true;
+    return GSIM_OK;
+}
+
+// nb <= kBatchMaxQ queries on every shard at once (shard i's result blocks: out_of(i), device memory, or nullptr = the
+// shard's pinned host array), then -- per shard -- what has to be repeated: a dense cutoff without a usable band goes to
+// the VALU pass, a batch whose candidates overflowed a segment runs again with larger segments.  On return every shard's
+// stream is idle and s.h_bflags[0] says what is left for the caller (bit 0: overflow at the largest segments, bit 2:
+// too many ties for the multi-query select).
+int run_batch(gsim_db* db, const uint32_t* qb, uint32_t nb, uint32_t k, float cutoff, int metric, float alpha, float beta,
+              const std::vector<void*>& outs)
+{
+    const size_t n = db->shards.size();
+    std::vector<char> allow(n, 1), todo(n, 1);
+    for (int round = 0; round < 8; round++) {
+        bool any = false;
+        for (size_t i = 0; i < n; i++) {
+            Shard& s = db->shards[i];
+            if (!todo[i] || s.nrows == 0) continue;
+            const int rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, db->row_base + static_cast<uint32_t>(s.first_row),
+                                         outs[i], allow[i] != 0);
+            if (rc != GSIM_OK) return rc;
+            any = true;
+        }
+        if (!any) break;
+        for (size_t i = 0; i < n; i++) {
+            Shard& s = db->shards[i];
+            if (!todo[i] || s.nrows == 0) continue;
+            todo[i] = 0;
+            GSIM_HIP(set_device(s.device));
+            int rc = wait_stream(s.stream);
+            if (rc != GSIM_OK) return rc;
+            const uint32_t fl = s.h_bflags[0];
+            if (fl & 16u) db->dense_batches++; // (the matrix-core pass counted a dense cutoff itself)
+            if ((fl & 24u) == 8u && allow[i]) { // the cutoff keeps too many rows for the exact path and has no band: VALU pass
+                allow[i] = 0;
+                todo[i] = 1;
+            } else if (fl & 1u) {
+                bool grown = false;
+                rc = grow_batch_segments(s, s.h_bflags[15], &grown);
+                if (rc != GSIM_OK) return rc;
+                if (grown) {
+                    db->batch_regrown++;
+                    todo[i] = 1;
+                }
+            }
+        }
+    }
+    return GSIM_OK;
+}
+
 // gsim_db_search with nq >= 4 on a batch-capable width: per 256 queries one enqueue per shard, one wait, host merge
 // across shards; queries the shared pass could not finish (heavy ties, candidate overflow) go through search_one.
 int search_batched(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff, int metric, float alpha,
@@ -174,34 +253,11 @@ int search_batched(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         const uint32_t nb = std::min<uint32_t>(kBatchMaxQ, nq - base);
         const uint32_t* qb = queries + static_cast<size_t>(base) * db->W;
         std::vector<char> redo(nb, 0);
+        rc = run_batch(db, qb, nb, k, cutoff, metric, alpha, beta, std::vector<void*>(db->shards.size(), nullptr));
+        if (rc != GSIM_OK) return rc;
+        bool overflow = false;
         for (auto& s : db->shards) {
             if (s.nrows == 0) continue;
-            rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta,
-                               db->row_base + static_cast<uint32_t>(s.first_row), nullptr);
-            if (rc != GSIM_OK) return rc;
-        }
-        bool overflow = false, dense_cutoff = false;
-        for (auto& s : db->shards) {
-            if (s.nrows == 0) continue;
-            GSIM_HIP(set_device(s.device));
-            rc = wait_stream(s.stream);
-            if (rc != GSIM_OK) return rc;
-            if ((s.h_bflags[0] & 24u) == 8u) dense_cutoff = true; // (8: a dense cutoff; 16: the matrix-core pass counted it itself)
-            if (s.h_bflags[0] & 16u) db->dense_batches++;
-        }
-        if (dense_cutoff) { // the cutoff keeps too many rows for the matrix-core pass: VALU pass
-            for (auto& s : db->shards) {
-                if (s.nrows == 0) continue;
-                rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta,
-                                   db->row_base + static_cast<uint32_t>(s.first_row), nullptr, false);
-                if (rc != GSIM_OK) return rc;
-            }
-        }
-        for (auto& s : db->shards) {
-            if (s.nrows == 0) continue;
-            GSIM_HIP(set_device(s.device));
-            rc = wait_stream(s.stream);
-            if (rc != GSIM_OK) return rc;
             if (s.h_bflags[0] & 1u) overflow = true;
             if (std::getenv("GSIM_DEBUG_BATCH")) { // counters of instrumented builds (GSIM_MF_TIMING)
                 std::fprintf(stderr, "batch flags %u dbg", s.h_bflags[0]);
@@ -248,20 +304,10 @@ int batch_to_device(gsim_db* db, Shard& s, const uint32_t* qb, uint32_t nb, uint
                     float beta, uint32_t row_base, unsigned char* out)
 {
     const size_t blk = gsim_result_block_bytes(k);
-    int rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, row_base, out);
+    // (a single-shard handle: row_base is the handle's) the one host synchronisation of a batch: did a query overflow its
+    // candidate segment at the largest size, or collect too many ties for the multi-query select (bit 2)?
+    int rc = run_batch(db, qb, nb, k, cutoff, metric, alpha, beta, std::vector<void*>(1, out));
     if (rc != GSIM_OK) return rc;
-    // the one host synchronisation of a batch: did a query overflow its candidate segment or
-    // collect too many ties for the multi-query select (bit 2, set by batch_select_kernel)?
-    GSIM_HIP(set_device(s.device));
-    rc = wait_stream(s.stream);
-    if (rc != GSIM_OK) return rc;
-    if (s.h_bflags[0] & 16u) db->dense_batches++;
-    if ((s.h_bflags[0] & 24u) == 8u) { // the cutoff keeps too many rows for the exact path and has no band: VALU pass
-        rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, row_base, out, false);
-        if (rc != GSIM_OK) return rc;
-        rc = wait_stream(s.stream);
-        if (rc != GSIM_OK) return rc;
-    }
     if ((s.h_bflags[0] & 5u) != 0) { // those cases are rare: the whole chunk goes through the single-query pipeline
         for (uint32_t q = 0; q < nb; q++) {
             rc = enqueue_query(db, s, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta, row_base, out + q * blk, false);

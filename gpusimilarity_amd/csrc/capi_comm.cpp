@@ -45,6 +45,7 @@ int ensure_gather(gsim_db* db, size_t per_shard)
             s.d_gather = nullptr;
             s.gather_bytes = 0;
             GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_gather), need));
+            GSIM_HIP(hipMemset(s.d_gather, 0, need)); // (a shard without rows never writes its slots: they read as empty blocks)
             s.gather_bytes = need;
         }
         if (!s.gather_ev) GSIM_HIP(hipEventCreateWithFlags(&s.gather_ev, hipEventDisableTiming));
@@ -186,31 +187,20 @@ int search_batch_comm(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_
             GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s0.d_merged), per));
             s0.merged_bytes = per;
         }
-        for (size_t i = 0; i < n; i++) { // all shards scan at once ...
+        // all shards scan at once; each says whether its pass could finish every query (run_batch repeats what it can)
+        std::vector<void*> outs(n);
+        for (size_t i = 0; i < n; i++) outs[i] = db->shards[i].d_gather + i * per;
+        rc = run_batch(db, qb, nb, k, cutoff, metric, alpha, beta, outs);
+        if (rc != GSIM_OK) return rc;
+        for (size_t i = 0; i < n; i++) {
             Shard& s = db->shards[i];
-            rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, db->row_base + static_cast<uint32_t>(s.first_row),
-                               s.d_gather + i * per);
-            if (rc != GSIM_OK) return rc;
-        }
-        for (size_t i = 0; i < n; i++) { // ... and each says whether its pass could finish every query
-            Shard& s = db->shards[i];
-            GSIM_HIP(set_device(s.device));
-            rc = wait_stream(s.stream);
-            if (rc != GSIM_OK) return rc;
+            if (s.nrows == 0 || (s.h_bflags[0] & 5u) == 0) continue;
+            // heavy ties / candidate overflow at the largest segments: this shard's chunk through the single-query pipeline
             const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
-            if (s.h_bflags[0] & 16u) db->dense_batches++;
-            if ((s.h_bflags[0] & 24u) == 8u) { // a dense cutoff without a usable band: the VALU pass
-                rc = enqueue_batch(db, s, qb, nb, k, cutoff, metric, alpha, beta, row_base, s.d_gather + i * per, false);
+            for (uint32_t q = 0; q < nb; q++) {
+                rc = enqueue_query(db, s, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta, row_base,
+                                   s.d_gather + i * per + q * blk, false);
                 if (rc != GSIM_OK) return rc;
-                rc = wait_stream(s.stream);
-                if (rc != GSIM_OK) return rc;
-            }
-            if ((s.h_bflags[0] & 5u) != 0) { // heavy ties / candidate overflow: this shard's chunk through the single-query pipeline
-                for (uint32_t q = 0; q < nb; q++) {
-                    rc = enqueue_query(db, s, qb + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta, row_base,
-                                       s.d_gather + i * per + q * blk, false);
-                    if (rc != GSIM_OK) return rc;
-                }
             }
         }
         GSIM_HIP(set_device(s0.device));

@@ -174,6 +174,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
     db->acc.batches_dense_cutoff = db->dense_batches;
     db->acc.blocks_rechecked = db->blocks_rechecked;
     db->acc.blocks_torn = db->blocks_torn;
+    db->acc.batches_regrown = db->batch_regrown;
     *out = db->acc;
     return GSIM_OK;
 }

@@ -132,7 +132,8 @@ struct Shard {
     // multi-query batches (allocated on first use)
     gsim::ScanGeometry bgeo{};
     uint32_t bq_cap = 0;          // queries the batch buffers hold
-    uint32_t bseg_cap = 0;
+    uint32_t bseg_cap = 0;        // candidate slots per wave segment, now / at most (grown on overflow) / number of segments
+    uint32_t bseg_max = 0, bseg_waves = 0;
     uint32_t* d_bqueries = nullptr;
     uint32_t* d_bqpop = nullptr;
     gsim::BatchQueryState* d_bstate = nullptr;
@@ -188,6 +189,7 @@ struct gsim_db {
     bool timing = false;
     gsim_timing acc{};
     unsigned long long dense_batches = 0; // multi-query passes whose dense cutoff the matrix-core pass counted itself
+    unsigned long long batch_regrown = 0; // batches run again with larger candidate segments
     unsigned long long blocks_checked = 0, blocks_rechecked = 0, blocks_torn = 0; // single launch, synchronous callers: result blocks whose checksum
                                                                // did not match at first sight / never did (re-run)
     gsim_comm* comm = nullptr; // gsim_db_set_comm: shard results meet through an RCCL all-gather + merge_kernel instead of on the host
@@ -233,6 +235,8 @@ int check_search_args(gsim_db* db, const uint32_t* queries, int metric);
 // capi_batch.cpp: multi-query passes
 int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric, float alpha,
                   float beta, uint32_t row_base, void* results, bool allow_mfma = true);
+int run_batch(gsim_db* db, const uint32_t* qb, uint32_t nb, uint32_t k, float cutoff, int metric, float alpha, float beta,
+              const std::vector<void*>& outs);
 int search_batched(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff, int metric, float alpha,
                    float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx);
 // capi_folded.cpp

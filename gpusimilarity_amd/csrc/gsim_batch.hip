@@ -325,7 +325,10 @@ __global__ __launch_bounds__(kScanBlock) void batch_scan_kernel(BatchArgs a, Sca
         if (lane == 0) {
             const BatchRare* rr = a.rare;
             rr->seg_count[w] = cursor < rr->seg_cap ? cursor : rr->seg_cap;
-            if (cursor > rr->seg_cap) atomicOr(rr->flags, 1u); // segment overflow: the host falls back
+            if (cursor > rr->seg_cap) { // segment overflow: the host grows the segments to what was needed (flags[15]) and runs the batch again
+                atomicOr(rr->flags, 1u);
+                atomicMax(&rr->flags[15], cursor);
+            }
         }
     }
     if (!SAMPLE && has_cutoff && lane < nq && keptv) atomicAdd(&a.rare->qstate[a.q0 + lane].kept, static_cast<u64>(keptv));

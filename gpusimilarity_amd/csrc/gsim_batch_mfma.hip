@@ -671,7 +671,10 @@ __global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nb
         atomicAdd(&qstate[q0t + lane].kept, static_cast<u64>(sh.kept[wq][lane]));
     if (lane == 0) {
         rr.seg_count[w] = cursor < rr.seg_cap ? cursor : rr.seg_cap;
-        if (cursor > rr.seg_cap) atomicOr(rr.flags, 1u); // segment overflow: the host falls back
+        if (cursor > rr.seg_cap) { // segment overflow: the host grows the segments to what was needed (flags[15]) and runs the batch again
+            atomicOr(rr.flags, 1u);
+            atomicMax(&rr.flags[15], cursor);
+        }
     }
 }
 

@@ -95,6 +95,8 @@ typedef struct {
     uint64_t blocks_rechecked;     /* since the handle was created: result blocks of the single launch whose checksum did not match
                                       the hits when the header arrived in host memory (the hits were still on their way) ...   */
     uint64_t blocks_torn;          /* ... and those that never matched: the query was re-run on the four-kernel pipeline      */
+    uint64_t batches_regrown;      /* since the handle was created: multi-query passes run again because a wave's candidate segment
+                                      overflowed (the segments start at 4 Ki slots and grow to what was asked for, up to 64 Ki)   */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */

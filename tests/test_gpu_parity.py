@@ -618,6 +618,22 @@ def test_multi_query_pass_fallbacks():
         t2.close()
     finally:
         del os.environ["GSIM_BATCH_SEG_CAP"]
+    # the segments start small (4 Ki slots per wave instead of round 3's 64 Ki worst case: ~130 MB instead of ~2 GB on a
+    # 256-CU part) and GROW when a wave asks for more: the batch runs again, nothing falls back, results stay exact
+    os.environ["GSIM_BATCH_SEG_CAP_INIT"] = "256"
+    try:
+        for W in (32, 4):  # the matrix-core pass and the VALU pass
+            db3 = O.synth_rows(0x0F11, 0, 0, 400_000, W)
+            t3 = make_table(db3)
+            qs3 = np.stack([db3[O.query_row(i, len(db3))] for i in range(40)])
+            batch_check(t3, db3, qs3, 300, 0.0, ctx="batch segments regrown W=%d" % W)
+            tm = t3.timing()
+            assert tm["batches_regrown"] >= 1, tm
+            batch_check(t3, db3, qs3, 300, 0.0, ctx="batch after regrowth W=%d" % W)
+            assert t3.timing()["batches_regrown"] == tm["batches_regrown"]  # (large enough now)
+            t3.close()
+    finally:
+        del os.environ["GSIM_BATCH_SEG_CAP_INIT"]
 
 
 # ---------------------------------------------------------------------------
