@@ -49,7 +49,7 @@ EXPORTS = [
     "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor", "gsim_db_set_fold_full_on_device",
     "gsim_fold_fingerprint", "gsim_db_generate", "gsim_synth_row", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
-    "gsim_db_shard_count", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
+    "gsim_db_shard_count", "gsim_db_shard_device", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
     "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm",
@@ -96,6 +96,7 @@ def load():
         "gsim_db_data_bytes": (C.c_size_t, [vp]),
         "gsim_db_row": (C.c_int, [vp, C.c_uint64, u32p]),
         "gsim_db_shard_count": (C.c_int, [vp]),
+        "gsim_db_shard_device": (C.c_int, [vp, C.c_int]),
         "gsim_db_search": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float,
                                      vp, u32p, u64p]),
         "gsim_db_search_each": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float,
@@ -235,6 +236,9 @@ class Table:
 
     def shard_count(self) -> int:
         return int(self._L.gsim_db_shard_count(self._h))
+
+    def shard_devices(self):
+        return [int(self._L.gsim_db_shard_device(self._h, i)) for i in range(self.shard_count())]
 
     def row(self, i: int) -> np.ndarray:
         out = np.empty(self.W, dtype=np.uint32)

@@ -34,7 +34,7 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
         if (cap < 256) cap = 256;
         s.bseg_max = static_cast<uint32_t>(cap);
         const uint64_t init = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP_INIT", 4096));
-        if (cap > init) cap = init < 256 ? 256 : init;
+        if (cap > init) cap = init < 16 ? 16 : init;
         s.bseg_cap = static_cast<uint32_t>(cap);
         s.bseg_waves = static_cast<uint32_t>(nw);
         const size_t slots = static_cast<size_t>(nw) * cap;

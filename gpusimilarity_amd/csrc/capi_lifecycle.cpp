@@ -561,6 +561,12 @@ int gsim_db_shard_count(const gsim_db* db)
     return db ? static_cast<int>(db->shards.size()) : 0;
 }
 
+int gsim_db_shard_device(const gsim_db* db, int shard)
+{
+    if (!db || shard < 0 || static_cast<size_t>(shard) >= db->shards.size()) return -1;
+    return db->shards[static_cast<size_t>(shard)].device;
+}
+
 int gsim_db_row(const gsim_db* db, uint64_t row, uint32_t* out_words)
 {
     if (!db || !out_words) return fail(GSIM_ERR_INVALID, "NULL argument");

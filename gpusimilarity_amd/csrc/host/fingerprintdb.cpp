@@ -119,14 +119,17 @@ FingerprintDB::FingerprintDB(int fp_bitcount, unsigned long long fp_count, const
 
 FingerprintDB::~FingerprintDB()
 {
+    if (m_db && m_comm) gsim_db_set_comm(m_db, nullptr);
     if (m_db) gsim_db_destroy(m_db);
+    if (m_comm) gsim_comm_destroy(m_comm);
 }
 
-void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices, bool full_on_device)
+void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices, bool full_on_device, bool rccl_merge)
 {
     if (m_synthetic) { // generated in HBM, one device (the one get_next_gpu picks)
         (void) fold_factor;
         (void) ndevices;
+        (void) rccl_merge;
         const unsigned int dev = get_next_gpu(m_total_data_size);
         if (gsim_db_generate(m_db, m_seed, m_kind, 0, static_cast<uint64_t>(m_total_count), static_cast<int>(dev)) != GSIM_OK)
             throw_last("copyToGPU (synthetic)");
@@ -137,6 +140,12 @@ void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices, bool full_
     if (fold_factor > 1 && gsim_db_set_fold_full_on_device(m_db, full_on_device ? 1 : 0) != GSIM_OK) throw_last("copyToGPU");
     if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
     m_fold_factor = static_cast<int>(gsim_db_fold_factor(m_db));
+    if (rccl_merge && m_fold_factor <= 1) {
+        std::vector<int> devs;
+        for (int i = 0; i < gsim_db_shard_count(m_db); i++) devs.push_back(gsim_db_shard_device(m_db, i));
+        if (gsim_comm_create(devs.data(), static_cast<int>(devs.size()), &m_comm) != GSIM_OK) throw_last("copyToGPU (gsim_comm_create)");
+        if (gsim_db_set_comm(m_db, m_comm) != GSIM_OK) throw_last("copyToGPU (gsim_db_set_comm)");
+    }
     m_on_gpu = true;
 }
 

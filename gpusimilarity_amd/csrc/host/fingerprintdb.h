@@ -12,6 +12,7 @@
 #include <vector>
 
 struct gsim_db;
+struct gsim_comm;
 
 namespace gpusim
 {
@@ -46,7 +47,9 @@ class FingerprintDB
     // full fingerprints).  ndevices: 1 = one GPU (round-robin placement like
     // get_next_gpu), 0 = shard over all GPUs.
     // full_on_device: a folded table may also keep its full fingerprints in HBM for the re-score (gsim_db_set_fold_full_on_device)
-    void copyToGPU(unsigned int fold_factor, int ndevices = 1, bool full_on_device = true);
+    // rccl_merge: the shards' results meet through the C ABI's collective (gsim_comm: RCCL all-gather over xGMI + a merge
+    // kernel) instead of on the host -- unfolded tables only
+    void copyToGPU(unsigned int fold_factor, int ndevices = 1, bool full_on_device = true, bool rccl_merge = false);
 
     unsigned int count() const { return static_cast<unsigned int>(m_total_count); }
     Fingerprint getFingerprint(unsigned int index) const; // :212-226
@@ -70,6 +73,7 @@ class FingerprintDB
 
   private:
     gsim_db* m_db = nullptr;
+    gsim_comm* m_comm = nullptr;
     int m_total_count = 0, m_fp_intsize = 0, m_fold_factor = 1;
     size_t m_total_data_size = 0;
     std::vector<char*> m_smiles;

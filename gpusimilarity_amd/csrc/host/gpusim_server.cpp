@@ -125,7 +125,7 @@ static PlacementPlan plan_placement(const std::vector<TableFacts>& tables, int g
 }
 
 GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int gpu_bitcount, bool open_socket,
-                           bool use_gpu, int ndevices)
+                           bool use_gpu, int ndevices, bool rccl_merge)
     : m_use_gpu(use_gpu)
 {
     std::fprintf(stderr, "--------------------------\nStarting up GPUSim Server\n--------------------------\n");
@@ -170,7 +170,8 @@ GPUSimServer::GPUSimServer(const std::vector<std::string>& database_fnames, int 
     std::fprintf(stderr, "Putting graphics card data up.\n");
     if (plan.fold_factor > 1) std::fprintf(stderr, "Folding databases by at least %u to fit in gpu memory\n", plan.fold_factor);
     if (ndevices == 1 && plan.ndevices == 0) std::fprintf(stderr, "Sharding every database over all GPUs (no single GPU holds the largest)\n");
-    for (auto& kv : m_databases) kv.second->copyToGPU(plan.fold_factor, plan.ndevices, plan.full_on_device);
+    if (rccl_merge && plan.fold_factor <= 1) std::fprintf(stderr, "Per-GPU results merged through an RCCL all-gather (--merge rccl)\n");
+    for (auto& kv : m_databases) kv.second->copyToGPU(plan.fold_factor, plan.ndevices, plan.full_on_device, rccl_merge);
     std::fprintf(stderr, "Finished putting graphics card data up.\n");
     std::fprintf(stderr, "Ready for searches.\n");
 }

@@ -26,7 +26,7 @@ class GPUSimServer
     // ndevices: GPUs a table is sharded over (1 = one GPU per table, round-robin;
     // 0 = every table over all GPUs).
     explicit GPUSimServer(const std::vector<std::string>& database_fnames, int gpu_bitcount = 0,
-                          bool open_socket = true, bool use_gpu = true, int ndevices = 1);
+                          bool open_socket = true, bool use_gpu = true, int ndevices = 1, bool rccl_merge = false);
     ~GPUSimServer();
 
     // gpusim.cpp:276-293

@@ -1,6 +1,7 @@
 // main.cpp -- `gpusimserver`: the backend process python/gpusim_server.py spawns.
 // Flags as the reference's main.cpp:21-62: --cpu_only, --gpu_bitcount N, positional
-// .fsim files; plus --gpus N (shard every table over N GPUs, 0 = all) and, in place of a file,
+// .fsim files; plus --gpus N (shard every table over N GPUs, 0 = all), --merge host|rccl (where the shards' results meet:
+// on the host as in the reference, fingerprintdb_cuda.cu:363-380, or through the C ABI's RCCL all-gather) and, in place of a file,
 // "synthetic:<rows>[:<kind>[:<bits>]]" (a benchmark table generated in HBM; scripts/server_latency.py).
 #include <sys/stat.h>
 
@@ -24,7 +25,7 @@ void on_signal(int)
 
 int main(int argc, char* argv[])
 {
-    bool cpu_only = false;
+    bool cpu_only = false, rccl_merge = false;
     int gpu_bitcount = 0, ndevices = 1;
     std::vector<std::string> db_fnames;
     for (int i = 1; i < argc; i++) {
@@ -52,6 +53,13 @@ int main(int argc, char* argv[])
                 std::fprintf(stderr, "--gpus must be an integer\n");
                 return 1;
             }
+        } else if (a == "--merge" || a.rfind("--merge=", 0) == 0) {
+            const std::string v = a.size() > 8 ? a.substr(8) : (i + 1 < argc ? std::string(argv[++i]) : std::string());
+            if (v != "host" && v != "rccl") {
+                std::fprintf(stderr, "--merge must be host or rccl\n");
+                return 1;
+            }
+            rccl_merge = v == "rccl";
         } else if (a == "--help" || a == "-h") {
             std::fprintf(stderr, "Arg parsing is only done in a reasonable way in the python gpusim_server.py.  "
                                  "Handling here is very error prone and not intended for direct use.\n");
@@ -78,7 +86,7 @@ int main(int argc, char* argv[])
     try {
         // the reference constructs (and uploads) first and applies --cpu_only after
         // (main.cpp:64-65); here --cpu_only also skips the upload
-        gpusim::GPUSimServer server(db_fnames, gpu_bitcount, true, !cpu_only, ndevices);
+        gpusim::GPUSimServer server(db_fnames, gpu_bitcount, true, !cpu_only, ndevices, rccl_merge);
         if (!server.socketOk()) return 1;
         g_server = &server;
         std::signal(SIGINT, on_signal);

@@ -172,6 +172,8 @@ size_t gsim_db_data_bytes(const gsim_db* db);
 int gsim_db_row(const gsim_db* db, uint64_t row, uint32_t* out_words);
 /* number of device shards the table was placed on (1 unless ndevices > 1) */
 int gsim_db_shard_count(const gsim_db* db);
+/* the device shard `shard` lives on (-1: no such shard) -- the order gsim_comm_create wants */
+int gsim_db_shard_device(const gsim_db* db, int shard);
 
 /* ---- search --------------------------------------------------------------- */
 /* FingerprintDB::search          fingerprintdb_cuda.cu:341-381 (+ search_storage

@@ -620,7 +620,7 @@ def test_multi_query_pass_fallbacks():
         del os.environ["GSIM_BATCH_SEG_CAP"]
     # the segments start small (4 Ki slots per wave instead of round 3's 64 Ki worst case: ~130 MB instead of ~2 GB on a
     # 256-CU part) and GROW when a wave asks for more: the batch runs again, nothing falls back, results stay exact
-    os.environ["GSIM_BATCH_SEG_CAP_INIT"] = "256"
+    os.environ["GSIM_BATCH_SEG_CAP_INIT"] = "16"
     try:
         for W in (32, 4):  # the matrix-core pass and the VALU pass
             db3 = O.synth_rows(0x0F11, 0, 0, 400_000, W)
