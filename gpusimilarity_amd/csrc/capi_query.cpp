@@ -158,6 +158,16 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
         f.xflags = static_cast<uint32_t>(xflags);
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+        // Narrow rows (128 / 256 bits): a wave meets 512 / 256 rows per trip and its LDS store (2048 slots) is full after a
+        // few trips -- before the first in-loop threshold has been elected (~12 us) -- so that sparse tables were handed back
+        // (1/64 of the queries at 256 bits, nearly all at 128: scanned twice).  A strided sample first (K0, ~25 us: the
+        // four-kernel pipeline's own) leaves a valid starting threshold in QueryState::gtau as a coarse BIN; the single
+        // launch turns it into a score key (xflags bit 2).
+        static const int seed_narrow = env_int("GSIM_FUSED_SEED_NARROW", 1);
+        if (seed_narrow && s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2 && s.nrows >= 4000000ull && s.sample_chunks > 0 && k > 0) {
+            GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream)); // (one chunk per scan wave: 0.25-0.5 M rows, enough for a seed)
+            f.xflags |= 4u;
+        }
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
         if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
         if (caller_syncs) {

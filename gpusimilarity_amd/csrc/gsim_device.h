@@ -111,7 +111,7 @@ struct FusedArgs {
     uint32_t* done_flag;  // non-NULL: a synchronous caller polls the result header (in pinned host memory): its flags word carries `epoch` << 8
     uint32_t epoch;
     uint32_t wait_ticks;     // bound of the grid-wide wait (100 MHz ticks): a few scan times, see fused_kernel
-    uint32_t xflags;         // experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints
+    uint32_t xflags;         // 4 = QueryState::gtau was seeded by the sample kernel (a coarse bin); experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints, 1024 = release fence before the closing ticket
     unsigned long long* dbg; // NULL, or 24 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };
 

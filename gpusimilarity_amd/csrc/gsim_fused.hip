@@ -9,6 +9,7 @@
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
+#include "gsim_prefilter.h"
 #include "gsim_scan_inl.h"
 
 namespace gsim
@@ -217,8 +218,46 @@ struct FusedFilter {
     FusedSchedule sched;
     uint32_t next_ck, ck_j;
     u64* dbg;
+    // Narrow rows (up to 512 bits: a lane scores a row for every one or two 16-byte loads) are bound by the per-row
+    // arithmetic, not by HBM: the reference's f32 divide, the order key and the compare cost ~30 vector instructions per
+    // row, the popcounts 12.  "score >= threshold" is linear in the counts (gsim_prefilter.h: c >= ka + kb b, conservative
+    // under f32 rounding, proven exhaustively by tests/cpp/prefilter_check.cpp for every (a, b, c) of these widths and any
+    // achievable score as the level), so a row is scored only when it may reach the wave's current threshold -- with a
+    // threshold in place: a handful per thousand.  Without a cutoff only (a cutoff needs every row's exact score for `approx`).
+    float pk_ka, pk_kb;  // the pair test at the level of `pk_tau`
+    uint32_t pk_tau;
 
     __device__ __forceinline__ uint32_t load_gtau() const { return 0u; } // (no polls from the streaming loop)
+
+    __device__ __forceinline__ void init_prefilter()
+    {
+        pk_tau = 0;
+        pk_ka = 0.0f; // (no threshold yet: everything passes)
+        pk_kb = 0.0f;
+    }
+
+    __device__ __forceinline__ void update_prefilter(const ScanArgs& a)
+    {
+        if (tau == pk_tau) return; // (wave-uniform; the threshold moves a few times per query)
+        pk_tau = tau;
+        const PrefilterConstants pk = prefilter_constants(a.metric == GSIM_METRIC_TVERSKY, a.alpha, a.beta, a.qpop,
+                                                          prefilter_level(true, key_score(tau), 0u), true);
+        pk_ka = pk.ka;
+        pk_kb = pk.kb;
+    }
+
+    template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane)
+    {
+        if constexpr (LPR <= 4) {
+            if (!has_cutoff) { // (wave-uniform)
+                update_prefilter(a);
+                const bool maybe = active && static_cast<float>(val >> 16) >= __builtin_fmaf(pk_kb, static_cast<float>(val & 0xFFFFu), pk_ka);
+                if (__ballot(maybe) == 0) return; // no row of this round can reach the threshold: none is scored
+                active = maybe; // (a row the test rejects scores below the threshold: not a candidate, and nothing counts it)
+            }
+        }
+        offer_scored(*this, active, row, val, a, lane);
+    }
 
     __device__ __forceinline__ void refresh(uint32_t g, int lane)
     {
@@ -523,6 +562,20 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         sh.abort = 0;
     }
     if (tid < kFusedCheckpoints) sh.ck_cnt[tid] = 0;
+    if (tid == 0 && (fa.xflags & 4u)) {
+        // seeded by the sample kernel (narrow rows): QueryState::gtau holds a coarse BIN B -- k sampled rows score at least
+        // B / 1024 (coarse_bin: exact, a power-of-two scale) -- which becomes the first threshold, as a score key.  Every
+        // workgroup converts it for itself and raises the table-wide word (idempotent; a poller that still reads the bin
+        // reads a key below every real one: harmless)
+        const uint32_t raw = agent_load(&st->gtau);
+        if (raw != 0u && raw < static_cast<uint32_t>(kScanBins)) {
+            const uint32_t key = order_key(static_cast<float>(raw) * (1.0f / static_cast<float>(kScanBins)));
+            sh.tau = key;
+            atomicMax(&st->gtau, key);
+        } else if (raw >= 0x80000000u) {
+            sh.tau = raw; // (another workgroup's conversion)
+        }
+    }
     __syncthreads();
     FusedSchedule sched;
     constexpr int CHR = U * (64 / LPR); // rows per chunk
@@ -556,6 +609,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.cutoff = a.cutoff;
     f.has_cutoff = a.cutoff > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
     f.store_off = false;
+    f.init_prefilter();
     f.sched = sched;
     f.ck_j = 0;
     f.next_ck = (f.M && !(fa.xflags & 2u)) ? sched.trip(0) : 0xFFFFFFFFu;

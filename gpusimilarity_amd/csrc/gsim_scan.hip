@@ -95,6 +95,10 @@ constexpr uint32_t kFirstPush = 64;
 struct WaveFilter {
     static constexpr bool kFused = false;
     __device__ __forceinline__ void checkpoint(uint32_t, int) {}
+    template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane)
+    {
+        offer_scored(*this, active, row, val, a, lane);
+    }
     BlockFilter* sh;
     QueryState* st;
     u64* seg;         // this wave's private candidate segment (keys)
@@ -312,6 +316,10 @@ struct SampleFilter {
     uint32_t* hist; // workgroup's LDS histogram
     float cutoff;
     bool has_cutoff;
+    template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane)
+    {
+        offer_scored(*this, active, row, val, a, lane);
+    }
     __device__ __forceinline__ void offer(bool active, uint32_t, float raw_score, uint32_t, int)
     {
         const float s = apply_cutoff(raw_score, cutoff);
@@ -388,14 +396,14 @@ __global__ __launch_bounds__(kScanBlock) void sample_kernel(ScanArgs a, uint32_t
 // address computation per 16 bytes), then every lane reads back ITS row -- 16 bytes per read when the rows are
 // 16-byte multiples.  (One row per lane straight from global memory -- the reference's access pattern,
 // fingerprintdb_cuda.cu:98 -- touches 64 different 128-byte lines per load instruction: 0.18-0.32 of the HBM peak.)
-constexpr uint32_t kGenericLdsBytes = 96 * 1024; // dynamic LDS: the query + four waves x two chunk buffers
+constexpr uint32_t kGenericLdsBytes = 96 * 1024; // dynamic LDS: the query + four wave regions
 
 __host__ __device__ inline uint32_t generic_query_words(uint32_t W) { return (W + 3u) & ~3u; }
-__host__ __device__ inline uint32_t generic_lds_bytes(uint32_t W, uint32_t R) { return (generic_query_words(W) + (kScanBlock / 64) * 2u * R * W) * 4u; }
+__host__ __device__ inline uint32_t generic_lds_bytes(uint32_t W, uint32_t R) { return (generic_query_words(W) + (kScanBlock / 64) * R * W) * 4u; }
 
 struct GenericChunk {
     const uint32_t* db;
-    uint32_t* sbuf[2];    // this wave's two LDS regions, R x W words each: one chunk is reduced while the next one lands
+    uint32_t* srow;       // this wave's LDS region: R x W words
     const uint32_t* sq;   // the query in LDS
     uint32_t W, R;
     u64 total_words;
@@ -405,15 +413,13 @@ struct GenericChunk {
         db = reinterpret_cast<const uint32_t*>(a.rows);
         W = a.W, R = R_;
         sq = s_words;
-        sbuf[0] = s_words + generic_query_words(W) + (2u * wv) * R * W;
-        sbuf[1] = sbuf[0] + R * W;
+        srow = s_words + generic_query_words(W) + wv * R * W;
         total_words = a.nrows * W;
         for (uint32_t i = threadIdx.x; i < W; i += kScanBlock) s_words[i] = a.query[i]; // (a workgroup barrier follows in the caller)
     }
-    // chunk c -> LDS buffer b, asynchronously (global_load_lds: no registers); wait() before the buffer is read
-    __device__ __forceinline__ void issue(u64 c, int b, int lane) const
+    // chunk c -> LDS; returns when it is there
+    __device__ __forceinline__ void load(u64 c, int lane) const
     {
-        uint32_t* srow = sbuf[b];
         const uint32_t units = R * W / 4u; // 16-byte units per chunk
         const u64 base = c * (static_cast<u64>(R) * W);
         for (uint32_t u0 = 0; u0 < units; u0 += 64u) {
@@ -427,22 +433,13 @@ struct GenericChunk {
                 for (uint32_t t = 0; t < 4; t++) srow[4u * u + t] = gi + t < total_words ? db[gi + t] : 0u;
             }
         }
-    }
-    __device__ __forceinline__ void wait() const
-    {
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): the words are in LDS
         __builtin_amdgcn_wave_barrier();
     }
-    // chunk c -> LDS; returns when it is there
-    __device__ __forceinline__ void load(u64 c, int lane) const
-    {
-        issue(c, 0, lane);
-        wait();
-    }
     // popc(row & query), popc(row) of this lane's row of the chunk in LDS
-    __device__ __forceinline__ void count(int lane, uint32_t& cc, uint32_t& bb, int b = 0) const
+    __device__ __forceinline__ void count(int lane, uint32_t& cc, uint32_t& bb) const
     {
-        const uint32_t* mine = sbuf[b] + (static_cast<uint32_t>(lane) < R ? static_cast<uint32_t>(lane) : 0u) * W;
+        const uint32_t* mine = srow + (static_cast<uint32_t>(lane) < R ? static_cast<uint32_t>(lane) : 0u) * W;
         cc = 0, bb = 0;
         if (W % 4u == 0) { // rows are 16-byte multiples: ds_read_b128
             const u32x4* m4 = reinterpret_cast<const u32x4*>(mine);
@@ -491,20 +488,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
     WaveFilter f;
     f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap,
            a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
-    // register-free double buffer: while a chunk is reduced the wave's next one is already on its way into the other LDS
-    // region (the loads of chunk c + nwaves are issued right after chunk c has landed: one vmcnt(0) per trip covers them)
-    int b = 0;
-    uint32_t gt = 0; // the table-wide threshold, loaded a trip ahead of its use (behind the chunk loads: the next wait covers it)
-    if (w < g.nchunks) ch.issue(w, 0, lane);
-    for (u64 c = w; c < g.nchunks; c += g.nwaves, b ^= 1) {
-        ch.wait();
-        f.refresh(gt, lane);
-        if (c + g.nwaves < g.nchunks) ch.issue(c + g.nwaves, b ^ 1, lane);
-        gt = (c / g.nwaves) % 8 == 0 ? f.load_gtau() : 0u;
+    for (u64 c = w; c < g.nchunks; c += g.nwaves) {
+        ch.load(c, lane);
         uint32_t cc, bb;
-        ch.count(lane, cc, bb, b);
+        ch.count(lane, cc, bb);
         const u64 row = c * ch.R + lane;
         const bool active = static_cast<uint32_t>(lane) < ch.R && row < a.nrows;
+        f.refresh((c / g.nwaves) % 8 == 0 ? f.load_gtau() : 0u, lane);
         const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc);
         f.offer(active, static_cast<uint32_t>(row), s, (cc << 16) + bb, lane);
     }

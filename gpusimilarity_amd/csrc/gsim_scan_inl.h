@@ -26,6 +26,13 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p)
 // The loop body over full chunks is branch-free up to the (rare) emit path, so the
 // compiler's s_waitcnt placement leaves the prefetch in flight during the reduce;
 // the table's last, partial chunk is handled once, outside the loop.
+// What most filters do with a row's counts (val = popc(q & row) << 16 | popc(row)): score it, offer the score.
+template <typename Filter>
+__device__ __forceinline__ void offer_scored(Filter& f, bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane)
+{
+    f.offer(active, row, score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16), val, lane);
+}
+
 template <int LPR, int U, bool FULL, typename Filter>
 __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q, u64 row0, const ScanArgs& a,
                                              Filter& f, int lane)
@@ -54,8 +61,9 @@ __device__ __forceinline__ void reduce_chunk(const u32x4 (&d)[U], const u32x4& q
         const int j = r * LPR + sub;
         const u64 row = row0 + static_cast<u64>(j * RPL + grp);
         const bool active = (j < U) && (FULL || row < a.nrows);
-        const float s = score_of(a.metric, a.alpha, a.beta, a.qpop, val & 0xFFFFu, val >> 16);
-        f.offer(active, static_cast<uint32_t>(row), s, val, lane);
+        // (the filter scores the row: the reference's arithmetic, score_of -- or, where it can prove from the counts alone
+        // that the row lies below its threshold, nothing at all: FusedFilter::offer_counts)
+        f.template offer_counts<LPR>(active, static_cast<uint32_t>(row), val, a, lane);
     }
 }
 

@@ -18,6 +18,7 @@ using namespace gsim;
 
 struct SinkFilter {
     static constexpr bool kFused = false;
+    template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane) { offer_scored(*this, active, row, val, a, lane); }
     __device__ __forceinline__ uint32_t load_gtau() const { return 0u; }
     __device__ __forceinline__ void refresh(uint32_t, int) {}
     __device__ __forceinline__ void checkpoint(uint32_t, int) {}
@@ -26,6 +27,7 @@ struct SinkFilter {
 
 struct BallotFilter {
     static constexpr bool kFused = false;
+    template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane) { offer_scored(*this, active, row, val, a, lane); }
     uint32_t tau, hits;
     __device__ __forceinline__ uint32_t load_gtau() const { return 0u; }
     __device__ __forceinline__ void refresh(uint32_t, int) {}
@@ -40,6 +42,7 @@ struct BallotFilter {
 
 struct StoreFilter {
     static constexpr bool kFused = false;
+    template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane) { offer_scored(*this, active, row, val, a, lane); }
     u64* skey;
     uint32_t* scb;
     uint32_t tau, staged;

@@ -60,16 +60,20 @@ def test_c_abi_collective_world_one_rccl():
         capi.Comm([5])     # not present on a one-GPU lease
 
 
-@pytest.mark.parametrize("gpus", ["4", "0"])
-def test_server_shards_over_aliased_devices(gpus, monkeypatch, tmp_path):
-    """`gpusimserver --gpus N`: every table sharded over N (0 = all) devices, replies byte-identical to the golden frames."""
+@pytest.mark.parametrize("gpus,merge", [("4", "host"), ("0", "host"), ("4", "rccl"), ("1", "rccl")])
+def test_server_shards_over_aliased_devices(gpus, merge, monkeypatch, tmp_path):
+    """`gpusimserver --gpus N [--merge rccl]`: every table sharded over N (0 = all) devices, the shards' results merged on
+    the host or through the C ABI's collective (aliased devices: its loop-back gather; one device: a real world-1 RCCL
+    communicator) -- replies byte-identical to the golden frames."""
     import test_host_cpp as H
     monkeypatch.setenv("GSIM_TEST_ALIAS_DEVICES", "4")
     import shutil
     pair = (str(tmp_path / "small.fsim"), str(tmp_path / "small_copy.fsim"))
     for f in pair:
         shutil.copy(os.path.join(ROOT, "tests", "golden", "small.fsim"), f)
-    srv = H.Server(["--gpus", gpus, pair[0], pair[1]])
+    if gpus == "1":
+        monkeypatch.delenv("GSIM_TEST_ALIAS_DEVICES")
+    srv = H.Server(["--gpus", gpus, "--merge", merge, pair[0], pair[1]])
     try:
         H.check_frames(srv, "gpu")
     finally:
