@@ -116,7 +116,10 @@ int setup_shard(gsim_db* db, Shard& s)
     s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
     s.fgeo = s.geo;
     if (s.geo.nchunks < 4ull * s.geo.nwaves) { // small table: threshold checkpoints need a few trips per wave
-        uint64_t nw = s.geo.nchunks / 4 / 4 * 4;
+        // (128-bit rows: a chunk is 512 rows and a wave's LDS store holds 2048 -- three chunks per wave, so that a store
+        // cannot fill before the one threshold such a table sees, the one after the loop)
+        const uint64_t per = s.geo.lanes_per_row == 1 ? 3 : 4;
+        uint64_t nw = s.geo.nchunks / per / 4 * 4;
         s.fgeo.nwaves = static_cast<uint32_t>(nw < 4 ? 4 : nw);
     }
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(s.W) * 4));

@@ -164,7 +164,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         // four-kernel pipeline's own) leaves a valid starting threshold in QueryState::gtau as a coarse BIN; the single
         // launch turns it into a score key (xflags bit 2).
         static const int seed_narrow = env_int("GSIM_FUSED_SEED_NARROW", 1);
-        if (seed_narrow && s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2 && s.nrows >= 4000000ull && s.sample_chunks > 0 && k > 0) {
+        if (seed_narrow && s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2 && s.nrows > 1500ull * s.fgeo.nwaves && s.sample_chunks > 0 && k > 0) {
             GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream)); // (one chunk per scan wave: 0.25-0.5 M rows, enough for a seed)
             f.xflags |= 4u;
         }

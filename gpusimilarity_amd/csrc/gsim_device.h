@@ -69,6 +69,9 @@ struct ScanGeometry {
     uint32_t nwaves;        // wavefronts in the grid
     uint32_t seg_cap;       // candidate slots per wavefront
     uint64_t nchunks;
+    uint32_t ragged_loads;  // generic widths that are whole 16-byte units per row, not a power of two (896, 1536 ... bits): loads per
+                            // chunk of scan_ragged_kernel (the odd part of W / 4: 3, 5 or 7), 0 = the LDS-staged generic scan
+    uint32_t pad;
 };
 
 struct ScanArgs {

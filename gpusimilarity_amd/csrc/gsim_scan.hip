@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
@@ -532,6 +533,116 @@ __global__ __launch_bounds__(kScanBlock) void sample_generic_kernel(ScanArgs a, 
 }
 
 // ---------------------------------------------------------------------------
+// K1 for rows of L = W / 4 sixteen-byte units where L is not a power of two (896-, 1536-, 768-, 640-bit rows ...)
+// ---------------------------------------------------------------------------
+// The power-of-two widths stream through registers (scan_rows); scan_generic_kernel stages its chunks through LDS and
+// tops out at 0.6-0.7 of the HBM rate: with the LDS as the only buffer a CU has ~half of it in flight.  Rows that are
+// whole 16-byte units can stream through registers as well.  P = the odd part of L consecutive wave loads (P KB) hold
+// exactly 64 / g whole rows (g = gcd(L, 64)): unit u = 64 j + lane of a chunk belongs to row u / L, position u % L.
+// Every lane counts its unit against the query unit of that position (P query units per lane, loaded once), an inclusive
+// prefix sum over the chunk's units in unit order (DPP scan per load, the running total carried from load to load)
+// turns "sum over a row's units" into E(row) - E(row - 1), E = the prefix at the row's last unit, fetched with one
+// ds_bpermute per load -- packed (common << 16 | popc): a chunk holds at most 8192 P <= 57 344 bits, neither field
+// overflows.  Lane r then scores row r of the chunk.  P <= 7: L in {3, 5, 7} x 2^i; other widths keep the LDS route.
+// C = sub-chunks per trip: a wave keeps 2 x C P KB in flight (register double buffer); C P ~ 7-9 loads, as the template path's 8.
+template <int P, int C> __global__ __launch_bounds__(kScanBlock) void scan_ragged_kernel(ScanArgs a, ScanGeometry g)
+{
+    __shared__ BlockFilter s_filter;
+    if (a.gate && *a.gate == 0) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (threadIdx.x >> 6));
+    block_filter_init(&s_filter, a.k, a.state->gtau);
+    WaveFilter f;
+    f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap, a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
+    const uint32_t L = a.W / 4u;          // units per row
+    const uint32_t R = g.chunk_rows / C;  // rows per sub-chunk: 64 P / L
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    const u32x4* qu = reinterpret_cast<const u32x4*>(a.query);
+    u32x4 q[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) q[j] = qu[(64u * j + static_cast<uint32_t>(lane)) % L];
+    // the last unit of this lane's row (lanes >= R have none: they read lane 0's and are inactive)
+    const uint32_t end_u = (static_cast<uint32_t>(lane) < R ? static_cast<uint32_t>(lane) + 1u : 1u) * L - 1u;
+    const uint32_t je = end_u >> 6;
+    const int le4 = static_cast<int>((end_u & 63u) * 4u);
+    const u64 total_units = a.nrows * L;
+    const u64 nfull = a.nrows / g.chunk_rows; // trips' worth of rows that are all present
+    uint32_t gt = 0;
+
+    // one sub-chunk: P loads = R whole rows; row0 = its first row
+    auto reduce = [&](const u32x4* d, u64 row0, bool full) {
+        uint32_t s[P];
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const uint32_t cc = __popc(d[j].x & q[j].x) + __popc(d[j].y & q[j].y) + __popc(d[j].z & q[j].z) + __popc(d[j].w & q[j].w);
+            const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
+            uint32_t v = (cc << 16) + bb;
+            // inclusive prefix sum over the wave: within the rows of 16 lanes by DPP, then the rows' totals
+            v += dpp_shr<1>(v);
+            v += dpp_shr<2>(v);
+            v += dpp_shr<4>(v);
+            v += dpp_shr<8>(v);
+            const uint32_t t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47),
+                           t3 = __builtin_amdgcn_readlane(v, 63);
+            const int rowi = lane >> 4;
+            v += carry + (rowi > 0 ? t0 : 0u) + (rowi > 1 ? t1 : 0u) + (rowi > 2 ? t2 : 0u);
+            carry += t0 + t1 + t2 + t3;
+            s[j] = v;
+        }
+        uint32_t e = 0; // the prefix at this lane's row's last unit
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const uint32_t x = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(le4, static_cast<int>(s[j])));
+            e = je == static_cast<uint32_t>(j) ? x : e;
+        }
+        uint32_t prev = static_cast<uint32_t>(__shfl_up(static_cast<int>(e), 1, 64)); // ... and at the previous row's
+        prev = lane == 0 ? 0u : prev;
+        const uint32_t val = e - prev; // (fieldwise: both prefixes are monotone and below 2^16, no borrow)
+        const u64 row = row0 + static_cast<u64>(lane);
+        const bool active = static_cast<uint32_t>(lane) < R && (full || row < a.nrows);
+        f.template offer_counts<0>(active, static_cast<uint32_t>(row), val, a, lane);
+    };
+
+    constexpr int NL = P * C; // loads per trip
+    if (w < nfull) {
+        const u64 last = w + (nfull - 1 - w) / g.nwaves * g.nwaves; // this wave's last full trip
+        u32x4 nxt[NL];
+        {
+            const u32x4* p = db + static_cast<u64>(w) * (64u * NL) + lane;
+#pragma unroll
+            for (int j = 0; j < NL; j++) nxt[j] = stream_load(p + j * 64);
+        }
+        uint32_t trip = 0;
+        for (u64 c = w;; c += g.nwaves) {
+            u32x4 d[NL];
+#pragma unroll
+            for (int j = 0; j < NL; j++) d[j] = nxt[j];
+            const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last; // (the final trip re-reads the last one: no branch in the body)
+            const u32x4* p = db + cn * (64u * NL) + lane;
+#pragma unroll
+            for (int j = 0; j < NL; j++) nxt[j] = stream_load(p + j * 64);
+            f.refresh(gt, lane);
+            gt = (trip++ & 7u) == 0 ? f.load_gtau() : 0u;
+#pragma unroll
+            for (int i = 0; i < C; i++) reduce(d + i * P, c * g.chunk_rows + static_cast<u64>(i) * R, true);
+            if (c == last) break;
+        }
+    }
+    if (nfull < g.nchunks && w == nfull % g.nwaves) { // the table's partial last trip
+        const u64 u0 = nfull * (64u * NL) + static_cast<u64>(lane);
+        u32x4 d[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) d[j] = u0 + 64u * j < total_units ? stream_load(db + u0 + 64u * j) : u32x4{0, 0, 0, 0};
+        f.refresh(f.load_gtau(), lane);
+#pragma unroll
+        for (int i = 0; i < C; i++) reduce(d + i * P, nfull * g.chunk_rows + static_cast<u64>(i) * R, false);
+    }
+    f.finish(w, a, lane);
+    block_filter_flush(&s_filter, a);
+}
+
+// ---------------------------------------------------------------------------
 // K2: compaction at the k-th best coarse bin
 // ---------------------------------------------------------------------------
 //
@@ -647,6 +758,18 @@ static bool is_pow2(uint32_t x)
     return x && !(x & (x - 1));
 }
 
+// loads per chunk of scan_ragged_kernel for rows of L sixteen-byte units: the odd part of L when that is 3, 5 or 7 and a
+// chunk holds at least one whole row (64 P / L >= 1), else 0
+static uint32_t ragged_loads_of(uint32_t L)
+{
+    static const int enabled = std::getenv("GSIM_SCAN_RAGGED") ? std::atoi(std::getenv("GSIM_SCAN_RAGGED")) : 1;
+    if (!enabled || L == 0) return 0;
+    uint32_t odd = L;
+    while (odd % 2 == 0) odd /= 2;
+    if (odd != 3 && odd != 5 && odd != 7) return 0;
+    return (64u * odd) % L == 0 && 64u * odd / L >= 1 ? odd : 0;
+}
+
 ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll)
 {
     ScanGeometry g{};
@@ -656,6 +779,11 @@ ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_pe
         if (unroll != 4 && unroll != 8 && unroll != 16) unroll = 8;
         g.unroll = static_cast<uint32_t>(unroll);
         g.chunk_rows = g.unroll * (64 / lpr);
+    } else if (W % 4 == 0 && ragged_loads_of(W / 4) != 0) {
+        // whole 16-byte units per row, odd part 3, 5 or 7: streamed through registers (scan_ragged_kernel)
+        g.ragged_loads = ragged_loads_of(W / 4);
+        g.unroll = g.ragged_loads == 3 ? 3 : (g.ragged_loads == 5 ? 2 : 1); // sub-chunks per trip: 9, 10 or 7 loads in flight
+        g.chunk_rows = g.unroll * (64u * g.ragged_loads / (W / 4));
     } else {
         // generic widths: the four waves' chunks live in LDS (scan_generic_kernel), fewer rows per chunk when they are wide
         g.unroll = 1;
@@ -689,7 +817,11 @@ hipError_t launch_sample_t(const ScanArgs& a, uint32_t nsample, uint64_t stride,
 hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s)
 {
     if (a.k == 0 || chunks_per_wave == 0) return hipSuccess;
-    const uint64_t nfull = a.nrows / g.chunk_rows;
+    // rows per sampled chunk: the scan's chunk -- for the register-streamed odd widths one sub-chunk (<= 64 rows: the sample
+    // kernel of the generic widths scores one row per lane), and more of them (the same number of rows as the template path)
+    const uint32_t chunk_rows = g.ragged_loads ? g.chunk_rows / g.unroll : g.chunk_rows;
+    if (g.ragged_loads) chunks_per_wave *= chunk_rows >= 64 ? 1u : 64u / chunk_rows;
+    const uint64_t nfull = a.nrows / chunk_rows;
     // never sample more than 1/8 of the table; under one chunk per wave the scan's own warm-up is cheaper
     const uint64_t fit = nfull / (8ull * g.nwaves);
     if (fit < chunks_per_wave) chunks_per_wave = static_cast<uint32_t>(fit);
@@ -699,12 +831,12 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     const uint32_t nsample = static_cast<uint32_t>(want);
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
     if (g.lanes_per_row == 0) {
-        const uint32_t lds = generic_lds_bytes(a.W, g.chunk_rows);
+        const uint32_t lds = generic_lds_bytes(a.W, chunk_rows);
         static DynLdsOnce once;
         const hipError_t e = once.ensure(reinterpret_cast<const void*>(sample_generic_kernel), kGenericLdsBytes);
         if (e != hipSuccess) return e;
         if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(sample_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, g.chunk_rows, nsample, stride);
+        hipLaunchKernelGGL(sample_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, chunk_rows, nsample, stride);
         return hipGetLastError();
     }
 #define GSIM_CASE(L, UU) \
@@ -742,6 +874,10 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
 #undef GSIM_CASE
     if (g.lanes_per_row != 0) return hipErrorInvalidValue;
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    if (g.ragged_loads == 3) hipLaunchKernelGGL((scan_ragged_kernel<3, 3>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    else if (g.ragged_loads == 5) hipLaunchKernelGGL((scan_ragged_kernel<5, 2>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    else if (g.ragged_loads == 7) hipLaunchKernelGGL((scan_ragged_kernel<7, 1>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    if (g.ragged_loads) return hipGetLastError();
     static DynLdsOnce once;
     const hipError_t e = once.ensure(reinterpret_cast<const void*>(scan_generic_kernel), kGenericLdsBytes);
     if (e != hipSuccess) return e;

@@ -2,7 +2,7 @@
 """Soak test of the single-launch query path: many thousand queries over the same table, every result compared with
 the one the four-kernel pipeline (GSIM_FUSED=0, a child process) gave for that query -- looks for rare races in the
 in-kernel protocol (thresholds, tickets, publication) that the parity suite's few hundred queries would not meet.
-    python scripts/soak_fused.py [rows] [iterations]      (on the GPU box; SOAK_KIND=sparse|morgan)"""
+    python scripts/soak_fused.py [rows] [iterations]      (on the GPU box; SOAK_KIND=sparse|morgan, SOAK_BITS=128...8192)"""
 import os, pickle, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,7 @@ from gpusimilarity_amd import capi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000
-W, NQ = 32, 48
+W, NQ = int(os.environ.get("SOAK_BITS", "1024")) // 32, 48
 cases = [(1000, 0.0), (10, 0.0), (100, 0.07), (2048, 0.0), (8192, 0.0)]
 KIND = {"sparse": capi.SYNTH_SPARSE, "morgan": capi.SYNTH_MORGAN}[os.environ.get("SOAK_KIND", "sparse")]
 
@@ -67,6 +67,7 @@ while done < iters:
 tm = t.timing()
 if hb_by_case:
     print("handed back by (k, cutoff):", sorted(hb_by_case.items()))
-print("soak (%s rows): rows %d, %d queries in %.1f s, mismatches %d, handed back %d%s" % (os.environ.get("SOAK_KIND", "sparse"), n, done, time.time() - t0, bad, tm["handed_back"],
-      " (reasons, gsim_timing.handed_back_why: %d)" % tm["handed_back_why"] if tm["handed_back"] else ""))
+print("soak (%s rows, %d-bit): rows %d, %d queries in %.1f s, mismatches %d, handed back %d%s, blocks rechecked %d torn %d" % (
+      os.environ.get("SOAK_KIND", "sparse"), 32 * W, n, done, time.time() - t0, bad, tm["handed_back"],
+      " (reasons, gsim_timing.handed_back_why: %d)" % tm["handed_back_why"] if tm["handed_back"] else "", tm["blocks_rechecked"], tm["blocks_torn"]))
 sys.exit(1 if bad else 0)

@@ -229,6 +229,29 @@ def test_generic_widths_match_oracle(n, W):
     t.close()
 
 
+@pytest.mark.parametrize("n,W", [(300_001, 28), (150_003, 48), (100_001, 12), (250_000, 20), (120_007, 24), (90_001, 56), (70_000, 40),
+                                 (30_001, 96), (9_001, 192), (5_003, 448), (63, 28), (64, 28), (65, 28), (1, 12), (17, 48), (2_000_001, 28)])
+def test_register_streamed_odd_widths_match_oracle(n, W):
+    """Rows of 3, 5 or 7 (x 2^i) sixteen-byte units -- 384-, 640-, 896-, 768-, 1536-, 1792-, 1280-, 3072-, 6144-, 14336-bit --
+    stream through registers (scan_ragged_kernel: prefix sums over the units of a chunk, a row's counts = the difference
+    of two prefixes); the same tables through the LDS-staged scan (GSIM_SCAN_RAGGED=0, a child process) give the same
+    bytes.  Whole chunks, ragged last chunks, tables shorter than one chunk, dense and sparse rows, a cutoff, Tversky."""
+    db = O.synth_rows(0x6A66 + W, n % 2, 0, n, W)
+    t = make_table(db)
+    q = db[O.query_row(1, n)]
+    for k, cutoff in ((1000, 0.0), (7, 0.0), (50, 0.2), (9000, 0.0)):
+        check_against_oracle(t, db, q, k, cutoff, ctx="ragged n=%d W=%d k=%d c=%g" % (n, W, k, cutoff))
+    check_against_oracle(t, db, O.synth_rows(0x5EED0003, 0, 5, 1, W)[0], 100, 0.0, ctx="ragged tversky W=%d" % W,
+                         metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    qs = np.stack([db[O.query_row(i, n)] for i in range(5)])
+    hits, approx = t.search(qs, 100, 0.0)  # (a batch on a width without a shared pass: five single queries)
+    for i in range(5):
+        want, wap = O.search(qs[i], db, 100, 0.0, nthreads=8)
+        assert int(approx[i]) == wap
+        assert_hits_equal(hits[i], want, "ragged batch W=%d q=%d" % (W, i))
+    t.close()
+
+
 def test_ragged_and_edge_sizes():
     W = 32
     for n in (1, 7, 63, 64, 65, 511, 513, 4095, 4097):
