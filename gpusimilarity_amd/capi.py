@@ -49,7 +49,7 @@ EXPORTS = [
     "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor", "gsim_db_set_fold_full_on_device",
     "gsim_fold_fingerprint", "gsim_db_generate", "gsim_synth_row", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
-    "gsim_db_shard_count", "gsim_db_shard_device", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
+    "gsim_db_shard_count", "gsim_db_shard_device", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_timed", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
     "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm",
@@ -101,6 +101,8 @@ def load():
                                      vp, u32p, u64p]),
         "gsim_db_search_each": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float,
                                           vp, u32p, u64p]),
+        "gsim_db_search_timed": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_float, C.c_float,
+                                           vp, u32p, u64p, C.POINTER(C.c_double)]),
         "gsim_db_search_cpu": (C.c_int, [vp, u32p, C.c_uint32, C.c_uint32, C.c_float, vp, u32p]),
         "gsim_db_set_stream": (C.c_int, [vp, vp]),
         "gsim_db_set_row_base": (C.c_int, [vp, C.c_uint32]),
@@ -276,6 +278,15 @@ class Table:
         check(self._L.gsim_db_search_each(self._h, _u32(queries), hits.shape[0], k, cutoff, metric, alpha, beta,
                                           hits.ctypes.data_as(C.c_void_p), _u32(counts),
                                           approx.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def search_timed_into(self, queries, k, bufs, cutoff=0.0, metric=METRIC_TANIMOTO, alpha=1.0, beta=1.0) -> np.ndarray:
+        """gsim_db_search_timed: the queries one at a time, nothing enqueued ahead; -> seconds per query (measured in the library)."""
+        hits, counts, approx = bufs
+        sec = np.zeros(hits.shape[0], dtype=np.float64)
+        check(self._L.gsim_db_search_timed(self._h, _u32(queries), hits.shape[0], k, cutoff, metric, alpha, beta,
+                                           hits.ctypes.data_as(C.c_void_p), _u32(counts),
+                                           approx.ctypes.data_as(C.POINTER(C.c_uint64)), sec.ctypes.data_as(C.POINTER(C.c_double))))
+        return sec
 
     def search_cpu(self, queries, k, cutoff=0.0):
         q = np.ascontiguousarray(queries, dtype=np.uint32).reshape(-1, self.W)

@@ -3,6 +3,8 @@
 // (fingerprintdb_cuda.cu:341-381), gsim_db_search / _each / _device.
 #include "capi_internal.h"
 
+#include <chrono>
+
 namespace gsim_host
 {
 
@@ -445,6 +447,26 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout, &counts[q],
                         approx ? &approx[q] : nullptr, merged);
         if (rc != GSIM_OK) return rc;
+    }
+    return GSIM_OK;
+}
+
+int gsim_db_search_timed(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t kout, float cutoff, int metric, float alpha,
+                         float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx, double* seconds)
+{
+    int rc = check_search_args(db, queries, metric);
+    if (rc != GSIM_OK) return rc;
+    if ((!hits && kout && nq) || (!counts && nq) || (!seconds && nq)) return fail(GSIM_ERR_INVALID, "NULL output");
+    if (db->fold > 1) return fail(GSIM_ERR_STATE, "gsim_db_search_timed does not support folded tables");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(kout, db->nrows));
+    std::vector<gsim_hit> merged;
+    for (uint32_t q = 0; q < nq; q++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = search_one(db, queries + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout,
+                        &counts[q], approx ? &approx[q] : nullptr, merged);
+        if (rc != GSIM_OK) return rc;
+        seconds[q] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return GSIM_OK;
 }

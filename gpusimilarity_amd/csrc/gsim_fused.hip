@@ -325,20 +325,32 @@ struct FusedFilter {
     // below the positions just read.
     __device__ __forceinline__ void compact_store(int lane)
     {
+        // four batches of 64 entries per trip, all eight LDS reads in flight before the first write (a wave's LDS
+        // operations execute in order and the survivors land at or below positions already read: one read at a time cost
+        // ~2 us at the end of a 1 M-row scan -- a thousand entries per wave, a dependent LDS round trip per batch)
         uint32_t out = 0;
-        for (uint32_t base = 0; base < staged; base += 64) {
-            const uint32_t i = base + lane;
-            const bool in = i < staged;
-            const u64 key = in ? skey[i] : 0ull;
-            const uint32_t cb = in ? scb[i] : 0u;
-            const bool keep = in && static_cast<uint32_t>(key >> 32) >= tau;
-            const u64 m = __ballot(keep);
-            if (keep) {
-                const uint32_t slot = out + lane_rank(m);
-                skey[slot] = key;
-                scb[slot] = cb;
+        for (uint32_t base = 0; base < staged; base += 256) {
+            u64 key[4];
+            uint32_t cb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = base + 64u * u + lane;
+                const bool in = i < staged;
+                key[u] = in ? skey[i] : 0ull;
+                cb[u] = in ? scb[i] : 0u;
             }
-            out += static_cast<uint32_t>(__popcll(m));
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = base + 64u * u + lane;
+                const bool keep = i < staged && static_cast<uint32_t>(key[u] >> 32) >= tau;
+                const u64 m = __ballot(keep);
+                if (keep) {
+                    const uint32_t slot = out + lane_rank(m);
+                    skey[slot] = key[u];
+                    scb[slot] = cb[u];
+                }
+                out += static_cast<uint32_t>(__popcll(m));
+            }
         }
         staged = out;
     }
@@ -497,7 +509,21 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
     const bool active = fa.summ_keys != 0 && !(fa.xflags & 2u);
     const bool stay = active && sched.late();
     const unsigned long long t0 = wall_clock64();
+    // an election this workgroup's forwarder won (consumed with an exchange: a request stored between a plain load and a plain
+    // clear would be lost); the HIGHEST checkpoint whose election has been held is recorded: one election may serve two requests
+    // that the same workgroup won back to back, and only the last checkpoint's matters to those who wait
+    auto serve = [&]() -> bool {
+        uint32_t req = 0;
+        if (lane == 0 && __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) req = atomicExch(&sh.elect_req, 0u);
+        req = __builtin_amdgcn_readfirstlane(req);
+        if (!req || !active) return false;
+        fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the threshold is out before the count
+        if (lane == 0) atomicMax(&st->elected, req);
+        return true;
+    };
     for (uint32_t spins = 0;; spins++) {
+        (void) serve(); // (before the poll as well: the poll is a ~1.5 us round trip, and an election is the longest step of a checkpoint)
         const u64 ge = __hip_atomic_load(reinterpret_cast<const u64*>(&st->gtau), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // {gtau, elected}: one poll
         const uint32_t g = static_cast<uint32_t>(ge), el = static_cast<uint32_t>(ge >> 32);
         if (lane == 0) {
@@ -507,17 +533,9 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
         // a poll every ~2 us at first, every ~5 us from the 64th on, every ~60 us from the 512th on
         const uint32_t naps = spins < 512u ? 1u : 16u;
         for (uint32_t i = 0; i < naps; i++) {
-            uint32_t req = 0; // (consumed with an exchange: a request stored between a plain load and a plain clear would be lost)
-            if (lane == 0 && __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) req = atomicExch(&sh.elect_req, 0u);
-            req = __builtin_amdgcn_readfirstlane(req);
-            if (req && active) {
-                fused_elect(sh, st, fa.summ, nwaves, (k + fa.summ_keys - 1) / fa.summ_keys, lane, dbg);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the threshold is out before the count
-                // (the HIGHEST checkpoint whose election has been held: one election may serve two requests that the same
-                // workgroup won back to back, and only the last checkpoint's matters to those who wait)
-                if (lane == 0) atomicMax(&st->elected, req);
-                break; // (poll at once: this workgroup's own waves want the count too)
-            }
+            // (a request is served at the top of the loop -- one copy of the election code, it is fetched cold in every launch --
+            // and the poll right behind it: this workgroup's own waves want the count too)
+            if (__hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
             if (__hip_atomic_load(&sh.scan_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kScanBlock / 64 &&
                 __hip_atomic_load(&sh.fwd_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 &&
                 __hip_atomic_load(&sh.elect_req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {

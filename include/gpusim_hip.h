@@ -201,6 +201,12 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
 int gsim_db_search_each(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
                         float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
                         uint32_t* counts, uint64_t* approx);
+/* gsim_db_search for nq queries strictly ONE AT A TIME -- nothing enqueued ahead, unlike gsim_db_search_each -- with the
+ * wall time of each, measured inside the library around the single-query path: seconds[q] = query q in host memory ->
+ * its hits in host memory (the reference's server logs the same interval per request, gpusim.cpp:420-429).  What a
+ * caller of gsim_db_search with nq = 1 waits for, without the caller's own binding overhead. */
+int gsim_db_search_timed(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, int metric,
+                         float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx, double* seconds);
 /* FingerprintDB::search_cpu      fingerprintdb_cuda.cpp:20-54: the reference's
  * explicit host path (TanimotoFunctorCPU on all host threads + the partial
  * bubble sort of :92-103).  Same outputs as gsim_db_search, but reference
