@@ -248,7 +248,7 @@ struct FusedFilter {
 
     template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane)
     {
-        if constexpr (LPR <= 4) {
+        if constexpr (LPR >= 1 && LPR <= 4) { // (the register-streamed odd widths pass LPR = 64: their rows are wider than the proof covers)
             if (!has_cutoff) { // (wave-uniform)
                 update_prefilter(a);
                 const bool maybe = active && static_cast<float>(val >> 16) >= __builtin_fmaf(pk_kb, static_cast<float>(val & 0xFFFFu), pk_ka);
@@ -555,6 +555,8 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
     }
 }
 
+// LPR > 0: rows of LPR sixteen-byte units (a power of two), U loads per chunk.  LPR < 0: the register-streamed odd widths
+// (scan_rows_ragged<-LPR, U>: rows of 3, 5 or 7 x 2^i units, -LPR loads per sub-chunk, U sub-chunks per trip).
 template <int LPR, int U>
 __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeometry g, FusedArgs fa)
 {
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     __syncthreads();
     FusedSchedule sched;
-    constexpr int CHR = U * (64 / LPR); // rows per chunk
+    const uint32_t CHR = LPR > 0 ? static_cast<uint32_t>(U * (64 / (LPR > 0 ? LPR : 1))) : g.chunk_rows; // rows per chunk (trip)
     const u64 nfull = a.nrows / CHR;    // full chunks
     sched.init(static_cast<uint32_t>(nfull / g.nwaves));
     if (wv == kScanBlock / 64) {
@@ -610,7 +612,6 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wv);
     const uint32_t nwg = gridDim.x;
 
-    const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
     FusedFilter f;
     f.sh = &sh;
     f.st = st;
@@ -632,7 +633,12 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     f.ck_j = 0;
     f.next_ck = (f.M && !(fa.xflags & 2u)) ? sched.trip(0) : 0xFFFFFFFFu;
     f.dbg = dbg;
-    scan_rows<LPR, U>(a, g, f, q, w, lane);
+    if constexpr (LPR > 0) {
+        const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
+        scan_rows<LPR, U>(a, g, f, q, w, lane);
+    } else {
+        scan_rows_ragged<-LPR, U>(a, g, f, w, lane);
+    }
     if (sched.end_ck() && f.M && !(fa.xflags & 2u)) { // the checkpoint after the loop: this wave's M-th best over all its rows
         const u64 mth = f.mth_best(lane);
         if (lane == 0) {
@@ -1347,7 +1353,7 @@ hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedA
 bool fused_supported(const ScanGeometry& g)
 {
     // every workgroup of the grid is a selector and reads every workgroup's header with one thread
-    return g.lanes_per_row != 0 && g.unroll == 8 && g.nwaves <= static_cast<uint32_t>(kFusedSelectors) * (kScanBlock / 64);
+    return ((g.lanes_per_row != 0 && g.unroll == 8) || g.ragged_loads != 0) && g.nwaves <= static_cast<uint32_t>(kFusedSelectors) * (kScanBlock / 64);
 }
 
 // M of the checkpoint summaries ("my M-th best key"): about 2k / nwaves, so that the election's rank
@@ -1391,6 +1397,9 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
     GSIM_CASE(32)
     GSIM_CASE(64)
 #undef GSIM_CASE
+    if (g.ragged_loads == 3) return launch_fused_t<-3, 3>(a, g, f, s);
+    if (g.ragged_loads == 5) return launch_fused_t<-5, 2>(a, g, f, s);
+    if (g.ragged_loads == 7) return launch_fused_t<-7, 1>(a, g, f, s);
     return hipErrorInvalidValue;
 }
 

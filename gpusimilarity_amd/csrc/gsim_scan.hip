@@ -545,6 +545,7 @@ __global__ __launch_bounds__(kScanBlock) void sample_generic_kernel(ScanArgs a, 
 // ds_bpermute per load -- packed (common << 16 | popc): a chunk holds at most 8192 P <= 57 344 bits, neither field
 // overflows.  Lane r then scores row r of the chunk.  P <= 7: L in {3, 5, 7} x 2^i; other widths keep the LDS route.
 // C = sub-chunks per trip: a wave keeps 2 x C P KB in flight (register double buffer); C P ~ 7-9 loads, as the template path's 8.
+// (the loop itself: scan_rows_ragged, gsim_scan_inl.h -- the single launch runs it too)
 template <int P, int C> __global__ __launch_bounds__(kScanBlock) void scan_ragged_kernel(ScanArgs a, ScanGeometry g)
 {
     __shared__ BlockFilter s_filter;
@@ -554,90 +555,7 @@ template <int P, int C> __global__ __launch_bounds__(kScanBlock) void scan_ragge
     block_filter_init(&s_filter, a.k, a.state->gtau);
     WaveFilter f;
     f.init(&s_filter, a.state, a.cand + static_cast<u64>(w) * g.seg_cap, a.cand_cb + static_cast<u64>(w) * g.seg_cap, a.k, a.cutoff);
-    const uint32_t L = a.W / 4u;          // units per row
-    const uint32_t R = g.chunk_rows / C;  // rows per sub-chunk: 64 P / L
-    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
-    const u32x4* qu = reinterpret_cast<const u32x4*>(a.query);
-    u32x4 q[P];
-#pragma unroll
-    for (int j = 0; j < P; j++) q[j] = qu[(64u * j + static_cast<uint32_t>(lane)) % L];
-    // the last unit of this lane's row (lanes >= R have none: they read lane 0's and are inactive)
-    const uint32_t end_u = (static_cast<uint32_t>(lane) < R ? static_cast<uint32_t>(lane) + 1u : 1u) * L - 1u;
-    const uint32_t je = end_u >> 6;
-    const int le4 = static_cast<int>((end_u & 63u) * 4u);
-    const u64 total_units = a.nrows * L;
-    const u64 nfull = a.nrows / g.chunk_rows; // trips' worth of rows that are all present
-    uint32_t gt = 0;
-
-    // one sub-chunk: P loads = R whole rows; row0 = its first row
-    auto reduce = [&](const u32x4* d, u64 row0, bool full) {
-        uint32_t s[P];
-        uint32_t carry = 0;
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            const uint32_t cc = __popc(d[j].x & q[j].x) + __popc(d[j].y & q[j].y) + __popc(d[j].z & q[j].z) + __popc(d[j].w & q[j].w);
-            const uint32_t bb = __popc(d[j].x) + __popc(d[j].y) + __popc(d[j].z) + __popc(d[j].w);
-            uint32_t v = (cc << 16) + bb;
-            // inclusive prefix sum over the wave: within the rows of 16 lanes by DPP, then the rows' totals
-            v += dpp_shr<1>(v);
-            v += dpp_shr<2>(v);
-            v += dpp_shr<4>(v);
-            v += dpp_shr<8>(v);
-            const uint32_t t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47),
-                           t3 = __builtin_amdgcn_readlane(v, 63);
-            const int rowi = lane >> 4;
-            v += carry + (rowi > 0 ? t0 : 0u) + (rowi > 1 ? t1 : 0u) + (rowi > 2 ? t2 : 0u);
-            carry += t0 + t1 + t2 + t3;
-            s[j] = v;
-        }
-        uint32_t e = 0; // the prefix at this lane's row's last unit
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            const uint32_t x = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(le4, static_cast<int>(s[j])));
-            e = je == static_cast<uint32_t>(j) ? x : e;
-        }
-        uint32_t prev = static_cast<uint32_t>(__shfl_up(static_cast<int>(e), 1, 64)); // ... and at the previous row's
-        prev = lane == 0 ? 0u : prev;
-        const uint32_t val = e - prev; // (fieldwise: both prefixes are monotone and below 2^16, no borrow)
-        const u64 row = row0 + static_cast<u64>(lane);
-        const bool active = static_cast<uint32_t>(lane) < R && (full || row < a.nrows);
-        f.template offer_counts<0>(active, static_cast<uint32_t>(row), val, a, lane);
-    };
-
-    constexpr int NL = P * C; // loads per trip
-    if (w < nfull) {
-        const u64 last = w + (nfull - 1 - w) / g.nwaves * g.nwaves; // this wave's last full trip
-        u32x4 nxt[NL];
-        {
-            const u32x4* p = db + static_cast<u64>(w) * (64u * NL) + lane;
-#pragma unroll
-            for (int j = 0; j < NL; j++) nxt[j] = stream_load(p + j * 64);
-        }
-        uint32_t trip = 0;
-        for (u64 c = w;; c += g.nwaves) {
-            u32x4 d[NL];
-#pragma unroll
-            for (int j = 0; j < NL; j++) d[j] = nxt[j];
-            const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last; // (the final trip re-reads the last one: no branch in the body)
-            const u32x4* p = db + cn * (64u * NL) + lane;
-#pragma unroll
-            for (int j = 0; j < NL; j++) nxt[j] = stream_load(p + j * 64);
-            f.refresh(gt, lane);
-            gt = (trip++ & 7u) == 0 ? f.load_gtau() : 0u;
-#pragma unroll
-            for (int i = 0; i < C; i++) reduce(d + i * P, c * g.chunk_rows + static_cast<u64>(i) * R, true);
-            if (c == last) break;
-        }
-    }
-    if (nfull < g.nchunks && w == nfull % g.nwaves) { // the table's partial last trip
-        const u64 u0 = nfull * (64u * NL) + static_cast<u64>(lane);
-        u32x4 d[NL];
-#pragma unroll
-        for (int j = 0; j < NL; j++) d[j] = u0 + 64u * j < total_units ? stream_load(db + u0 + 64u * j) : u32x4{0, 0, 0, 0};
-        f.refresh(f.load_gtau(), lane);
-#pragma unroll
-        for (int i = 0; i < C; i++) reduce(d + i * P, nfull * g.chunk_rows + static_cast<u64>(i) * R, false);
-    }
+    scan_rows_ragged<P, C>(a, g, f, w, lane);
     f.finish(w, a, lane);
     block_filter_flush(&s_filter, a);
 }

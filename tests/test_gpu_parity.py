@@ -233,9 +233,10 @@ def test_generic_widths_match_oracle(n, W):
                                  (30_001, 96), (9_001, 192), (5_003, 448), (63, 28), (64, 28), (65, 28), (1, 12), (17, 48), (2_000_001, 28)])
 def test_register_streamed_odd_widths_match_oracle(n, W):
     """Rows of 3, 5 or 7 (x 2^i) sixteen-byte units -- 384-, 640-, 896-, 768-, 1536-, 1792-, 1280-, 3072-, 6144-, 14336-bit --
-    stream through registers (scan_ragged_kernel: prefix sums over the units of a chunk, a row's counts = the difference
-    of two prefixes); the same tables through the LDS-staged scan (GSIM_SCAN_RAGGED=0, a child process) give the same
-    bytes.  Whole chunks, ragged last chunks, tables shorter than one chunk, dense and sparse rows, a cutoff, Tversky."""
+    stream through registers (scan_rows_ragged: prefix sums over the units of a chunk, a row's counts = the difference of
+    two prefixes) -- inside the single launch for k <= 8192, in scan_ragged_kernel on the four-kernel pipeline (k = 9000
+    here, and GSIM_FUSED=0 in test_gpu_fused.py).  Whole chunks, ragged last chunks, tables shorter than one chunk, dense
+    and sparse rows, a cutoff, Tversky."""
     db = O.synth_rows(0x6A66 + W, n % 2, 0, n, W)
     t = make_table(db)
     q = db[O.query_row(1, n)]
