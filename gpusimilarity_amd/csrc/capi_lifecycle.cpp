@@ -115,11 +115,12 @@ int setup_shard(gsim_db* db, Shard& s)
     s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, unroll);
     s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
     s.fgeo = s.geo;
-    if (s.geo.nchunks < 4ull * s.geo.nwaves) { // small table: threshold checkpoints need a few trips per wave
-        // (128-bit rows: a chunk is 512 rows and a wave's LDS store holds 2048 -- three chunks per wave, so that a store
+    (void) gsim::fused_word_geometry(s.nrows, s.W, s.num_cus, &s.fgeo); // (rows of 3, 5, 7 or twice that many words: the single launch's own)
+    if (s.fgeo.nchunks < 4ull * s.fgeo.nwaves) { // small table: threshold checkpoints need a few trips per wave
+        // (narrow rows: a chunk is 512 rows and a wave's LDS store holds 2048 -- three chunks per wave, so that a store
         // cannot fill before the one threshold such a table sees, the one after the loop)
-        const uint64_t per = s.geo.lanes_per_row == 1 ? 3 : 4;
-        uint64_t nw = s.geo.nchunks / per / 4 * 4;
+        const uint64_t per = s.fgeo.chunk_rows > 512 ? 2 : (s.fgeo.chunk_rows == 512 ? 3 : 4);
+        uint64_t nw = s.fgeo.nchunks / per / 4 * 4;
         s.fgeo.nwaves = static_cast<uint32_t>(nw < 4 ? 4 : nw);
     }
     GSIM_HIP(hipMalloc(&s.d_query, static_cast<size_t>(s.W) * 4));

@@ -162,12 +162,13 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
         // Narrow rows (128 / 256 bits): a wave meets 512 / 256 rows per trip and its LDS store (2048 slots) is full after a
         // few trips -- before the first in-loop threshold has been elected (~12 us) -- so that sparse tables were handed back
-        // (1/64 of the queries at 256 bits, nearly all at 128: scanned twice).  A strided sample first (K0, ~25 us: the
+        // (1/64 of the queries at 256 bits, nearly all at 128: scanned twice).  A strided sample first (K0: the
         // four-kernel pipeline's own) leaves a valid starting threshold in QueryState::gtau as a coarse BIN; the single
         // launch turns it into a score key (xflags bit 2).
         static const int seed_narrow = env_int("GSIM_FUSED_SEED_NARROW", 1);
-        if (seed_narrow && s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2 && s.nrows > 1500ull * s.fgeo.nwaves && s.sample_chunks > 0 && k > 0) {
-            GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream)); // (one chunk per scan wave: 0.25-0.5 M rows, enough for a seed)
+        if (seed_narrow && ((s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2) || s.fgeo.ragged_words) && s.nrows > 1500ull * s.fgeo.nwaves &&
+            s.sample_chunks > 0 && k > 0) {
+            GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream)); // (sample_rows_kernel: 64 Ki ... 1 Mi rows, by k and the table)
             f.xflags |= 4u;
         }
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));

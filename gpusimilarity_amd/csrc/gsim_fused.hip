@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
@@ -79,6 +80,7 @@ struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
         struct { // while streaming
             u64 key[kScanBlock / 64][kFusedWaveCap];
             uint32_t cb[kScanBlock / 64][kFusedWaveCap];
+            uint32_t words[kScanBlock / 64][256 * 10]; // scan_rows_wragged's per-word counts (rows of 3, 5, 7 or twice that many words)
         } store;
         struct { // selectors
             u64 fkey[kFusedFinalLds];
@@ -556,8 +558,9 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
 }
 
 // LPR > 0: rows of LPR sixteen-byte units (a power of two), U loads per chunk.  LPR < 0: the register-streamed odd widths
-// (scan_rows_ragged<-LPR, U>: rows of 3, 5 or 7 x 2^i units, -LPR loads per sub-chunk, U sub-chunks per trip).
-template <int LPR, int U>
+// (scan_rows_ragged<-LPR, U>: rows of 3, 5 or 7 x 2^i units, -LPR loads per sub-chunk, U sub-chunks per trip); WORDS: rows of
+// -LPR = 3, 5, 7, 6, 10 or 14 words (scan_rows_wragged<-LPR, U>; its LDS area is FusedShared::store.words).
+template <int LPR, int U, bool WORDS = false>
 __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeometry g, FusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_smem[];
@@ -636,6 +639,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if constexpr (LPR > 0) {
         const u32x4 q = reinterpret_cast<const u32x4*>(a.query)[lane % LPR];
         scan_rows<LPR, U>(a, g, f, q, w, lane);
+    } else if constexpr (WORDS) {
+        scan_rows_wragged<-LPR, U>(a, g, f, w, lane, sh.store.words[wv]);
     } else {
         scan_rows_ragged<-LPR, U>(a, g, f, w, lane);
     }
@@ -1339,15 +1344,41 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
 
 } // namespace
 
-template <int LPR, int U>
+template <int LPR, int U, bool WORDS = false>
 hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
 {
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
+    const size_t lds = sizeof(FusedShared);
     static DynLdsOnce once;
-    const hipError_t e = once.ensure(reinterpret_cast<const void*>(fused_kernel<LPR, U>), sizeof(FusedShared));
+    const hipError_t e = once.ensure(reinterpret_cast<const void*>(fused_kernel<LPR, U, WORDS>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fused_kernel<LPR, U>), dim3(nblocks), dim3(kFusedBlock), sizeof(FusedShared), s, a, g, f);
+    hipLaunchKernelGGL((fused_kernel<LPR, U, WORDS>), dim3(nblocks), dim3(kFusedBlock), lds, s, a, g, f);
     return hipGetLastError();
+}
+
+// Rows of 3, 5, 7 or twice that many 32-bit words: the single launch streams them through registers at word granularity
+// (scan_rows_wragged); the four-kernel pipeline keeps its LDS-staged scan and its own geometry for them.
+bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out)
+{
+    static const int enabled = std::getenv("GSIM_SCAN_RAGGED") ? std::atoi(std::getenv("GSIM_SCAN_RAGGED")) : 1;
+    if (!enabled || W % 4 == 0 || W == 0) return false;
+    uint32_t odd = W;
+    while (odd % 2 == 0) odd /= 2;
+    if ((odd != 3 && odd != 5 && odd != 7) || W / odd > 2) return false;
+    ScanGeometry g{};
+    g.ragged_loads = odd;
+    g.ragged_words = 1;
+    g.unroll = odd == 3 ? 3 : (odd == 5 ? 2 : 1); // sub-chunks per trip
+    g.chunk_rows = g.unroll * (256u * odd / W);
+    g.nchunks = (nrows + g.chunk_rows - 1) / g.chunk_rows;
+    uint64_t nw = static_cast<uint64_t>(num_cus) * (kScanBlock / 64);
+    if (nw > g.nchunks) nw = g.nchunks;
+    if (nw < 1) nw = 1;
+    nw = (nw + 3) / 4 * 4;
+    g.nwaves = static_cast<uint32_t>(nw);
+    g.seg_cap = 0; // (no candidate segments: the single launch keeps its candidates in LDS)
+    *out = g;
+    return true;
 }
 
 bool fused_supported(const ScanGeometry& g)
@@ -1397,6 +1428,15 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
     GSIM_CASE(32)
     GSIM_CASE(64)
 #undef GSIM_CASE
+    if (g.ragged_words) {
+        if (a.W == 3) return launch_fused_t<-3, 3, true>(a, g, f, s);
+        if (a.W == 5) return launch_fused_t<-5, 2, true>(a, g, f, s);
+        if (a.W == 7) return launch_fused_t<-7, 1, true>(a, g, f, s);
+        if (a.W == 6) return launch_fused_t<-6, 3, true>(a, g, f, s);
+        if (a.W == 10) return launch_fused_t<-10, 2, true>(a, g, f, s);
+        if (a.W == 14) return launch_fused_t<-14, 1, true>(a, g, f, s);
+        return hipErrorInvalidValue;
+    }
     if (g.ragged_loads == 3) return launch_fused_t<-3, 3>(a, g, f, s);
     if (g.ragged_loads == 5) return launch_fused_t<-5, 2>(a, g, f, s);
     if (g.ragged_loads == 7) return launch_fused_t<-7, 1>(a, g, f, s);

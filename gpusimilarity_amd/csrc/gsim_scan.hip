@@ -39,6 +39,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -333,15 +335,18 @@ struct SampleFilter {
 __device__ __forceinline__ void sample_publish(const ScanArgs& a, uint32_t* s_hist, uint32_t& s_last, int lane)
 {
     __syncthreads();
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock)
-        if (s_hist[i]) atomicAdd(&a.state->ghist[i], s_hist[i]);
-    // ticket: the last workgroup turns the histogram into tau0 and clears it
-    __threadfence();
+    // No fences: a __threadfence() on this part writes the XCD's L2 back and invalidates it -- two per workgroup were most
+    // of a 20 us sample.  The adds are agent-scope atomics (performed at the coherence point) and RETURN: once the values are
+    // back they have been performed, the ticket after the barrier is ordered behind them; the last workgroup reads the
+    // table-wide histogram with agent-scope atomic loads.
+    uint32_t sink = 0;
+    for (int i = threadIdx.x; i < kScanBins; i += blockDim.x)
+        if (s_hist[i]) sink += __hip_atomic_fetch_add(&a.state->ghist[i], s_hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(sink));
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&a.state->done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&a.state->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (threadIdx.x < 64) {
         constexpr int PER = kScanBins / 64;
         uint32_t h[PER];
@@ -359,7 +364,7 @@ __device__ __forceinline__ void sample_publish(const ScanArgs& a, uint32_t* s_hi
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) a.state->ghist[i] = 0;
+    for (int i = threadIdx.x; i < kScanBins; i += blockDim.x) a.state->ghist[i] = 0;
 }
 
 template <int LPR, int U>
@@ -503,31 +508,92 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
     block_filter_flush(&s_filter, a);
 }
 
-// K0 for the generic widths: as sample_kernel, chunks through GenericChunk
-__global__ __launch_bounds__(kScanBlock) void sample_generic_kernel(ScanArgs a, uint32_t R, uint32_t nsample, u64 stride_chunks)
+// K0 for narrow rows (128 / 256 bits) and every width without a register-streaming template: one row per lane, 64
+// consecutive rows per sampled chunk, the row's words read by its lane (16-byte loads where rows are whole units) -- a
+// sample is 64 Ki ... 1 Mi rows (launch_sample), its access pattern does not matter.  What matters is the number of workgroups:
+// each adds its histogram to the table-wide one and takes a ticket, atomics on the same few addresses (1024 workgroups of
+// four waves: 67 us; 256: 21 us) -- sixteen waves per workgroup, at most 64 workgroups.
+constexpr int kSampleRowsBlock = 1024;
+__global__ __launch_bounds__(kSampleRowsBlock) void sample_rows_kernel(ScanArgs a, uint32_t nsample, u64 stride_chunks)
 {
     __shared__ uint32_t s_hist[kScanBins];
     __shared__ uint32_t s_last;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_words[];
     if (a.gate && *a.gate == 0) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t w = blockIdx.x * (kScanBlock / 64) + wv;
-    GenericChunk ch;
-    ch.init(a, R, s_words, wv);
-    for (int i = threadIdx.x; i < kScanBins; i += kScanBlock) s_hist[i] = 0;
+    const uint32_t w = blockIdx.x * (kSampleRowsBlock / 64) + (threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < kScanBins; i += kSampleRowsBlock) s_hist[i] = 0;
     __syncthreads();
     SampleFilter f;
     f.hist = s_hist;
     f.cutoff = a.cutoff;
     f.has_cutoff = a.cutoff > 0.0f;
-    const uint32_t nw = gridDim.x * (kScanBlock / 64);
-    for (uint32_t i = w; i < nsample; i += nw) {
-        const u64 c = static_cast<u64>(i) * stride_chunks; // a full chunk by construction
-        ch.load(c, lane);
-        uint32_t cc, bb;
-        ch.count(lane, cc, bb);
-        f.offer(static_cast<uint32_t>(lane) < R, 0u, score_of(a.metric, a.alpha, a.beta, a.qpop, bb, cc), 0u, lane);
+    const uint32_t nw = gridDim.x * (kSampleRowsBlock / 64);
+    const uint32_t W = a.W;
+    constexpr int NC = 4; // chunks in flight per wave (one row per lane: latency-bound)
+    for (uint32_t i = w; i < nsample; i += NC * nw) {
+        const uint32_t* p[NC];
+        bool valid[NC];
+        uint32_t cc[NC], bb[NC];
+#pragma unroll
+        for (int u = 0; u < NC; u++) {
+            valid[u] = i + u * nw < nsample;
+            const u64 chunk = static_cast<u64>(valid[u] ? i + u * nw : i) * stride_chunks; // a full chunk by construction
+            p[u] = static_cast<const uint32_t*>(a.rows) + (chunk * 64u + static_cast<u64>(lane)) * W;
+            cc[u] = bb[u] = 0;
+        }
+        if (W % 4 == 0) {
+            const u32x4* q4 = reinterpret_cast<const u32x4*>(a.query);
+            for (uint32_t t = 0; t < W / 4; t++) {
+                const u32x4 q = q4[t];
+#pragma unroll
+                for (int u = 0; u < NC; u++) {
+                    const u32x4 d = reinterpret_cast<const u32x4*>(p[u])[t];
+                    cc[u] += __popc(d.x & q.x) + __popc(d.y & q.y) + __popc(d.z & q.z) + __popc(d.w & q.w);
+                    bb[u] += __popc(d.x) + __popc(d.y) + __popc(d.z) + __popc(d.w);
+                }
+            }
+        } else {
+            auto words = [&](auto ww) { // (a compile-time width: every load of the four rows issued before the first count)
+                constexpr uint32_t WW = decltype(ww)::value;
+                if constexpr (WW != 0) {
+                    uint32_t d[NC][WW];
+#pragma unroll
+                    for (int u = 0; u < NC; u++)
+#pragma unroll
+                        for (uint32_t t = 0; t < WW; t++) d[u][t] = p[u][t];
+#pragma unroll
+                    for (uint32_t t = 0; t < WW; t++) {
+                        const uint32_t q = a.query[t];
+#pragma unroll
+                        for (int u = 0; u < NC; u++) {
+                            cc[u] += __popc(d[u][t] & q);
+                            bb[u] += __popc(d[u][t]);
+                        }
+                    }
+                } else {
+                    for (uint32_t t = 0; t < W; t++) {
+                        const uint32_t q = a.query[t];
+#pragma unroll
+                        for (int u = 0; u < NC; u++) {
+                            const uint32_t x = p[u][t];
+                            cc[u] += __popc(x & q);
+                            bb[u] += __popc(x);
+                        }
+                    }
+                }
+            };
+            switch (W) {
+            case 3: words(std::integral_constant<uint32_t, 3>{}); break;
+            case 5: words(std::integral_constant<uint32_t, 5>{}); break;
+            case 6: words(std::integral_constant<uint32_t, 6>{}); break;
+            case 7: words(std::integral_constant<uint32_t, 7>{}); break;
+            case 10: words(std::integral_constant<uint32_t, 10>{}); break;
+            case 14: words(std::integral_constant<uint32_t, 14>{}); break;
+            default: words(std::integral_constant<uint32_t, 0>{}); break;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NC; u++) f.offer(valid[u], 0u, score_of(a.metric, a.alpha, a.beta, a.qpop, bb[u], cc[u]), 0u, lane);
     }
     sample_publish(a, s_hist, s_last, lane);
 }
@@ -735,10 +801,23 @@ hipError_t launch_sample_t(const ScanArgs& a, uint32_t nsample, uint64_t stride,
 hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s)
 {
     if (a.k == 0 || chunks_per_wave == 0) return hipSuccess;
-    // rows per sampled chunk: the scan's chunk -- for the register-streamed odd widths one sub-chunk (<= 64 rows: the sample
-    // kernel of the generic widths scores one row per lane), and more of them (the same number of rows as the template path)
-    const uint32_t chunk_rows = g.ragged_loads ? g.chunk_rows / g.unroll : g.chunk_rows;
-    if (g.ragged_loads) chunks_per_wave *= chunk_rows >= 64 ? 1u : 64u / chunk_rows;
+    if (g.lanes_per_row == 0 || g.lanes_per_row <= 2) {
+        // sample_rows_kernel, chunks of 64 rows.  The k-th best of a sample of S rows out of N leaves ~k N / S rows above it:
+        // S = k N / 2^15 keeps that at ~32 Ki rows (a few dozen per scan wave) -- at least 64 Ki rows, at most 1 Mi, never
+        // more than 1/8 of the table; under 64 Ki the scan's own warm-up is cheaper.
+        uint64_t want = (static_cast<uint64_t>(a.k) * a.nrows) >> 15;
+        if (want < 65536) want = 65536;
+        if (want > (1u << 20)) want = 1u << 20;
+        if (want > a.nrows / 8) want = a.nrows / 8;
+        if (want < 65536) return hipSuccess;
+        const uint32_t nsample = static_cast<uint32_t>(want / 64);
+        const uint64_t stride = (a.nrows / 64) / nsample;
+        uint32_t nblocks = 64;
+        if (nblocks > nsample / (kSampleRowsBlock / 64)) nblocks = nsample / (kSampleRowsBlock / 64);
+        hipLaunchKernelGGL(sample_rows_kernel, dim3(nblocks), dim3(kSampleRowsBlock), 0, s, a, nsample, stride);
+        return hipGetLastError();
+    }
+    const uint32_t chunk_rows = g.chunk_rows;
     const uint64_t nfull = a.nrows / chunk_rows;
     // never sample more than 1/8 of the table; under one chunk per wave the scan's own warm-up is cheaper
     const uint64_t fit = nfull / (8ull * g.nwaves);
@@ -748,15 +827,6 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     const uint64_t stride = nfull / want;
     const uint32_t nsample = static_cast<uint32_t>(want);
     const uint32_t nblocks = g.nwaves / (kScanBlock / 64);
-    if (g.lanes_per_row == 0) {
-        const uint32_t lds = generic_lds_bytes(a.W, chunk_rows);
-        static DynLdsOnce once;
-        const hipError_t e = once.ensure(reinterpret_cast<const void*>(sample_generic_kernel), kGenericLdsBytes);
-        if (e != hipSuccess) return e;
-        if (lds > kGenericLdsBytes) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(sample_generic_kernel, dim3(nblocks), dim3(kScanBlock), lds, s, a, chunk_rows, nsample, stride);
-        return hipGetLastError();
-    }
 #define GSIM_CASE(L, UU) \
     if (g.lanes_per_row == L && g.unroll == UU) return launch_sample_t<L, UU>(a, nsample, stride, nblocks, s);
     GSIM_CASE(8, 8)
@@ -765,8 +835,6 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     GSIM_CASE(16, 8)
     GSIM_CASE(16, 4)
     GSIM_CASE(16, 16)
-    GSIM_CASE(1, 8)
-    GSIM_CASE(2, 8)
     GSIM_CASE(4, 8)
     GSIM_CASE(32, 8)
     GSIM_CASE(64, 8)

@@ -223,6 +223,109 @@ __device__ __forceinline__ void scan_rows_ragged(const ScanArgs& a, const ScanGe
     }
 }
 
+// ... and for rows that are not even whole 16-byte units: WW = 3, 5, 7 or twice that many 32-bit words (96-, 160-, 224-, 192-,
+// 320-, 448-bit rows).  NL = PP x C consecutive wave loads (PP = the odd part of WW; NL KB = 256 NL words) hold 256 NL / WW
+// whole rows, several per lane.  Every lane counts its four words against the query words of their positions (4 NL query
+// words per lane, loaded once) and leaves the packed counts (common << 16 | row bits) in the wave's LDS area `wlds` in word
+// order; lane l then sums the WW words of row 64 i + l (ds_read_b32 at a stride of WW words: odd, or twice odd read as
+// b64 -- conflict-free).  No cross-lane arithmetic at all: with one streaming wave per SIMD the DPP prefix sum this replaced
+// cost twice the instructions and all of their latency.
+template <int WW, int C, typename Filter>
+__device__ __forceinline__ void scan_rows_wragged(const ScanArgs& a, const ScanGeometry& g, Filter& f, uint32_t w, int lane, uint32_t* wlds)
+{
+    constexpr int PP = WW % 2 ? WW : WW / 2;
+    constexpr int NL = PP * C;
+    constexpr uint32_t TR = 256u * NL / WW; // rows per trip (= g.chunk_rows)
+    static_assert((256 * NL) % WW == 0 && TR % 64 == 0, "a trip holds whole rows, 64 at a time");
+    const u32x4* __restrict__ db = reinterpret_cast<const u32x4*>(a.rows);
+    u32x4 q[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const uint32_t w0 = 4u * (64u * j + static_cast<uint32_t>(lane));
+        q[j] = u32x4{a.query[w0 % WW], a.query[(w0 + 1u) % WW], a.query[(w0 + 2u) % WW], a.query[(w0 + 3u) % WW]};
+    }
+    const u64 total_words = a.nrows * WW;
+    const u64 total_units = (total_words + 3u) / 4u;
+    const u64 nfull = a.nrows / TR;
+    uint32_t gt = 0;
+    u32x4* wl4 = reinterpret_cast<u32x4*>(wlds);
+
+    auto reduce = [&](const u32x4* d, u64 row0, bool full) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            wl4[64 * j + lane] = u32x4{(static_cast<uint32_t>(__popc(d[j].x & q[j].x)) << 16) + __popc(d[j].x),
+                                       (static_cast<uint32_t>(__popc(d[j].y & q[j].y)) << 16) + __popc(d[j].y),
+                                       (static_cast<uint32_t>(__popc(d[j].z & q[j].z)) << 16) + __popc(d[j].z),
+                                       (static_cast<uint32_t>(__popc(d[j].w & q[j].w)) << 16) + __popc(d[j].w)};
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier(); // (one wave: its LDS operations execute in order)
+        uint32_t val[TR / 64];
+#pragma unroll
+        for (uint32_t rr = 0; rr < TR / 64u; rr++) {
+            const uint32_t r = 64u * rr + static_cast<uint32_t>(lane);
+            uint32_t v = 0;
+            if constexpr (WW % 2 == 0) {
+                const uint2* p2 = reinterpret_cast<const uint2*>(wlds) + r * (WW / 2);
+#pragma unroll
+                for (int t = 0; t < WW / 2; t++) v += p2[t].x + p2[t].y;
+            } else {
+                const uint32_t* p1 = wlds + r * WW;
+#pragma unroll
+                for (int t = 0; t < WW; t++) v += p1[t];
+            }
+            val[rr] = v;
+        }
+#pragma unroll
+        for (uint32_t rr = 0; rr < TR / 64u; rr++) {
+            const u64 row = row0 + 64u * rr + static_cast<uint32_t>(lane);
+            f.template offer_counts<1>(full || row < a.nrows, static_cast<uint32_t>(row), val[rr], a, lane);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier(); // the next trip overwrites the area
+    };
+
+    if (w < nfull) {
+        const u64 last = w + (nfull - 1 - w) / g.nwaves * g.nwaves;
+        u32x4 nxt[NL];
+        {
+            const u32x4* p = db + static_cast<u64>(w) * (64u * NL) + lane;
+#pragma unroll
+            for (int j = 0; j < NL; j++) nxt[j] = stream_load(p + j * 64);
+        }
+        uint32_t trip = 0;
+        for (u64 c = w;; c += g.nwaves) {
+            u32x4 d[NL];
+#pragma unroll
+            for (int j = 0; j < NL; j++) d[j] = nxt[j];
+            const u64 cn = c + g.nwaves <= last ? c + g.nwaves : last;
+            const u32x4* p = db + cn * (64u * NL) + lane;
+#pragma unroll
+            for (int j = 0; j < NL; j++) nxt[j] = stream_load(p + j * 64);
+            f.refresh(gt, lane);
+            gt = (trip++ & 7u) == 0 ? f.load_gtau() : 0u;
+            reduce(d, c * TR, true);
+            if (Filter::kFused) f.checkpoint(trip, lane);
+            if (c == last) break;
+        }
+    }
+    if (nfull < g.nchunks && w == nfull % g.nwaves) { // the table's partial last trip: whole units inside the table, the last one word by word
+        const u64 u0 = nfull * (64u * NL) + static_cast<u64>(lane);
+        const uint32_t* dbw = reinterpret_cast<const uint32_t*>(a.rows);
+        u32x4 d[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const u64 u = u0 + 64u * j;
+            if (4u * u + 4u <= total_words) d[j] = stream_load(db + u);
+            else if (u < total_units) d[j] = u32x4{4u * u < total_words ? dbw[4u * u] : 0u, 4u * u + 1u < total_words ? dbw[4u * u + 1u] : 0u,
+                                                   4u * u + 2u < total_words ? dbw[4u * u + 2u] : 0u, 0u};
+            else d[j] = u32x4{0, 0, 0, 0};
+        }
+        f.refresh(f.load_gtau(), lane);
+        reduce(d, nfull * TR, false);
+    }
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize, set once per device and kernel (whether the runtime keeps the attribute
 // per function or per device is its business; a multi-device handle launches the same kernel on several devices).
 struct DynLdsOnce {

@@ -51,7 +51,7 @@ for n in sizes:
     nq = max(1, tm["queries"])
     us = 1e6 * el / reps
     floor = n * (bits // 8) / 8e12 * 1e6
-    print("rows %11d  %8.1f us/query (C loop %7.1f)  (HBM floor %7.1f us, frac %.3f)  kernel %8.1f us  select %6.1f us  cand/q %8.0f  final/q %6.0f  handed back %d/64  fused=%s"
+    print("rows %11d  %8.1f us/query (C loop %7.1f)  (HBM floor %7.1f us, frac %.3f)  kernel %8.1f us  select %6.1f us  cand/q %8.0f  final/q %6.0f  handed back %d/64 (why %d)  fused=%s"
           % (n, us, 1e6 * el_c, floor, floor / us, 1e3 * tm["scan_ms_sum"] / nq, 1e3 * tm["select_ms_sum"] / nq,
-             tm["candidates_sum"] / nq, tm["finalists_sum"] / nq, tm["handed_back"], os.environ.get("GSIM_FUSED", "1")), flush=True)
+             tm["candidates_sum"] / nq, tm["finalists_sum"] / nq, tm["handed_back"], tm["handed_back_why"], os.environ.get("GSIM_FUSED", "1")), flush=True)
     t.close()

@@ -253,6 +253,24 @@ def test_register_streamed_odd_widths_match_oracle(n, W):
     t.close()
 
 
+@pytest.mark.parametrize("n,W", [(400_003, 5), (2_000_001, 5), (300_001, 6), (1_700_000, 6), (200_000, 3), (2_100_007, 3), (150_001, 7),
+                                 (120_000, 10), (90_003, 14), (1_600_001, 14), (255, 5), (256, 5), (257, 5), (1, 3), (100, 7), (513, 6)])
+def test_word_streamed_narrow_odd_widths_match_oracle(n, W):
+    """Rows of 3, 5, 7 or twice that many 32-bit words (96-, 160-, 224-, 192-, 320-, 448-bit: not whole 16-byte units) stream
+    through registers at word granularity inside the single launch (scan_rows_wragged: a prefix sum over the words of a
+    chunk through a per-wave LDS area); k = 9000 goes to the four-kernel pipeline and its LDS-staged scan.  Tables above
+    1500 rows per wave are seeded by the sample first.  Whole chunks, partial last trips whose last 16-byte unit is cut by
+    the end of the table, tables shorter than one chunk, a cutoff, Tversky."""
+    db = O.synth_rows(0x7A66 + W, n % 2, 0, n, W)
+    t = make_table(db)
+    q = db[O.query_row(1, n)]
+    for k, cutoff in ((1000, 0.0), (7, 0.0), (50, 0.2), (9000, 0.0)):
+        check_against_oracle(t, db, q, k, cutoff, ctx="words n=%d W=%d k=%d c=%g" % (n, W, k, cutoff))
+    check_against_oracle(t, db, O.synth_rows(0x5EED0003, 0, 5, 1, W)[0], 100, 0.0, ctx="words tversky W=%d" % W,
+                         metric=capi.METRIC_TVERSKY, alpha=np.float32(0.3), beta=np.float32(0.7))
+    t.close()
+
+
 def test_ragged_and_edge_sizes():
     W = 32
     for n in (1, 7, 63, 64, 65, 511, 513, 4095, 4097):
