@@ -1440,6 +1440,10 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
     if (g.ragged_loads == 3) return launch_fused_t<-3, 3>(a, g, f, s);
     if (g.ragged_loads == 5) return launch_fused_t<-5, 2>(a, g, f, s);
     if (g.ragged_loads == 7) return launch_fused_t<-7, 1>(a, g, f, s);
+    if (g.ragged_loads == 9) return launch_fused_t<-9, 1>(a, g, f, s);
+    if (g.ragged_loads == 11) return launch_fused_t<-11, 1>(a, g, f, s);
+    if (g.ragged_loads == 13) return launch_fused_t<-13, 1>(a, g, f, s);
+    if (g.ragged_loads == 15) return launch_fused_t<-15, 1>(a, g, f, s);
     return hipErrorInvalidValue;
 }
 

@@ -742,15 +742,15 @@ static bool is_pow2(uint32_t x)
     return x && !(x & (x - 1));
 }
 
-// loads per chunk of scan_ragged_kernel for rows of L sixteen-byte units: the odd part of L when that is 3, 5 or 7 and a
-// chunk holds at least one whole row (64 P / L >= 1), else 0
+// loads per chunk of scan_ragged_kernel for rows of L sixteen-byte units: the odd part of L when that is 3, 5, ... 15, a
+// chunk holds at least one whole row (64 P / L >= 1) and a row's bits fit the packed counts' 16-bit fields, else 0
 static uint32_t ragged_loads_of(uint32_t L)
 {
     static const int enabled = std::getenv("GSIM_SCAN_RAGGED") ? std::atoi(std::getenv("GSIM_SCAN_RAGGED")) : 1;
     if (!enabled || L == 0) return 0;
     uint32_t odd = L;
     while (odd % 2 == 0) odd /= 2;
-    if (odd != 3 && odd != 5 && odd != 7) return 0;
+    if (odd < 3 || odd > 15 || L * 128u > 65535u) return 0;
     return (64u * odd) % L == 0 && 64u * odd / L >= 1 ? odd : 0;
 }
 
@@ -764,9 +764,9 @@ ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_pe
         g.unroll = static_cast<uint32_t>(unroll);
         g.chunk_rows = g.unroll * (64 / lpr);
     } else if (W % 4 == 0 && ragged_loads_of(W / 4) != 0) {
-        // whole 16-byte units per row, odd part 3, 5 or 7: streamed through registers (scan_ragged_kernel)
+        // whole 16-byte units per row, odd part 3 ... 15: streamed through registers (scan_ragged_kernel)
         g.ragged_loads = ragged_loads_of(W / 4);
-        g.unroll = g.ragged_loads == 3 ? 3 : (g.ragged_loads == 5 ? 2 : 1); // sub-chunks per trip: 9, 10 or 7 loads in flight
+        g.unroll = g.ragged_loads == 3 ? 3 : (g.ragged_loads == 5 ? 2 : 1); // sub-chunks per trip: 9, 10 or P loads in flight
         g.chunk_rows = g.unroll * (64u * g.ragged_loads / (W / 4));
     } else {
         // generic widths: the four waves' chunks live in LDS (scan_generic_kernel), fewer rows per chunk when they are wide
@@ -863,6 +863,10 @@ hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s)
     if (g.ragged_loads == 3) hipLaunchKernelGGL((scan_ragged_kernel<3, 3>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
     else if (g.ragged_loads == 5) hipLaunchKernelGGL((scan_ragged_kernel<5, 2>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
     else if (g.ragged_loads == 7) hipLaunchKernelGGL((scan_ragged_kernel<7, 1>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    else if (g.ragged_loads == 9) hipLaunchKernelGGL((scan_ragged_kernel<9, 1>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    else if (g.ragged_loads == 11) hipLaunchKernelGGL((scan_ragged_kernel<11, 1>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    else if (g.ragged_loads == 13) hipLaunchKernelGGL((scan_ragged_kernel<13, 1>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
+    else if (g.ragged_loads == 15) hipLaunchKernelGGL((scan_ragged_kernel<15, 1>), dim3(nblocks), dim3(kScanBlock), 0, s, a, g);
     if (g.ragged_loads) return hipGetLastError();
     static DynLdsOnce once;
     const hipError_t e = once.ensure(reinterpret_cast<const void*>(scan_generic_kernel), kGenericLdsBytes);

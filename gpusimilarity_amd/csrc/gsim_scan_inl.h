@@ -180,7 +180,9 @@ __device__ __forceinline__ void scan_rows_ragged(const ScanArgs& a, const ScanGe
         }
         uint32_t prev = static_cast<uint32_t>(__shfl_up(static_cast<int>(e), 1, 64)); // ... and at the previous row's
         prev = lane == 0 ? 0u : prev;
-        const uint32_t val = e - prev; // (fieldwise: both prefixes are monotone and below 2^16, no borrow)
+        // (as 32-bit integers: the difference of the two prefixes is the sum over the row's units of common << 16 | bits, exact
+        // mod 2^32 whatever the prefixes have grown to -- a row's own bits fit 16 bits, ragged_loads_of)
+        const uint32_t val = e - prev;
         const u64 row = row0 + static_cast<u64>(lane);
         const bool active = static_cast<uint32_t>(lane) < R && (full || row < a.nrows);
         f.template offer_counts<64>(active, static_cast<uint32_t>(row), val, a, lane);

@@ -230,9 +230,11 @@ def test_generic_widths_match_oracle(n, W):
 
 
 @pytest.mark.parametrize("n,W", [(300_001, 28), (150_003, 48), (100_001, 12), (250_000, 20), (120_007, 24), (90_001, 56), (70_000, 40),
-                                 (30_001, 96), (9_001, 192), (5_003, 448), (63, 28), (64, 28), (65, 28), (1, 12), (17, 48), (2_000_001, 28)])
+                                 (30_001, 96), (9_001, 192), (5_003, 448), (63, 28), (64, 28), (65, 28), (1, 12), (17, 48), (2_000_001, 28),
+                                 (200_001, 36), (150_000, 44), (100_003, 52), (90_001, 60), (60_000, 72), (20_001, 240), (65, 36)])
 def test_register_streamed_odd_widths_match_oracle(n, W):
-    """Rows of 3, 5 or 7 (x 2^i) sixteen-byte units -- 384-, 640-, 896-, 768-, 1536-, 1792-, 1280-, 3072-, 6144-, 14336-bit --
+    """Rows of 3, 5, ... 15 (x 2^i) sixteen-byte units -- 384-, 640-, 896-, 768-, 1536-, 1792-, 1280-, 3072-, 6144-, 14336-bit,
+    1152-, 1408-, 1664-, 1920-, 2304-, 7680-bit --
     stream through registers (scan_rows_ragged: prefix sums over the units of a chunk, a row's counts = the difference of
     two prefixes) -- inside the single launch for k <= 8192, in scan_ragged_kernel on the four-kernel pipeline (k = 9000
     here, and GSIM_FUSED=0 in test_gpu_fused.py).  Whole chunks, ragged last chunks, tables shorter than one chunk, dense
