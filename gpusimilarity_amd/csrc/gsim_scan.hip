@@ -510,9 +510,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_generic_kernel(ScanArgs a, Sc
 
 // K0 for narrow rows (128 / 256 bits) and every width without a register-streaming template: one row per lane, 64
 // consecutive rows per sampled chunk, the row's words read by its lane (16-byte loads where rows are whole units) -- a
-// sample is 64 Ki ... 1 Mi rows (launch_sample), its access pattern does not matter.  What matters is the number of workgroups:
-// each adds its histogram to the table-wide one and takes a ticket, atomics on the same few addresses (1024 workgroups of
-// four waves: 67 us; 256: 21 us) -- sixteen waves per workgroup, at most 64 workgroups.
+// sample is 64 Ki ... 1 Mi rows (launch_sample), its access pattern does not matter.  What matters is the end of the kernel:
+// every workgroup adds its histogram to the table-wide one and takes a ticket (with the two fences sample_publish once had:
+// 1024 workgroups of four waves 67 us, 256: 21 us) -- sixteen waves per workgroup, at most 64 workgroups, no fences: 8.6 us.
 constexpr int kSampleRowsBlock = 1024;
 __global__ __launch_bounds__(kSampleRowsBlock) void sample_rows_kernel(ScanArgs a, uint32_t nsample, u64 stride_chunks)
 {
