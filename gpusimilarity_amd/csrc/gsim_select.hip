@@ -203,10 +203,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
     } else if (blockIdx.x == 0) {
         select_heavy(a, finalists, m2, row_base, keys, dhist, ctl, hdr, hits);
     }
-    // ticket: the last workgroup resets the state (all others are done reading it)
-    __threadfence();
+    // ticket: the last workgroup resets the state (all others are done reading it: what a workgroup read of the state it has
+    // used -- the values have arrived -- before its ticket; no fence, which on this part would write the XCD's L2 back)
     __syncthreads();
-    if (tid == 0) ctl[3] = (atomicAdd(&a.state->done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    if (tid == 0) ctl[3] = (__hip_atomic_fetch_add(&a.state->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (ctl[3]) {
         if (tid == 0) {
@@ -275,13 +275,14 @@ __global__ __launch_bounds__(256) void largek_pass_kernel(ScanArgs a, const u64*
         if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_h[(key >> shift) & 0xFFu], 1u);
     }
     __syncthreads();
-    if (s_h[tid]) atomicAdd(&lk->hist[tid], s_h[tid]);
-    __threadfence();
+    // (no fences, as sample_publish: the adds return, so they have been performed before the ticket behind the barrier)
+    uint32_t sink = 0;
+    if (s_h[tid]) sink = __hip_atomic_fetch_add(&lk->hist[tid], s_h[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(sink));
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&lk->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(&lk->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (tid < 64) {
         uint32_t h[4];
         uint32_t s4 = 0;
