@@ -133,7 +133,7 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
             const uint32_t npad = next_pow2_u32(kshard[i] ? kshard[i] : 1);
             if (!s.d_fq) {
                 GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_fq), static_cast<size_t>(W) * 4 + 64));
-                GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_key2), static_cast<size_t>(65536) * 8));
+                GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_key2), static_cast<size_t>(65536) * 16)); // (keys + the sort's second buffer)
                 GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cb2), static_cast<size_t>(65536) * 4));
                 GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_fq), static_cast<size_t>(W) * 4 + 64, kHostPinned));
             }

@@ -93,9 +93,9 @@ struct Shard {
     uint32_t* d_full = nullptr;
     uint32_t* d_fq = nullptr;              // the full query (+ one word: the NaN flag)
     uint32_t* h_fq = nullptr;              // ... its pinned staging
-    unsigned long long* d_key2 = nullptr;  // re-scored keys, 64 Ki
+    unsigned long long* d_key2 = nullptr;  // re-scored keys, 2 x 64 Ki (the sort's second buffer)
     uint32_t* d_cb2 = nullptr;
-    unsigned long long* d_large = nullptr; // k > kSelectCap: the gathered top-k keys (sorted in place), next_pow2(k) entries
+    unsigned long long* d_large = nullptr; // k > kSelectCap: the gathered top-k keys and the sort's second buffer, 2 x next_pow2(k) entries
     uint32_t large_cap = 0;
     gsim::LargeKState* d_lk = nullptr;
     bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)

@@ -204,7 +204,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             if (s.d_large) GSIM_HIP(hipFree(s.d_large));
             s.d_large = nullptr;
             s.large_cap = 0;
-            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_large), static_cast<size_t>(np2) * 8));
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_large), static_cast<size_t>(np2) * 16)); // (+ the sort's second buffer)
             s.large_cap = np2;
         }
         if (!s.d_lk) {
@@ -213,8 +213,9 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         }
         GSIM_HIP(hipMemsetAsync(s.d_large, 0, static_cast<size_t>(np2) * 8, s.stream));
         GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, s.stream));
-        GSIM_HIP(gsim::launch_bitonic_global(s.d_large, np2, s.stream));
-        GSIM_HIP(gsim::launch_emit_hits(a, s.d_large, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
+        unsigned long long* sorted = nullptr;
+        GSIM_HIP(gsim::launch_sort_desc(s.d_large, s.d_large + np2, np2, s.stream, &sorted));
+        GSIM_HIP(gsim::launch_emit_hits(a, sorted, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
         GSIM_HIP(gsim::launch_reset_state(s.d_state, s.d_lk, s.stream));
     }
     if (ev) {

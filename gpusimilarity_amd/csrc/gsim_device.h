@@ -161,8 +161,9 @@ hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s)
 hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
                                 unsigned long long* out, uint32_t out_cap, hipStream_t s);
 
-// Large-k path (k > kSelectCap): global-memory bitonic sort of all finalists.
-hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s);
+// Large-k path (k > kSelectCap): the gathered top-k keys sorted in two launches (tiles in LDS, positions by counting).
+// (n_pow2 keys, unique apart from zero padding; `tmp` holds n_pow2 more; *sorted = where the result is: keys or tmp)
+hipError_t launch_sort_desc(unsigned long long* keys, unsigned long long* tmp, uint32_t n_pow2, hipStream_t s, unsigned long long** sorted);
 hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s);
 hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, const LargeKState* lk,
                             uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags,

@@ -28,7 +28,7 @@
 //   K3 select_kernel   32 workgroups: every finalist's output slot is its rank (the
 //                      number of larger unique 64-bit keys), counted from LDS; more
 //                      than kSelectCap finalists: one workgroup runs an MSD radix
-//                      select; k > kSelectCap: global-memory bitonic sort.
+//                      select; k > kSelectCap: radix select + a two-launch sort.
 //
 // This file: K0-K2 of the four-kernel pipeline.  gsim_fused.hip: the single launch.  gsim_select.hip: K3, the large-k
 // route, folded re-score, merge.  gsim_scan_inl.h: the streaming loop they share.
@@ -47,6 +47,7 @@
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
+#include "gsim_prefilter.h"
 #include "gsim_scan_inl.h"
 
 namespace gsim
@@ -98,10 +99,30 @@ constexpr uint32_t kFirstPush = 64;
 struct WaveFilter {
     static constexpr bool kFused = false;
     __device__ __forceinline__ void checkpoint(uint32_t, int) {}
+    // Narrow rows (128 ... 512 bits): a wave meets 64 ... 512 rows per load and the score (an f32 divide per row) is most of
+    // the kernel -- 20 M x 128-bit rows: 149 us against the 40 us the bytes take.  Without a cutoff only rows that can reach
+    // the threshold bin need a score: the division-free test of the single launch (gsim_prefilter.h, proven for rows up to
+    // 512 bits), at the lower edge of the bin.  (With a cutoff every row at or above it is counted: all are scored.)
     template <int LPR> __device__ __forceinline__ void offer_counts(bool active, uint32_t row, uint32_t val, const ScanArgs& a, int lane)
     {
+        if constexpr (LPR >= 1 && LPR <= 4) {
+            if (!has_cutoff && k) { // (wave-uniform)
+                if (tau != pk_tau) { // (wave-uniform; the threshold moves a few times per query)
+                    pk_tau = tau;
+                    const PrefilterConstants pk = prefilter_constants(a.metric == GSIM_METRIC_TVERSKY, a.alpha, a.beta, a.qpop,
+                                                                      prefilter_level(true, static_cast<float>(tau) * (1.0f / kScanBins), 0u), true);
+                    pk_ka = pk.ka;
+                    pk_kb = pk.kb;
+                }
+                const bool maybe = active && static_cast<float>(val >> 16) >= __builtin_fmaf(pk_kb, static_cast<float>(val & 0xFFFFu), pk_ka);
+                if (__ballot(maybe) == 0) return; // no row of this round can reach the threshold bin: none is scored
+                active = maybe;                   // (a row the test rejects lies below the bin: not a candidate, and nothing counts it)
+            }
+        }
         offer_scored(*this, active, row, val, a, lane);
     }
+    uint32_t pk_tau;
+    float pk_ka, pk_kb;
     BlockFilter* sh;
     QueryState* st;
     u64* seg;         // this wave's private candidate segment (keys)
@@ -125,6 +146,9 @@ struct WaveFilter {
         k = kk;
         cutoff = cut;
         has_cutoff = cut > 0.0f; // fingerprintdb_cuda.cu:263: compaction only if cutoff > 0
+        pk_tau = 0; // (no threshold yet: everything passes)
+        pk_ka = 0.0f;
+        pk_kb = 0.0f;
         tau = kk ? state->gtau : static_cast<uint32_t>(kScanBins); // gtau: 0, or set by sample_kernel
         step = kk / 8 > 32 ? kk / 8 : 32;
         cursor = 0;

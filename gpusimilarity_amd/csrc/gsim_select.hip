@@ -1,5 +1,5 @@
 // gsim_select.hip -- behind the scan: K3 (exact select of the finalists, result emission), the large-k route (device
-// radix select + global bitonic sort), the folded tables' re-score, the merge of per-shard result blocks
+// radix select + a two-launch sort), the folded tables' re-score, the merge of per-shard result blocks
 // (fingerprintdb_cuda.cu:284-339, 363-380), the synthetic-table generator and the score table of the parity tests.
 #include "gsim_device.h"
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeK
 }
 
 // ---------------------------------------------------------------------------
-// large-k path (k > kSelectCap): bitonic sort of ALL finalists in global memory
+// large-k path (k > kSelectCap): radix select of the k-th key, gather, sort (launch_sort_desc)
 // (multi-launch), then emission of the first k.  Exact for any input.
 // ---------------------------------------------------------------------------
 
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u6
 // fingerprints (tanimoto_similarity_cpu, :387-399), stably sorted by the new score (top_results_bubble_sort: strict '>',
 // so ties keep the order of the folded list) and the first min(k, R) kept up to the first one below the cutoff.  The
 // reference does this on the host (slide 19 lists it as future GPU work); here the full rows are resident as well
-// (288 GB hold both) and three small launches do it: re-score into keys (score key << 32 | ~position), a bitonic sort
+// (288 GB hold both) and three small launches do it: re-score into keys (score key << 32 | ~position), a sort (launch_sort_desc)
 // of the <= 64 Ki keys, emission.  A NaN score (0 / 0: two empty fingerprints) is not ordered by '>': it raises a flag
 // and the host path, which has the literal bubble sort for that case, answers the query.
 __global__ __launch_bounds__(256) void fold_rescore_kernel(const void* folded_block, const uint32_t* full_rows, const uint32_t* full_query,
@@ -409,18 +409,78 @@ __global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64
     if (i < to) keys[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void bitonic_step_kernel(u64* keys, uint32_t n, uint32_t size, uint32_t stride)
+// Sorting 2 ... 64 Ki (and more) unique 64-bit keys, descending -- the large-k path's top-k keys and the folded tables' re-scored
+// candidates.  A global bitonic sort with one launch per step was 136 launches for 64 Ki keys (0.6 ms of launches for 0.02 ms of
+// work: a launch is ~5 us however little it does); with the steps that fit a tile run in LDS it was still 6 launches and
+// 143 us for 32 Ki keys (91 barrier-separated steps in the first).  Now two launches: every tile of kSortTile keys sorted in LDS
+// (one compare-exchange per thread and step), then every key's final position by counting -- its position in its own tile + for
+// every other tile the keys before it, found by a branch-free binary search (eight tiles' searches in flight per thread).
+// Equal keys (only the zero padding) are ordered by tile, so that the positions are a permutation.
+constexpr uint32_t kSortTile = 2048;
+constexpr int kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(u64* keys, uint32_t n)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n / 2) return;
-    const uint32_t lo = 2 * t - (t & (stride - 1));
-    const uint32_t hi = lo + stride;
-    const bool desc = (lo & size) == 0;
-    const u64 x = keys[lo], y = keys[hi];
-    if ((x < y) == desc) {
-        keys[lo] = y;
-        keys[hi] = x;
+    __shared__ u64 t[kSortTile];
+    const uint32_t tile = n < kSortTile ? n : kSortTile;
+    const uint32_t base = blockIdx.x * tile;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < tile; i += kSortThreads) t[i] = keys[base + i];
+    for (uint32_t sz = 2; sz <= tile; sz <<= 1) {
+        for (uint32_t stride = sz >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            if (tid < tile / 2) {
+                const uint32_t lo = 2 * tid - (tid & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool desc = (lo & sz) == 0; // (the last stage: sz = tile, every pair descending)
+                const u64 x = t[lo], y = t[hi];
+                if ((x < y) == desc) {
+                    t[lo] = y;
+                    t[hi] = x;
+                }
+            }
+        }
     }
+    __syncthreads();
+    for (uint32_t i = tid; i < tile; i += kSortThreads) keys[base + i] = t[i];
+}
+
+__global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__ keys, u64* __restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = keys[i];
+    const uint32_t ti = i / kSortTile, ntiles = n / kSortTile;
+    uint32_t rank = i % kSortTile;
+    constexpr int NC = 8;
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += NC) {
+        uint32_t cnt[NC];
+        const u64* tp[NC];
+        bool ge[NC]; // the keys of tile tj that come before `key`: x > key, and in earlier tiles also x == key
+#pragma unroll
+        for (int u = 0; u < NC; u++) {
+            const uint32_t tj = t0 + u < ntiles ? t0 + u : ti;
+            tp[u] = keys + static_cast<size_t>(tj) * kSortTile;
+            ge[u] = tj < ti;
+            cnt[u] = 0;
+        }
+        for (uint32_t step = kSortTile / 2; step > 0; step >>= 1) {
+#pragma unroll
+            for (int u = 0; u < NC; u++)
+            {
+                const u64 x = tp[u][cnt[u] + step - 1u];
+                if (x > key || (ge[u] && x == key)) cnt[u] += step;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NC; u++) {
+            const u64 x = tp[u][cnt[u]]; // (cnt <= kSortTile - 1 here)
+            if (x > key || (ge[u] && x == key)) cnt[u] += 1u;
+            const uint32_t tj = t0 + u;
+            rank += (tj < ntiles && tj != ti) ? cnt[u] : 0u;
+        }
+    }
+    out[rank] = key;
 }
 
 __global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, const LargeKState* lk,
@@ -559,9 +619,10 @@ hipError_t launch_fold_rescore(const void* folded_block, const uint32_t* full_ro
 {
     hipLaunchKernelGGL(fold_rescore_kernel, dim3((npad + 255) / 256), dim3(256), 0, s, folded_block, full_rows, full_query, W, qpop, keys, cbs,
                        npad, nan_flag);
-    hipError_t e = launch_bitonic_global(keys, npad, s);
+    unsigned long long* sorted = nullptr;
+    hipError_t e = launch_sort_desc(keys, keys + npad, npad, s, &sorted); // (the caller's buffer holds 2 npad keys)
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fold_emit_kernel, dim3((k + 255) / 256 ? (k + 255) / 256 : 1), dim3(256), 0, s, folded_block, keys, cbs, k, cutoff, row_base,
+    hipLaunchKernelGGL(fold_emit_kernel, dim3((k + 255) / 256 ? (k + 255) / 256 : 1), dim3(256), 0, s, folded_block, sorted, cbs, k, cutoff, row_base,
                        out_block);
     return hipGetLastError();
 }
@@ -583,14 +644,15 @@ hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* fin
     return hipGetLastError();
 }
 
-hipError_t launch_bitonic_global(unsigned long long* keys, uint32_t n_pow2, hipStream_t s)
+hipError_t launch_sort_desc(unsigned long long* keys, unsigned long long* tmp, uint32_t n_pow2, hipStream_t s, unsigned long long** sorted)
 {
+    *sorted = keys;
     if (n_pow2 < 2) return hipSuccess;
-    const uint32_t nb = (n_pow2 / 2 + 255) / 256;
-    for (uint32_t size = 2; size <= n_pow2 && size != 0; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            hipLaunchKernelGGL(bitonic_step_kernel, dim3(nb), dim3(256), 0, s, keys, n_pow2, size, stride);
-        }
+    const uint32_t tile = n_pow2 < kSortTile ? n_pow2 : kSortTile;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_pow2 / tile), dim3(kSortThreads), 0, s, keys, n_pow2);
+    if (n_pow2 > kSortTile) {
+        hipLaunchKernelGGL(rank_merge_kernel, dim3((n_pow2 + 255) / 256), dim3(256), 0, s, keys, tmp, n_pow2);
+        *sorted = tmp;
     }
     return hipGetLastError();
 }
