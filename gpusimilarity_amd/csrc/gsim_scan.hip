@@ -829,7 +829,8 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
         // sample_rows_kernel, chunks of 64 rows.  The k-th best of a sample of S rows out of N leaves ~k N / S rows above it:
         // S = k N / 2^15 keeps that at ~32 Ki rows (a few dozen per scan wave) -- at least 64 Ki rows, at most 1 Mi, never
         // more than 1/8 of the table; under 64 Ki the scan's own warm-up is cheaper.
-        uint64_t want = (static_cast<uint64_t>(a.k) * a.nrows) >> 15;
+        static const int shift = std::getenv("GSIM_SAMPLE_SHIFT") ? std::atoi(std::getenv("GSIM_SAMPLE_SHIFT")) : 15;
+        uint64_t want = (static_cast<uint64_t>(a.k) * a.nrows) >> shift;
         if (want < 65536) want = 65536;
         if (want > (1u << 20)) want = 1u << 20;
         if (want > a.nrows / 8) want = a.nrows / 8;

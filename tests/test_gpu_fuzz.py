@@ -52,3 +52,35 @@ def test_random_tables_and_queries_match_the_oracle(seed):
         assert int(approx[i]) == wap, ctx
         assert_hits_equal(hits[i], want, ctx)
     t.close()
+
+
+ODD_WIDTHS = [3, 5, 6, 7, 10, 14, 12, 20, 24, 28, 36, 44, 52, 60, 72, 9, 11, 17, 33]
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_odd_width_tables_match_the_oracle(seed):
+    """The same walk over the widths off the power-of-two template: rows of 3 ... 14 words (word-granular streaming inside the
+    single launch), of 3 ... 15 (x 2^i) sixteen-byte units (register-streamed), and a few that keep the LDS-staged scan; sizes
+    on both sides of the seeding rule (1500 rows per wave), k on both sides of 8192 (the four-kernel pipeline and its
+    two-launch sort above it)."""
+    rng = np.random.default_rng(0x0DD0 + seed)
+    W = ODD_WIDTHS[seed % len(ODD_WIDTHS)] if seed < len(ODD_WIDTHS) else int(rng.choice(ODD_WIDTHS))
+    n = int(np.exp(rng.uniform(np.log(200), np.log(3_000_000 if W <= 16 else 600_000))))
+    kind = int(rng.choice([0, 1]))
+    db = O.synth_rows(0x0DD00000 + seed, kind, 0, n, W)
+    t = make_table(db)
+    tv = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(rng.choice([0.3, 0.5, 1.0, 0.0])), beta=np.float32(rng.choice([0.7, 0.5, 1.0])))
+    for case in range(12):
+        own = rng.random() < 0.75
+        q = db[int(rng.integers(n))] if own else O.synth_rows(0x0DD09999 + seed, kind, 50 + case, 1, W)[0]
+        if case == 11 and seed % 4 == 0:
+            q = np.zeros(W, dtype=np.uint32)
+        k = int(rng.choice([1, 3, 20, 100, 1000, 1500, 2048, 3000, 5000, 8192, 9000, 20000, 40000]))
+        cutoff = float(rng.choice([0.0, 0.0, 0.0, 0.05, 0.2, 0.5, 0.9]))
+        kw = tv if rng.random() < 0.3 else {}
+        hits, approx = t.search(q, k, np.float32(cutoff), **kw)
+        want, wap = O.search(q, db, k, np.float32(cutoff), nthreads=8, **kw)
+        ctx = "seed %d case %d: n=%d W=%d kind=%d k=%d cutoff=%g %s" % (seed, case, n, W, kind, k, cutoff, "tversky" if kw else "tanimoto")
+        assert int(approx[0]) == wap, ctx
+        assert_hits_equal(hits[0], want, ctx)
+    t.close()
