@@ -334,8 +334,7 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
         "fingerprints_per_s": total_rows * steps * qps / elapsed,
         "whole_path_hbm_frac": (total_rows * (fp_bits // 8) / (elapsed / (steps * qps))) / (HBM_PEAK_GBS * 1e9 * ctx["world"]),
         "roofline": {
-            "kernel": ("fused_kernel<%d,8> (single launch: scan + publish + select)" % (W // 4)) if table_uses_fused(k, tm) else
-                      "scan_kernel<%d,8>" % (W // 4),
+            "kernel": kernel_label(W, table_uses_fused(k, tm)),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "traffic_note": "not collected for this entry (the headline entry runs the rocprofv3 --pmc passes)",
@@ -346,6 +345,23 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
         },
     }
     return res, ss
+
+
+def kernel_label(W, fused):
+    """The dominant kernel's name for rows of W words (csrc/gsim_fused.hip launch_fused, gsim_scan.hip launch_scan)."""
+    L = W // 4
+    if W % 4 == 0 and L & (L - 1) == 0:
+        return ("fused_kernel<%d,8> (single launch: scan + publish + select)" % L) if fused else "scan_kernel<%d,8>" % L
+    odd = W
+    while odd % 2 == 0:
+        odd //= 2
+    if W % 4 == 0 and odd <= 15:
+        c = {3: 3, 5: 2}.get(odd, 1)
+        return ("fused_kernel<-%d,%d> (single launch, rows of %d sixteen-byte units streamed through registers)" % (odd, c, L)) if fused \
+            else "scan_ragged_kernel<%d,%d>" % (odd, c)
+    if W in (3, 5, 7, 6, 10, 14) and fused:
+        return "fused_kernel<-%d,%d,words> (single launch, rows of %d words streamed at word granularity)" % (W, {3: 3, 6: 3, 5: 2, 10: 2}.get(W, 1), W)
+    return "scan_generic_kernel (LDS-staged rows, four-kernel pipeline)"
 
 
 def table_uses_fused(k, tm):
@@ -650,6 +666,23 @@ def main():
                          "queries_per_s": r5["queries_per_s"], "timed_region_s": r5["seconds"], "roofline": r5["roofline"]})
         except Exception as e:  # never lose the headline over it
             cfgs.append({"name": "BASELINE configs[4] per-GPU shape", "error": repr(e)})
+        # other row widths (the reference's --gpu_bitcount folds 1024-bit rows to 512 / 256 / 128 bits; MACCS-sized keys
+        # are 166 -> 192 bits): whole-query fraction of the HBM peak per width, 50 M rows (2048-bit: 30 M), top-1000
+        widths = []
+        for bits, rows in ((128, 50_000_000), (256, 50_000_000), (512, 50_000_000), (2048, 30_000_000), (160, 50_000_000), (192, 50_000_000),
+                           (896, 50_000_000), (1152, 30_000_000)):
+            try:
+                tw = capi.Table(bits)
+                tw.generate(DB_SEED, kind, 0, rows, device_index)
+                rw, _ = time_queries(ctx, tw, rows, rows, bits, kind, 1000, 4, 1, 32, False)
+                tw.close()
+                widths.append({"fp_bits": bits, "rows": rows, "ms_per_query": rw["ms_per_query"], "whole_path_hbm_frac": rw["whole_path_hbm_frac"],
+                               "kernel": rw["roofline"]["kernel"], "kernel_ms_avg": rw["roofline"]["kernel_ms_avg"], "kernel_hbm_frac": rw["roofline"]["frac"],
+                               "queries_handed_back": rw["roofline"]["queries_handed_back"],
+                               "sync_ms_median": rw["sync_latency"]["sync_ms_median"] if rw["sync_latency"] else None})
+            except Exception as e:  # never lose the headline over it
+                widths.append({"fp_bits": bits, "error": repr(e)})
+        out["widths"] = widths
         out["configs"] = cfgs
         out["configs_note"] = ("configs[0] (small.fsim, CPU path) is timed under cpu_baseline.parts; configs[3] (1B rows over 8 GPUs) "
                                "is this script at --gpus 8")
