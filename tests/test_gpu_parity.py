@@ -505,6 +505,35 @@ def test_baseline_sizes_whole_table_against_oracle(nrows, kind):
     del host
 
 
+@pytest.mark.parametrize("nrows,W", [(300_000_000, 5), (400_000_000, 4), (45_000_000, 36), (250_000_000, 6)])
+def test_large_tables_of_other_widths_whole_table_against_oracle(nrows, W):
+    """The widths that got their own streaming loops in round 4, at sizes whose byte offsets pass 4 GB: 160-bit and 192-bit rows
+    (word-granular streaming), 128-bit rows (seeded by sample_rows_kernel), 1152-bit rows (nine sixteen-byte units through
+    registers) -- generated in HBM by the product and row for row on the host by the oracle's generator, the GPU's full top-k
+    compared with the oracle's scan of ALL rows: self hit, fresh fingerprint, small k, a cutoff, and k above 8192 (the
+    four-kernel pipeline with its own scan for the width, radix select, two-launch sort)."""
+    seed, kind = 0x5EED0077 + W, capi.SYNTH_SPARSE
+    if capi.device_free_bytes(0) < nrows * W * 4 * 1.3:
+        pytest.skip("not enough free HBM")
+    nt = os.cpu_count() or 1
+    host = O.synth_rows_mt(seed, kind, 0, nrows, W, nt)
+    t = capi.Table(32 * W)
+    t.generate(seed, kind, 0, nrows, 0)
+    qrow = O.query_row(0, nrows)
+    q = t.row(qrow)
+    assert (q == host[qrow]).all() and (t.row(nrows - 1) == host[nrows - 1]).all()
+    fresh = O.synth_rows(0x5EED0002, kind, 77, 1, W)[0]
+    for i, (qq, kk, cut) in enumerate([(q, 1000, 0.0), (fresh, 1000, 0.0), (host[nrows - 3], 10, 0.0), (q, 500, 0.4), (host[O.query_row(2, nrows)], 9000, 0.0)]):
+        hits, approx = t.search(qq, kk, cut)
+        want, wap = O.search(qq, host, kk, cut, nthreads=nt)
+        assert int(approx[0]) == wap, "case %d" % i
+        assert_hits_equal(hits[0], want, "case %d (%d rows of %d words)" % (i, nrows, W))
+    tm = t.timing()
+    assert tm["blocks_torn"] == 0
+    t.close()
+    del host
+
+
 def test_folded_search_host_rescore_route_and_nan_scores():
     """The re-score of a folded table's candidates runs on the device when the full fingerprints are in HBM as well;
     the host route (the reference's, fingerprintdb_cuda.cu:307-331) stays: forced here through GSIM_FOLD_RESCORE=host in a
