@@ -204,19 +204,16 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             if (s.d_large) GSIM_HIP(hipFree(s.d_large));
             s.d_large = nullptr;
             s.large_cap = 0;
-            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_large), static_cast<size_t>(np2) * 16)); // (+ the sort's second buffer)
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_large), static_cast<size_t>(np2) * 8));
             s.large_cap = np2;
         }
         if (!s.d_lk) {
             GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_lk), sizeof(gsim::LargeKState)));
             GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
         }
-        GSIM_HIP(hipMemsetAsync(s.d_large, 0, static_cast<size_t>(np2) * 8, s.stream));
         GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, s.stream));
-        unsigned long long* sorted = nullptr;
-        GSIM_HIP(gsim::launch_sort_desc(s.d_large, s.d_large + np2, np2, s.stream, &sorted));
-        GSIM_HIP(gsim::launch_emit_hits(a, sorted, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
-        GSIM_HIP(gsim::launch_reset_state(s.d_state, s.d_lk, s.stream));
+        // (tiles sorted, then positions by counting + the hits + the header + the state's reset in one launch)
+        GSIM_HIP(gsim::launch_largek_sort_emit(a, s.d_large, np2, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
     }
     if (ev) {
         GSIM_HIP(hipEventRecord(ev[2], s.stream));

@@ -224,16 +224,16 @@ __global__ __launch_bounds__(kSelectThreads) void select_kernel(ScanArgs a, cons
     }
 }
 
-__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeKState* lk)
+__device__ __forceinline__ void reset_query_state(QueryState* st, LargeKState* lk, int tid, int nthreads)
 {
-    if (threadIdx.x == 0 && lk) {
+    if (tid == 0 && lk) {
         lk->prefix = 0;
         lk->remaining = 0;
         lk->ticket = 0;
         lk->count = 0;
         lk->all = 0;
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         st->ncand_sum += st->ncand;
         st->nfinal_sum += st->nfinal;
         st->queries += 1;
@@ -244,7 +244,12 @@ __global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeK
         st->gtau = 0;
         st->redo = 0;
     }
-    for (int i = threadIdx.x; i < kScanBins; i += 256) st->ghist[i] = 0;
+    for (int i = tid; i < kScanBins; i += nthreads) st->ghist[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeKState* lk)
+{
+    reset_query_state(st, lk, static_cast<int>(threadIdx.x), 256);
 }
 
 // ---------------------------------------------------------------------------
@@ -252,61 +257,69 @@ __global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeK
 // (multi-launch), then emission of the first k.  Exact for any input.
 // ---------------------------------------------------------------------------
 
-// The k-th largest finalist key by an MSD radix descent, one launch per byte, the finalist count read ON THE DEVICE:
-// nothing of the large-k path is sized by the host from a value it would have to wait for.  Pass p histograms byte
-// (7 - p) of the keys that match the prefix found so far (LDS histogram per workgroup, one global atomic per non-empty
-// bin); the last workgroup (ticket) picks the digit that holds the wanted rank, extends the prefix and clears the
-// histogram.  Fewer finalists than k: `all` is set and every finalist is taken.
+// The k-th largest finalist key by an MSD radix descent, one launch per digit of 8 bits (digits of 11 bits, six launches, were
+// tried: 8.6 us per pass instead of 5.5 -- a pass is its chain of global round trips, adds -> ticket -> the last workgroup's
+// reads, and 2048 bins lengthen it more than two passes fewer save), the finalist count read ON THE DEVICE: nothing of the
+// large-k path is sized by the host from a value it would have to wait for.  Pass p histograms bits [lo, hi) = [56 - 8 p, 64 - 8 p)
+// of the keys that match the prefix found so far (LDS histogram per workgroup, one global atomic per non-empty bin); the last workgroup
+// (ticket) picks the digit that holds the wanted rank, extends the prefix and clears the histogram.  Fewer finalists than k:
+// `all` is set and every finalist is taken.
+constexpr int kLargeKDigit = 8, kLargeKBins = 1 << kLargeKDigit, kLargeKPasses = 8;
+static_assert(kLargeKPasses * kLargeKDigit >= 64 && sizeof(LargeKState::hist) == kLargeKBins * 4, "the passes cover the key");
+
 __global__ __launch_bounds__(256) void largek_pass_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, int pass)
 {
-    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_h[kLargeKBins];
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     uint32_t nfinal = a.state->nfinal;
     if (nfinal > cap) nfinal = cap;
     if (pass > 0 && lk->all) return;
-    const int shift = 56 - 8 * pass;
+    const int hi = 64 - kLargeKDigit * pass, lo = hi > kLargeKDigit ? hi - kLargeKDigit : 0;
+    const u64 dmask = (1ull << (hi - lo)) - 1ull;
     const u64 prefix = lk->prefix;
     const uint32_t want = pass == 0 ? a.k : lk->remaining;
-    s_h[tid] = 0;
+    for (int i = tid; i < kLargeKBins; i += 256) s_h[i] = 0;
     __syncthreads();
     for (uint32_t i = blockIdx.x * 256 + tid; i < nfinal; i += gridDim.x * 256) {
         const u64 key = finalists[i];
-        if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_h[(key >> shift) & 0xFFu], 1u);
+        if (pass == 0 || (key >> hi) == prefix) atomicAdd(&s_h[(key >> lo) & dmask], 1u);
     }
     __syncthreads();
     // (no fences, as sample_publish: the adds return, so they have been performed before the ticket behind the barrier)
     uint32_t sink = 0;
-    if (s_h[tid]) sink = __hip_atomic_fetch_add(&lk->hist[tid], s_h[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = tid; i < kLargeKBins; i += 256)
+        if (s_h[i]) sink += __hip_atomic_fetch_add(&lk->hist[i], s_h[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(sink));
     __syncthreads();
     if (tid == 0) s_last = (__hip_atomic_fetch_add(&lk->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     if (tid < 64) {
-        uint32_t h[4];
-        uint32_t s4 = 0;
+        constexpr int PER = kLargeKBins / 64;
+        uint32_t h[PER];
+        uint32_t sm = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            h[i] = __hip_atomic_load(&lk->hist[tid * 4 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s4 += h[i];
+        for (int i = 0; i < PER; i++) {
+            h[i] = __hip_atomic_load(&lk->hist[tid * PER + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm += h[i];
         }
         uint32_t bin, cnt;
-        threshold_from_counts<4>(h, s4, want, tid, bin, cnt);
+        threshold_from_counts<PER>(h, sm, want, tid, bin, cnt);
         if (tid == 0) {
             if (cnt < want) { // (pass 0 only: fewer finalists than k)
                 lk->all = 1;
                 lk->prefix = 0;
             } else {
                 const uint32_t pop = __hip_atomic_load(&lk->hist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lk->prefix = (prefix << 8) | bin;
+                lk->prefix = (prefix << (hi - lo)) | bin;
                 lk->remaining = want - (cnt - pop);
             }
             lk->ticket = 0;
         }
     }
     __syncthreads();
-    lk->hist[tid] = 0;
+    for (int i = tid; i < kLargeKBins; i += 256) lk->hist[i] = 0;
 }
 
 // the keys at or above the k-th largest (exactly min(k, #finalists) of them: keys are unique) -> out[0 ..)
@@ -419,16 +432,26 @@ __global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64
 constexpr uint32_t kSortTile = 2048;
 constexpr int kSortThreads = 1024;
 
-__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(u64* keys, uint32_t n)
+__global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(u64* keys, uint32_t n, const uint32_t* count)
 {
     __shared__ u64 t[kSortTile];
     const uint32_t tile = n < kSortTile ? n : kSortTile;
     const uint32_t base = blockIdx.x * tile;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < tile; i += kSortThreads) t[i] = keys[base + i];
+    const uint32_t valid = count ? (*count < n ? *count : n) : n; // (slots past the gathered keys: padding, whatever the buffer holds)
+    for (uint32_t i = tid; i < tile; i += kSortThreads) t[i] = base + i < valid ? keys[base + i] : 0ull;
+    // (thread t's pair at strides up to 64 lies among the 128 elements its wave owns: such steps follow each other behind a
+    // wave barrier -- a wave's LDS operations execute in order --, only the steps at longer strides, and the first one
+    // after them, need the workgroup's: 14 of the 66 steps of a full tile)
+    uint32_t prev = 128;
     for (uint32_t sz = 2; sz <= tile; sz <<= 1) {
         for (uint32_t stride = sz >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
+            if (stride >= 128 || prev >= 128) __syncthreads();
+            else {
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            prev = stride;
             if (tid < tile / 2) {
                 const uint32_t lo = 2 * tid - (tid & (stride - 1));
                 const uint32_t hi = lo + stride;
@@ -445,10 +468,20 @@ __global__ __launch_bounds__(kSortThreads) void tile_sort_kernel(u64* keys, uint
     for (uint32_t i = tid; i < tile; i += kSortThreads) keys[base + i] = t[i];
 }
 
-__global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__ keys, u64* __restrict__ out, uint32_t n)
+struct LargeKEmit { // rank_merge_kernel<true>: the hit of every key goes to its position, the header, the state's reset
+    ScanArgs a;
+    LargeKState* lk;
+    uint32_t row_base, flags;
+    u64 approx_if_no_cutoff;
+    void* d_result;
+};
+
+__device__ __forceinline__ void reset_query_state(QueryState* st, LargeKState* lk, int tid, int nthreads);
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__ keys, u64* __restrict__ out, uint32_t n, LargeKEmit em)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x; // (the grid covers n exactly: n is a multiple of kSortTile)
     const u64 key = keys[i];
     const uint32_t ti = i / kSortTile, ntiles = n / kSortTile;
     uint32_t rank = i % kSortTile;
@@ -480,7 +513,24 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__
             rank += (tj < ntiles && tj != ti) ? cnt[u] : 0u;
         }
     }
-    out[rank] = key;
+    if (!EMIT) {
+        out[rank] = key;
+        return;
+    }
+    __shared__ uint32_t s_last;
+    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(em.d_result);
+    const uint32_t nkeys = em.lk->count < em.a.k ? em.lk->count : em.a.k;
+    if (rank < nkeys) emit_hit(em.a, key, em.row_base, reinterpret_cast<gsim_hit*>(hdr + 1) + rank); // (rank < count: a gathered key, not padding)
+    if (i == 0) {
+        hdr->count = nkeys;
+        hdr->flags = em.flags;
+        hdr->approx = em.a.cutoff > 0.0f ? em.a.state->kept : em.approx_if_no_cutoff;
+    }
+    // the last workgroup re-zeroes the per-query state (every workgroup has used what it read of it before its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&em.lk->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) reset_query_state(em.a.state, em.lk, static_cast<int>(threadIdx.x), 256);
 }
 
 __global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, const LargeKState* lk,
@@ -633,12 +683,12 @@ hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s)
     return hipGetLastError();
 }
 
-// k > kSelectCap: the k-th largest finalist key by eight radix passes, then the keys at or above it into `out`
-// (out_cap >= k entries; the caller zero-fills it and sorts it afterwards).  Nothing here is sized by the finalist count.
+// k > kSelectCap: the k-th largest finalist key by eight radix passes, then the keys at or above it into out[0 .. count)
+// (out_cap >= k entries; launch_largek_sort_emit sorts them and emits the hits).  Nothing here is sized by the finalist count.
 hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
                                 unsigned long long* out, uint32_t out_cap, hipStream_t s)
 {
-    for (int pass = 0; pass < 8; pass++)
+    for (int pass = 0; pass < kLargeKPasses; pass++)
         hipLaunchKernelGGL(largek_pass_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, pass);
     hipLaunchKernelGGL(largek_gather_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, out, out_cap);
     return hipGetLastError();
@@ -649,11 +699,21 @@ hipError_t launch_sort_desc(unsigned long long* keys, unsigned long long* tmp, u
     *sorted = keys;
     if (n_pow2 < 2) return hipSuccess;
     const uint32_t tile = n_pow2 < kSortTile ? n_pow2 : kSortTile;
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_pow2 / tile), dim3(kSortThreads), 0, s, keys, n_pow2);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_pow2 / tile), dim3(kSortThreads), 0, s, keys, n_pow2, static_cast<const uint32_t*>(nullptr));
     if (n_pow2 > kSortTile) {
-        hipLaunchKernelGGL(rank_merge_kernel, dim3((n_pow2 + 255) / 256), dim3(256), 0, s, keys, tmp, n_pow2);
+        hipLaunchKernelGGL(rank_merge_kernel<false>, dim3(n_pow2 / 256), dim3(256), 0, s, keys, tmp, n_pow2, LargeKEmit{});
         *sorted = tmp;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_largek_sort_emit(const ScanArgs& a, unsigned long long* keys, uint32_t n_pow2, LargeKState* lk, uint32_t row_base,
+                                   uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result, hipStream_t s)
+{
+    if (n_pow2 <= kSortTile) return hipErrorInvalidValue; // (k > kSelectCap = 8192: at least eight tiles)
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(n_pow2 / kSortTile), dim3(kSortThreads), 0, s, keys, n_pow2, &lk->count);
+    LargeKEmit em{a, lk, row_base, flags, approx_if_no_cutoff, d_result};
+    hipLaunchKernelGGL(rank_merge_kernel<true>, dim3(n_pow2 / 256), dim3(256), 0, s, keys, static_cast<u64*>(nullptr), n_pow2, em);
     return hipGetLastError();
 }
 
