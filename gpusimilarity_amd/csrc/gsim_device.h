@@ -156,23 +156,17 @@ struct LargeKState {
     uint32_t all;              // fewer finalists than k: every finalist is taken
     uint32_t hist[256];
 };
-// Re-zero the per-query part of the state (large-k path only; the select kernel does it otherwise).
-hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s);
 hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
                                 unsigned long long* out, uint32_t out_cap, hipStream_t s);
 
 // Large-k path (k > kSelectCap): the gathered top-k keys sorted in two launches (tiles in LDS, positions by counting).
 // (n_pow2 keys, unique apart from zero padding; `tmp` holds n_pow2 more; *sorted = where the result is: keys or tmp)
 hipError_t launch_sort_desc(unsigned long long* keys, unsigned long long* tmp, uint32_t n_pow2, hipStream_t s, unsigned long long** sorted);
-hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s);
 // ... the large-k path's last two launches: tiles sorted (slots past LargeKState::count read as padding -- nobody zero-fills
 // the buffer), then every key's position by counting AND its hit written there, the header, and -- the last workgroup -- the
-// per-query state re-zeroed (what launch_sort_desc + launch_emit_hits + launch_reset_state did in four launches and a fill)
+// per-query state re-zeroed (until round 4: a fill, the sort, an emission kernel and a reset kernel)
 hipError_t launch_largek_sort_emit(const ScanArgs& a, unsigned long long* keys, uint32_t n_pow2, LargeKState* lk, uint32_t row_base,
                                    uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result, hipStream_t s);
-hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, const LargeKState* lk,
-                            uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags,
-                            void* d_result, hipStream_t s);
 
 // Folded tables: re-score the candidates of a folded search (result block `folded_block`, device memory) with the full
 // fingerprints, stable sort by the new score, first min(k, .) at or above the cutoff -> out_block (fingerprintdb_cuda.cu:

@@ -247,11 +247,6 @@ __device__ __forceinline__ void reset_query_state(QueryState* st, LargeKState* l
     for (int i = tid; i < kScanBins; i += nthreads) st->ghist[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void reset_state_kernel(QueryState* st, LargeKState* lk)
-{
-    reset_query_state(st, lk, static_cast<int>(threadIdx.x), 256);
-}
-
 // ---------------------------------------------------------------------------
 // large-k path (k > kSelectCap): radix select of the k-th key, gather, sort (launch_sort_desc)
 // (multi-launch), then emission of the first k.  Exact for any input.
@@ -416,12 +411,6 @@ __global__ __launch_bounds__(256) void fold_emit_kernel(const void* folded_block
     }
 }
 
-__global__ __launch_bounds__(256) void fill_keys_kernel(u64* keys, u64 from, u64 to)
-{
-    const u64 i = from + static_cast<u64>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < to) keys[i] = 0;
-}
-
 // Sorting 2 ... 64 Ki (and more) unique 64-bit keys, descending -- the large-k path's top-k keys and the folded tables' re-scored
 // candidates.  A global bitonic sort with one launch per step was 136 launches for 64 Ki keys (0.6 ms of launches for 0.02 ms of
 // work: a launch is ~5 us however little it does); with the steps that fit a tile run in LDS it was still 6 launches and
@@ -531,22 +520,6 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__
     if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&em.lk->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
     __syncthreads();
     if (s_last) reset_query_state(em.a.state, em.lk, static_cast<int>(threadIdx.x), 256);
-}
-
-__global__ __launch_bounds__(256) void emit_hits_kernel(ScanArgs a, const u64* sorted_keys, const LargeKState* lk,
-                                                        uint32_t row_base, u64 approx_if_no_cutoff, uint32_t flags,
-                                                        void* d_result)
-{
-    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
-    gsim_hit* hits = reinterpret_cast<gsim_hit*>(hdr + 1);
-    const uint32_t nkeys = lk->count < a.k ? lk->count : a.k;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nkeys) emit_hit(a, sorted_keys[i], row_base, hits + i);
-    if (i == 0) {
-        hdr->count = nkeys;
-        hdr->flags = flags;
-        hdr->approx = a.cutoff > 0.0f ? a.state->kept : approx_if_no_cutoff;
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -677,12 +650,6 @@ hipError_t launch_fold_rescore(const void* folded_block, const uint32_t* full_ro
     return hipGetLastError();
 }
 
-hipError_t launch_reset_state(QueryState* state, LargeKState* lk, hipStream_t s)
-{
-    hipLaunchKernelGGL(reset_state_kernel, dim3(1), dim3(256), 0, s, state, lk);
-    return hipGetLastError();
-}
-
 // k > kSelectCap: the k-th largest finalist key by eight radix passes, then the keys at or above it into out[0 .. count)
 // (out_cap >= k entries; launch_largek_sort_emit sorts them and emits the hits).  Nothing here is sized by the finalist count.
 hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
@@ -714,24 +681,6 @@ hipError_t launch_largek_sort_emit(const ScanArgs& a, unsigned long long* keys, 
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_pow2 / kSortTile), dim3(kSortThreads), 0, s, keys, n_pow2, &lk->count);
     LargeKEmit em{a, lk, row_base, flags, approx_if_no_cutoff, d_result};
     hipLaunchKernelGGL(rank_merge_kernel<true>, dim3(n_pow2 / 256), dim3(256), 0, s, keys, static_cast<u64*>(nullptr), n_pow2, em);
-    return hipGetLastError();
-}
-
-hipError_t launch_fill_zero_keys(unsigned long long* keys, uint64_t from, uint64_t to, hipStream_t s)
-{
-    if (to <= from) return hipSuccess;
-    const uint64_t nb = (to - from + 255) / 256;
-    hipLaunchKernelGGL(fill_keys_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, keys, from, to);
-    return hipGetLastError();
-}
-
-hipError_t launch_emit_hits(const ScanArgs& a, const unsigned long long* sorted_keys, const LargeKState* lk,
-                            uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result,
-                            hipStream_t s)
-{
-    const uint32_t nb = a.k ? (a.k + 255) / 256 : 1; // (the kernel emits min(k, gathered) hits)
-    hipLaunchKernelGGL(emit_hits_kernel, dim3(nb), dim3(256), 0, s, a, sorted_keys, lk, row_base,
-                       approx_if_no_cutoff, flags, d_result);
     return hipGetLastError();
 }
 
