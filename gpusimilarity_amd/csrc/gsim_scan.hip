@@ -828,13 +828,14 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     if (g.lanes_per_row == 0 || g.lanes_per_row <= 2) {
         // sample_rows_kernel, chunks of 64 rows.  The k-th best of a sample of S rows out of N leaves ~k N / S rows above it:
         // S = k N / 2^15 keeps that at ~32 Ki rows (a few dozen per scan wave) -- at least 64 Ki rows, at most 1 Mi, never
-        // more than 1/8 of the table; under 64 Ki the scan's own warm-up is cheaper.
+        // more than 1/8 of the table (down to 16 Ki rows, tables of 131 k rows: sparse 128-bit tables of 0.5 M rows were
+        // handed back one query in ten without a seed); under that the scan's own warm-up is cheaper.
         static const int shift = std::getenv("GSIM_SAMPLE_SHIFT") ? std::atoi(std::getenv("GSIM_SAMPLE_SHIFT")) : 15;
         uint64_t want = (static_cast<uint64_t>(a.k) * a.nrows) >> shift;
         if (want < 65536) want = 65536;
         if (want > (1u << 20)) want = 1u << 20;
         if (want > a.nrows / 8) want = a.nrows / 8;
-        if (want < 65536) return hipSuccess;
+        if (want < 16384) return hipSuccess;
         const uint32_t nsample = static_cast<uint32_t>(want / 64);
         const uint64_t stride = (a.nrows / 64) / nsample;
         uint32_t nblocks = 64;
