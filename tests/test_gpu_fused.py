@@ -38,7 +38,8 @@ def overflowing_table():
 
 @pytest.mark.parametrize("n,W", [(700, 32), (4_097, 32), (65_000, 32), (300_000, 32), (1_300_000, 32), (2_500_000, 8),
                                  (400_000, 64), (250_000, 4), (120_000, 128), (90_000, 256),
-                                 (1_100_000, 28), (600_000, 48), (300_000, 20), (5_000, 12), (70_000, 96)])
+                                 (1_100_000, 28), (600_000, 48), (300_000, 20), (5_000, 12), (70_000, 96),
+                                 (2_000_000, 5), (300_000, 6), (900_000, 3), (150_000, 14), (700_000, 36), (200_000, 60), (400_000, 4)])
 def test_single_launch_path_is_taken_and_exact(n, W):
     """Table sizes on either side of every geometry switch (tiny grids without thresholds, few trips
     with the end-of-scan checkpoint, many trips), all specialised widths; k from 1 to the path's
