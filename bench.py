@@ -359,7 +359,7 @@ def kernel_label(W, fused):
         c = {3: 3, 5: 2}.get(odd, 1)
         return ("fused_kernel<-%d,%d> (single launch, rows of %d sixteen-byte units streamed through registers)" % (odd, c, L)) if fused \
             else "scan_ragged_kernel<%d,%d>" % (odd, c)
-    if W in (3, 5, 7, 6, 10, 14) and fused:
+    if W in (3, 5, 7, 6, 10, 14, 9, 11, 18, 22) and fused:
         return "fused_kernel<-%d,%d,words> (single launch, rows of %d words streamed at word granularity)" % (W, {3: 3, 6: 3, 5: 2, 10: 2}.get(W, 1), W)
     return "scan_generic_kernel (LDS-staged rows, four-kernel pipeline)"
 

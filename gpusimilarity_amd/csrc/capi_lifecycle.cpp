@@ -115,7 +115,7 @@ int setup_shard(gsim_db* db, Shard& s)
     s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, unroll);
     s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
     s.fgeo = s.geo;
-    (void) gsim::fused_word_geometry(s.nrows, s.W, s.num_cus, &s.fgeo); // (rows of 3, 5, 7 or twice that many words: the single launch's own)
+    (void) gsim::fused_word_geometry(s.nrows, s.W, s.num_cus, &s.fgeo); // (rows of 3 ... 11 or twice that many words: the single launch's own)
     if (s.fgeo.nchunks < 4ull * s.fgeo.nwaves) { // small table: threshold checkpoints need a few trips per wave
         // (narrow rows: a chunk is 512 rows and a wave's LDS store holds 2048 -- three chunks per wave, so that a store
         // cannot fill before the one threshold such a table sees, the one after the loop)

@@ -71,7 +71,7 @@ struct ScanGeometry {
     uint64_t nchunks;
     uint32_t ragged_loads;  // generic widths that are whole 16-byte units per row, not a power of two (896, 1536 ... bits): loads per
                             // chunk of scan_ragged_kernel (the odd part of W / 4: 3, 5 or 7), 0 = the LDS-staged generic scan
-    uint32_t ragged_words;  // 1: rows are NOT whole 16-byte units (W = 3, 5, 7 or twice that: 96 ... 448 bits) -- the single launch's
+    uint32_t ragged_words;  // 1: rows are NOT whole 16-byte units (W = 3, 5, 7, 9, 11 or twice that: 96 ... 704 bits) -- the single launch's
                             // word-granular variant (scan_rows_wragged), ragged_loads = the odd part of W; the four-kernel pipeline
                             // keeps the LDS-staged generic scan for them
 };
@@ -131,7 +131,7 @@ uint32_t fused_final_keys(uint32_t nwg, uint32_t k);
 
 // Geometry of the scan grid for a table (host side, no device work).
 ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll);
-// ... of the single launch where it differs from the four-kernel pipeline's: rows of 3, 5, 7 or twice that many WORDS
+// ... of the single launch where it differs from the four-kernel pipeline's: rows of 3, 5, 7, 9, 11 or twice that many WORDS
 // (false: it does not -- use scan_geometry's)
 bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out);
 

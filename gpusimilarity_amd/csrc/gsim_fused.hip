@@ -80,7 +80,7 @@ struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
         struct { // while streaming
             u64 key[kScanBlock / 64][kFusedWaveCap];
             uint32_t cb[kScanBlock / 64][kFusedWaveCap];
-            uint32_t words[kScanBlock / 64][256 * 10]; // scan_rows_wragged's per-word counts (rows of 3, 5, 7 or twice that many words)
+            uint32_t words[kScanBlock / 64][256 * 12]; // scan_rows_wragged's per-word counts (the streaming part of the union: 144 KB, as the selectors')
         } store;
         struct { // selectors
             u64 fkey[kFusedFinalLds];
@@ -559,7 +559,7 @@ __device__ __forceinline__ void fused_poller(FusedShared& sh, QueryState* st, co
 
 // LPR > 0: rows of LPR sixteen-byte units (a power of two), U loads per chunk.  LPR < 0: the register-streamed odd widths
 // (scan_rows_ragged<-LPR, U>: rows of 3, 5 or 7 x 2^i units, -LPR loads per sub-chunk, U sub-chunks per trip); WORDS: rows of
-// -LPR = 3, 5, 7, 6, 10 or 14 words (scan_rows_wragged<-LPR, U>; its LDS area is FusedShared::store.words).
+// -LPR = 3, 5, 7, 9, 11 or twice that many words (scan_rows_wragged<-LPR, U>; its LDS area is FusedShared::store.words).
 template <int LPR, int U, bool WORDS = false>
 __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeometry g, FusedArgs fa)
 {
@@ -1356,7 +1356,7 @@ hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedA
     return hipGetLastError();
 }
 
-// Rows of 3, 5, 7 or twice that many 32-bit words: the single launch streams them through registers at word granularity
+// Rows of 3, 5, 7, 9, 11 or twice that many 32-bit words: the single launch streams them through registers at word granularity
 // (scan_rows_wragged); the four-kernel pipeline keeps its LDS-staged scan and its own geometry for them.
 bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out)
 {
@@ -1364,7 +1364,7 @@ bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* 
     if (!enabled || W % 4 == 0 || W == 0) return false;
     uint32_t odd = W;
     while (odd % 2 == 0) odd /= 2;
-    if ((odd != 3 && odd != 5 && odd != 7) || W / odd > 2) return false;
+    if ((odd != 3 && odd != 5 && odd != 7 && odd != 9 && odd != 11) || W / odd > 2) return false; // (13, 15: no LDS left for their words)
     ScanGeometry g{};
     g.ragged_loads = odd;
     g.ragged_words = 1;
@@ -1435,6 +1435,10 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
         if (a.W == 6) return launch_fused_t<-6, 3, true>(a, g, f, s);
         if (a.W == 10) return launch_fused_t<-10, 2, true>(a, g, f, s);
         if (a.W == 14) return launch_fused_t<-14, 1, true>(a, g, f, s);
+        if (a.W == 9) return launch_fused_t<-9, 1, true>(a, g, f, s);
+        if (a.W == 18) return launch_fused_t<-18, 1, true>(a, g, f, s);
+        if (a.W == 11) return launch_fused_t<-11, 1, true>(a, g, f, s);
+        if (a.W == 22) return launch_fused_t<-22, 1, true>(a, g, f, s);
         return hipErrorInvalidValue;
     }
     if (g.ragged_loads == 3) return launch_fused_t<-3, 3>(a, g, f, s);

@@ -613,6 +613,8 @@ __global__ __launch_bounds__(kSampleRowsBlock) void sample_rows_kernel(ScanArgs 
             case 7: words(std::integral_constant<uint32_t, 7>{}); break;
             case 10: words(std::integral_constant<uint32_t, 10>{}); break;
             case 14: words(std::integral_constant<uint32_t, 14>{}); break;
+            case 9: words(std::integral_constant<uint32_t, 9>{}); break;
+            case 11: words(std::integral_constant<uint32_t, 11>{}); break;
             default: words(std::integral_constant<uint32_t, 0>{}); break;
             }
         }

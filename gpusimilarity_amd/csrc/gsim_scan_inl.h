@@ -225,7 +225,7 @@ __device__ __forceinline__ void scan_rows_ragged(const ScanArgs& a, const ScanGe
     }
 }
 
-// ... and for rows that are not even whole 16-byte units: WW = 3, 5, 7 or twice that many 32-bit words (96-, 160-, 224-, 192-,
+// ... and for rows that are not even whole 16-byte units: WW = 3, 5, 7, 9, 11 or twice that many 32-bit words (96-, 160-, 224-, 288-, 352-, 192-,
 // 320-, 448-bit rows).  NL = PP x C consecutive wave loads (PP = the odd part of WW; NL KB = 256 NL words) hold 256 NL / WW
 // whole rows, several per lane.  Every lane counts its four words against the query words of their positions (4 NL query
 // words per lane, loaded once) and leaves the packed counts (common << 16 | row bits) in the wave's LDS area `wlds` in word

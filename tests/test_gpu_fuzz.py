@@ -54,10 +54,10 @@ def test_random_tables_and_queries_match_the_oracle(seed):
     t.close()
 
 
-ODD_WIDTHS = [3, 5, 6, 7, 10, 14, 12, 20, 24, 28, 36, 44, 52, 60, 72, 9, 11, 17, 33]
+ODD_WIDTHS = [3, 5, 6, 7, 10, 14, 12, 20, 24, 28, 36, 44, 52, 60, 72, 9, 11, 18, 22, 13, 17, 33]
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(22))
 def test_random_odd_width_tables_match_the_oracle(seed):
     """The same walk over the widths off the power-of-two template: rows of 3 ... 14 words (word-granular streaming inside the
     single launch), of 3 ... 15 (x 2^i) sixteen-byte units (register-streamed), and a few that keep the LDS-staged scan; sizes

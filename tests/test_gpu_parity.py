@@ -256,9 +256,10 @@ def test_register_streamed_odd_widths_match_oracle(n, W):
 
 
 @pytest.mark.parametrize("n,W", [(400_003, 5), (2_000_001, 5), (300_001, 6), (1_700_000, 6), (200_000, 3), (2_100_007, 3), (150_001, 7),
-                                 (120_000, 10), (90_003, 14), (1_600_001, 14), (255, 5), (256, 5), (257, 5), (1, 3), (100, 7), (513, 6)])
+                                 (120_000, 10), (90_003, 14), (1_600_001, 14), (255, 5), (256, 5), (257, 5), (1, 3), (100, 7), (513, 6),
+                                 (200_001, 9), (1_700_003, 9), (150_000, 11), (100_001, 18), (1_600_000, 22), (129, 22), (257, 9)])
 def test_word_streamed_narrow_odd_widths_match_oracle(n, W):
-    """Rows of 3, 5, 7 or twice that many 32-bit words (96-, 160-, 224-, 192-, 320-, 448-bit: not whole 16-byte units) stream
+    """Rows of 3, 5, 7, 9, 11 or twice that many 32-bit words (96- ... 704-bit: not whole 16-byte units) stream
     through registers at word granularity inside the single launch (scan_rows_wragged: a prefix sum over the words of a
     chunk through a per-wave LDS area); k = 9000 goes to the four-kernel pipeline and its LDS-staged scan.  Tables above
     1500 rows per wave are seeded by the sample first.  Whole chunks, partial last trips whose last 16-byte unit is cut by
