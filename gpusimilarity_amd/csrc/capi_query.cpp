@@ -211,7 +211,14 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_lk), sizeof(gsim::LargeKState)));
             GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
         }
-        GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, s.stream));
+        // (the route by the finalist count of the previous large-k query, left in pinned memory by its kernels: one workgroup in
+        // one launch while the finalists fit its LDS, 16 Ki keys -- select + gather 67 us instead of 87 at k = 10 000 --, the
+        // grid's eight passes beyond: at 52 k finalists the single workgroup reading global memory took 195 us against 122.  A
+        // wrong guess is slower, never wrong)
+        static const int one_block_max = env_int("GSIM_LARGEK_ONE_BLOCK_MAX", 16384);
+        uint32_t* hint = s.h_done + 15;
+        const bool one_block = *static_cast<volatile uint32_t*>(hint) <= static_cast<uint32_t>(one_block_max);
+        GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, hint, one_block, s.stream));
         // (tiles sorted, then positions by counting + the hits + the header + the state's reset in one launch)
         GSIM_HIP(gsim::launch_largek_sort_emit(a, s.d_large, np2, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
     }

@@ -157,7 +157,7 @@ struct LargeKState {
     uint32_t hist[256];
 };
 hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
-                                unsigned long long* out, uint32_t out_cap, hipStream_t s);
+                                unsigned long long* out, uint32_t out_cap, uint32_t* hint, bool one_block, hipStream_t s);
 
 // Large-k path (k > kSelectCap): the gathered top-k keys sorted in two launches (tiles in LDS, positions by counting).
 // (n_pow2 keys, unique apart from zero padding; `tmp` holds n_pow2 more; *sorted = where the result is: keys or tmp)

@@ -319,11 +319,12 @@ __global__ __launch_bounds__(256) void largek_pass_kernel(ScanArgs a, const u64*
 
 // the keys at or above the k-th largest (exactly min(k, #finalists) of them: keys are unique) -> out[0 ..)
 __global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, u64* out,
-                                                            uint32_t out_cap)
+                                                            uint32_t out_cap, uint32_t* hint)
 {
     const int lane = threadIdx.x & 63;
     uint32_t nfinal = a.state->nfinal;
     if (nfinal > cap) nfinal = cap;
+    if (hint && blockIdx.x == 0 && threadIdx.x == 0) *hint = nfinal; // (pinned: the host picks the next large-k query's route by it)
     const u64 kth = lk->all ? 0ull : lk->prefix;
     const uint32_t n64 = (nfinal + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n64; i += gridDim.x * 256) {
@@ -336,6 +337,88 @@ __global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u6
         base = __builtin_amdgcn_readfirstlane(base);
         const uint32_t pos = base + lane_rank(m);
         if (take && pos < out_cap) out[pos] = key;
+    }
+}
+
+// The same selection and gather in ONE launch by one workgroup: the usual large-k query has little more than k finalists
+// (10.7 k at k = 10 000), nine launches for them are nine times ~5 us of dependent global round trips -- here the keys sit in LDS
+// (up to 16 Ki; more: read from global memory in every pass, still exact, but slower than the grid of passes -- 195 us against
+// 122 at 52 k keys --, which is why the host chooses the route by the finalist count of the previous large-k query, `hint`, in
+// pinned memory).
+constexpr uint32_t kLargeKLdsKeys = 16384;
+constexpr int kLargeKOneThreads = 1024;
+
+__global__ __launch_bounds__(kLargeKOneThreads) void largek_one_block_kernel(ScanArgs a, const u64* finalists, uint32_t cap, LargeKState* lk, u64* out,
+                                                                          uint32_t out_cap, uint32_t* hint)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 skeys[];
+    __shared__ uint32_t s_hist[256];
+    __shared__ u64 s_prefix;
+    __shared__ uint32_t s_want, s_all, s_cursor;
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t nfinal = a.state->nfinal;
+    if (nfinal > cap) nfinal = cap;
+    const bool in_lds = nfinal <= kLargeKLdsKeys;
+    if (in_lds)
+        for (uint32_t i = tid; i < nfinal; i += kLargeKOneThreads) skeys[i] = finalists[i];
+    if (tid == 0) {
+        s_prefix = 0;
+        s_want = a.k;
+        s_all = 0;
+        s_cursor = 0;
+        if (hint) *hint = nfinal;
+    }
+    for (int pass = 0; pass < 8; pass++) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const int shift = 56 - 8 * pass;
+        const u64 prefix = s_prefix;
+        const uint32_t want = s_want;
+        for (uint32_t i = tid; i < nfinal; i += kLargeKOneThreads) {
+            const u64 key = in_lds ? skeys[i] : finalists[i];
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t h[4];
+            uint32_t s4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                h[i] = s_hist[tid * 4 + i];
+                s4 += h[i];
+            }
+            uint32_t bin, cnt;
+            threshold_from_counts<4>(h, s4, want, tid, bin, cnt);
+            if (tid == 0) {
+                if (cnt < want) { // (pass 0 only: fewer finalists than k)
+                    s_all = 1;
+                } else {
+                    s_prefix = (prefix << 8) | bin;
+                    s_want = want - (cnt - s_hist[bin]);
+                }
+            }
+        }
+        __syncthreads();
+        if (s_all) break;
+    }
+    const u64 kth = s_all ? 0ull : s_prefix;
+    const uint32_t n64 = (nfinal + 63u) & ~63u;
+    for (uint32_t i = tid; i < n64; i += kLargeKOneThreads) {
+        const u64 key = i < nfinal ? (in_lds ? skeys[i] : finalists[i]) : 0ull;
+        const bool take = i < nfinal && key >= kth;
+        const u64 m = __ballot(take);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_cursor, static_cast<uint32_t>(__popcll(m)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t pos = base + lane_rank(m);
+        if (take && pos < out_cap) out[pos] = key;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        lk->count = s_cursor;
+        lk->all = s_all;
+        lk->prefix = kth;
     }
 }
 
@@ -650,14 +733,24 @@ hipError_t launch_fold_rescore(const void* folded_block, const uint32_t* full_ro
     return hipGetLastError();
 }
 
-// k > kSelectCap: the k-th largest finalist key by eight radix passes, then the keys at or above it into out[0 .. count)
-// (out_cap >= k entries; launch_largek_sort_emit sorts them and emits the hits).  Nothing here is sized by the finalist count.
+// k > kSelectCap: the k-th largest finalist key by a radix descent, then the keys at or above it into out[0 .. count)
+// (out_cap >= k entries; launch_largek_sort_emit sorts them and emits the hits).  Nothing here is sized by the finalist count:
+// one workgroup in one launch (`one_block`; the usual case) or eight passes of the whole grid + a gather (many finalists:
+// heavy ties at the k-th score) -- both exact for any count; `hint` (pinned, may be null) receives the count.
 hipError_t launch_largek_select(const ScanArgs& a, const unsigned long long* finalists, uint32_t finalists_cap, LargeKState* lk,
-                                unsigned long long* out, uint32_t out_cap, hipStream_t s)
+                                unsigned long long* out, uint32_t out_cap, uint32_t* hint, bool one_block, hipStream_t s)
 {
+    if (one_block) {
+        const size_t lds = static_cast<size_t>(kLargeKLdsKeys) * sizeof(u64);
+        static DynLdsOnce once;
+        const hipError_t e = once.ensure(reinterpret_cast<const void*>(largek_one_block_kernel), lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(largek_one_block_kernel, dim3(1), dim3(kLargeKOneThreads), lds, s, a, finalists, finalists_cap, lk, out, out_cap, hint);
+        return hipGetLastError();
+    }
     for (int pass = 0; pass < kLargeKPasses; pass++)
         hipLaunchKernelGGL(largek_pass_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, pass);
-    hipLaunchKernelGGL(largek_gather_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, out, out_cap);
+    hipLaunchKernelGGL(largek_gather_kernel, dim3(256), dim3(256), 0, s, a, finalists, finalists_cap, lk, out, out_cap, hint);
     return hipGetLastError();
 }
 
