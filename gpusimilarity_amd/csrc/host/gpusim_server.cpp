@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <sstream>
 #include <stdexcept>
+#include <string_view>
 
 #include "fsim_reader.h"
 #include "qds.h"
@@ -276,33 +277,45 @@ void GPUSimServer::searchDatabases(const Fingerprint& query, int results_request
 
     // Hits with equal SMILES fold into one result whose id is the ids joined by ";:;" (:342-357); the
     // merge stops with the entry that completes the results_requested-th distinct SMILES (:355).
+    // (no allocation per hit: the map's keys are views of the databases' own SMILES strings, an id is the database's own
+    // string until a second hit with the same SMILES makes it a joined copy -- at k = 1000 the four std::string
+    // constructions per hit were a third of a millisecond of the server-side latency)
     struct Result {
         float score;
         char* smiles;
-        std::string ids;
+        char* id;           // the first hit's id (the database's string)
+        std::string joined; // ... or, once a second hit has the same SMILES, the ids joined by ";:;"
     };
     std::vector<Result> results;
-    std::unordered_map<std::string, size_t> by_smiles;
+    results.reserve(static_cast<size_t>(results_requested));
+    std::unordered_map<std::string_view, size_t> by_smiles;
+    by_smiles.reserve(static_cast<size_t>(results_requested) * 2);
     while (!heap.empty()) {
         std::pop_heap(heap.begin(), heap.end(), later);
         List& l = lists[heap.back()];
         const size_t p = l.pos++;
-        auto found = by_smiles.find(l.smiles[p]);
+        const std::string_view key(l.smiles[p]);
+        auto found = by_smiles.find(key);
         if (found != by_smiles.end()) {
-            results[found->second].ids += ";:;";
-            results[found->second].ids += l.ids[p];
+            Result& r = results[found->second];
+            if (r.joined.empty()) r.joined = r.id;
+            r.joined += ";:;";
+            r.joined += l.ids[p];
         } else {
-            by_smiles.emplace(l.smiles[p], results.size());
-            results.push_back({l.scores[p], l.smiles[p], l.ids[p]});
+            by_smiles.emplace(key, results.size());
+            results.push_back({l.scores[p], l.smiles[p], l.ids[p], std::string()});
         }
         if (results.size() >= static_cast<size_t>(results_requested)) break;
         if (l.pos < l.scores.size()) std::push_heap(heap.begin(), heap.end(), later);
         else heap.pop_back();
     }
+    results_scores.reserve(results.size());
+    results_smiles.reserve(results.size());
+    results_ids.reserve(results.size());
     for (const auto& r : results) {
         results_scores.push_back(r.score);
         results_smiles.push_back(r.smiles);
-        results_ids.push_back(strdup(r.ids.c_str())); // the receiver frees them (:369-370)
+        results_ids.push_back(strdup(r.joined.empty() ? r.id : r.joined.c_str())); // the receiver frees them (:369-370)
     }
 }
 
