@@ -212,10 +212,10 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
         }
         // (the route by the finalist count of the previous large-k query, left in pinned memory by its kernels: one workgroup in
-        // one launch while the finalists fit its LDS, 16 Ki keys -- select + gather 67 us instead of 87 at k = 10 000 --, the
-        // grid's eight passes beyond: at 52 k finalists the single workgroup reading global memory took 195 us against 122.  A
-        // wrong guess is slower, never wrong)
-        static const int one_block_max = env_int("GSIM_LARGEK_ONE_BLOCK_MAX", 16384);
+        // one launch -- two reads of the finalists, the radix passes in LDS over the keys of the boundary bin: select + gather
+        // 56 us instead of 87 at k = 10 000 -- up to 32 Ki finalists, the grid's eight passes + gather beyond (52 k finalists, a
+        // boundary bin of more than 16 Ki keys: 121 us either way).  A wrong guess is slower, never wrong)
+        static const int one_block_max = env_int("GSIM_LARGEK_ONE_BLOCK_MAX", 32768);
         uint32_t* hint = s.h_done + 15;
         const bool one_block = *static_cast<volatile uint32_t*>(hint) <= static_cast<uint32_t>(one_block_max);
         GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, hint, one_block, s.stream));

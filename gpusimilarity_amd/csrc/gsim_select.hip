@@ -340,11 +340,15 @@ __global__ __launch_bounds__(256) void largek_gather_kernel(ScanArgs a, const u6
     }
 }
 
-// The same selection and gather in ONE launch by one workgroup: the usual large-k query has little more than k finalists
-// (10.7 k at k = 10 000), nine launches for them are nine times ~5 us of dependent global round trips -- here the keys sit in LDS
-// (up to 16 Ki; more: read from global memory in every pass, still exact, but slower than the grid of passes -- 195 us against
-// 122 at 52 k keys --, which is why the host chooses the route by the finalist count of the previous large-k query, `hint`, in
-// pinned memory).
+// The same selection and gather in ONE launch by one workgroup: nine launches are nine times ~5 us of dependent global round
+// trips.  The finalists are the candidates of the bins >= B*, the table's k-th best coarse bin (compact_kernel); the histogram
+// that gave B* is still there: every finalist above B* is in the top k, only the r = k - (rows above B*) best keys OF bin B*
+// have to be found.  One pass over the finalists collects the keys of bin B* into LDS (up to 16 Ki of them), eight radix passes
+// over those (LDS only) find the r-th largest, a second pass over the finalists gathers.  More than 16 Ki keys in bin B* (heavy
+// ties): the radix passes read the finalists from global memory, bin B* only -- exact, slow.  Two reads of the finalists by
+// one workgroup beat the grid's nine launches up to a few ten thousand finalists (10.7 k: 56 us against 87; 52 k with 20 k of
+// them in bin B*: 121 us either way): the host picks the route by the count of the previous large-k query (`hint`, pinned
+// memory); either route is exact for any count.
 constexpr uint32_t kLargeKLdsKeys = 16384;
 constexpr int kLargeKOneThreads = 1024;
 
@@ -354,57 +358,76 @@ __global__ __launch_bounds__(kLargeKOneThreads) void largek_one_block_kernel(Sca
     extern __shared__ __attribute__((aligned(16))) u64 skeys[];
     __shared__ uint32_t s_hist[256];
     __shared__ u64 s_prefix;
-    __shared__ uint32_t s_want, s_all, s_cursor;
+    __shared__ uint32_t s_want, s_all, s_cursor, s_nb, s_bstar;
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t nfinal = a.state->nfinal;
     if (nfinal > cap) nfinal = cap;
-    const bool in_lds = nfinal <= kLargeKLdsKeys;
-    if (in_lds)
-        for (uint32_t i = tid; i < nfinal; i += kLargeKOneThreads) skeys[i] = finalists[i];
-    if (tid == 0) {
-        s_prefix = 0;
-        s_want = a.k;
-        s_all = 0;
-        s_cursor = 0;
-        if (hint) *hint = nfinal;
+    if (tid < 64) { // B*, and how many of bin B*'s keys the top k takes
+        uint32_t bstar, cnt;
+        find_threshold(a.state->ghist, a.k, lane, bstar, cnt);
+        if (tid == 0) {
+            s_all = cnt < a.k ? 1u : 0u; // fewer finalists than k: every finalist is taken
+            s_bstar = bstar;
+            s_want = cnt < a.k ? 0u : a.k - (cnt - a.state->ghist[bstar]);
+            s_prefix = 0;
+            s_cursor = 0;
+            s_nb = 0;
+            if (hint) *hint = nfinal;
+        }
     }
-    for (int pass = 0; pass < 8; pass++) {
-        if (tid < 256) s_hist[tid] = 0;
-        __syncthreads();
-        const int shift = 56 - 8 * pass;
-        const u64 prefix = s_prefix;
-        const uint32_t want = s_want;
-        for (uint32_t i = tid; i < nfinal; i += kLargeKOneThreads) {
-            const u64 key = in_lds ? skeys[i] : finalists[i];
-            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xFFu], 1u);
+    __syncthreads();
+    const uint32_t bstar = s_bstar;
+    const bool all = s_all != 0;
+    auto in_bstar = [&](u64 key) { return coarse_bin(key_score(static_cast<uint32_t>(key >> 32))) == bstar; };
+    const uint32_t n64 = (nfinal + 63u) & ~63u;
+    if (!all) {
+        for (uint32_t i = tid; i < n64; i += kLargeKOneThreads) { // bin B*'s keys -> LDS
+            const u64 key = i < nfinal ? finalists[i] : 0ull;
+            const bool take = i < nfinal && in_bstar(key);
+            const u64 m = __ballot(take);
+            if (m == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_nb, static_cast<uint32_t>(__popcll(m)));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t pos = base + lane_rank(m);
+            if (take && pos < kLargeKLdsKeys) skeys[pos] = key;
         }
         __syncthreads();
-        if (tid < 64) {
-            uint32_t h[4];
-            uint32_t s4 = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                h[i] = s_hist[tid * 4 + i];
-                s4 += h[i];
+        const uint32_t nb = s_nb;
+        const bool in_lds = nb <= kLargeKLdsKeys;
+        const uint32_t nscan = in_lds ? nb : nfinal;
+        for (int pass = 0; pass < 8; pass++) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            const int shift = 56 - 8 * pass;
+            const u64 prefix = s_prefix;
+            const uint32_t want = s_want;
+            for (uint32_t i = tid; i < nscan; i += kLargeKOneThreads) {
+                const u64 key = in_lds ? skeys[i] : finalists[i];
+                if ((in_lds || in_bstar(key)) && (pass == 0 || (key >> (shift + 8)) == prefix)) atomicAdd(&s_hist[(key >> shift) & 0xFFu], 1u);
             }
-            uint32_t bin, cnt;
-            threshold_from_counts<4>(h, s4, want, tid, bin, cnt);
-            if (tid == 0) {
-                if (cnt < want) { // (pass 0 only: fewer finalists than k)
-                    s_all = 1;
-                } else {
+            __syncthreads();
+            if (tid < 64) {
+                uint32_t h[4];
+                uint32_t s4 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    h[i] = s_hist[tid * 4 + i];
+                    s4 += h[i];
+                }
+                uint32_t bin, cnt;
+                threshold_from_counts<4>(h, s4, want, tid, bin, cnt); // (want <= the keys that match: bin B* holds at least r keys)
+                if (tid == 0) {
                     s_prefix = (prefix << 8) | bin;
                     s_want = want - (cnt - s_hist[bin]);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (s_all) break;
     }
-    const u64 kth = s_all ? 0ull : s_prefix;
-    const uint32_t n64 = (nfinal + 63u) & ~63u;
+    const u64 kth = all ? 0ull : s_prefix;
     for (uint32_t i = tid; i < n64; i += kLargeKOneThreads) {
-        const u64 key = i < nfinal ? (in_lds ? skeys[i] : finalists[i]) : 0ull;
+        const u64 key = i < nfinal ? finalists[i] : 0ull;
         const bool take = i < nfinal && key >= kth;
         const u64 m = __ballot(take);
         if (m == 0) continue;
