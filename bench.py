@@ -667,16 +667,17 @@ def main():
         except Exception as e:  # never lose the headline over it
             cfgs.append({"name": "BASELINE configs[4] per-GPU shape", "error": repr(e)})
         # other row widths (the reference's --gpu_bitcount folds 1024-bit rows to 512 / 256 / 128 bits; MACCS-sized keys
-        # are 166 -> 192 bits): whole-query fraction of the HBM peak per width, 50 M rows (2048-bit: 30 M), top-1000
+        # are 166 -> 192 bits): whole-query fraction of the HBM peak per width at EQUAL TABLE BYTES (6.4 GB each, top-1000) -- at
+        # equal rows a table of narrow rows is simply smaller and shows the query's fixed ~25 us instead of the width's rate
         widths = []
-        for bits, rows in ((128, 50_000_000), (256, 50_000_000), (512, 50_000_000), (2048, 30_000_000), (160, 50_000_000), (192, 50_000_000),
-                           (896, 50_000_000), (1152, 30_000_000)):
+        for bits in (128, 256, 512, 2048, 160, 192, 896, 1152):
+            rows = int(6_400_000_000 // (bits // 8))
             try:
                 tw = capi.Table(bits)
                 tw.generate(DB_SEED, kind, 0, rows, device_index)
                 rw, _ = time_queries(ctx, tw, rows, rows, bits, kind, 1000, 4, 1, 32, False)
                 tw.close()
-                widths.append({"fp_bits": bits, "rows": rows, "ms_per_query": rw["ms_per_query"], "whole_path_hbm_frac": rw["whole_path_hbm_frac"],
+                widths.append({"fp_bits": bits, "rows": rows, "table_bytes": rows * (bits // 8), "ms_per_query": rw["ms_per_query"], "whole_path_hbm_frac": rw["whole_path_hbm_frac"],
                                "kernel": rw["roofline"]["kernel"], "kernel_ms_avg": rw["roofline"]["kernel_ms_avg"], "kernel_hbm_frac": rw["roofline"]["frac"],
                                "queries_handed_back": rw["roofline"]["queries_handed_back"],
                                "sync_ms_median": rw["sync_latency"]["sync_ms_median"] if rw["sync_latency"] else None})
