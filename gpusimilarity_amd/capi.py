@@ -54,7 +54,7 @@ EXPORTS = [
     "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm",
     "gsim_db_enable_timing",
-    "gsim_db_get_timing", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_last_error", "gsim_version",
+    "gsim_db_get_timing", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
 ]
 
 
@@ -121,6 +121,7 @@ def load():
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                              C.c_uint32, C.POINTER(C.c_float)]),
+        "gsim_debug_sort_desc": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32]),
         "gsim_debug_prefilter_constants": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_int, C.c_float,
                                                       C.POINTER(C.c_float)]),
         "gsim_last_error": (C.c_char_p, []),
@@ -393,6 +394,13 @@ def debug_score_table(metric, alpha, beta, a, max_b, max_c, device=0) -> np.ndar
     out = np.empty((max_c + 1, max_b + 1), dtype=np.float32)
     check(load().gsim_debug_score_table(device, metric, alpha, beta, a, max_b, max_c,
                                         out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def debug_sort_desc(keys: np.ndarray, device=0) -> np.ndarray:
+    """The device sort of the large-k and folded paths (launch_sort_desc) on a uint64 array of 2^i keys, descending."""
+    out = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    check(load().gsim_debug_sort_desc(device, out.ctypes.data_as(C.c_void_p), len(out)))
     return out
 
 

@@ -197,6 +197,26 @@ int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint
     return GSIM_OK;
 }
 
+int gsim_debug_sort_desc(int device, unsigned long long* keys, uint32_t n)
+{
+    if (!keys) return fail(GSIM_ERR_INVALID, "keys is NULL");
+    if (n == 0 || (n & (n - 1)) != 0) return fail(GSIM_ERR_INVALID, "n must be a power of two");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (device < 0 || device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    GSIM_HIP(set_device(device));
+    unsigned long long* d = nullptr;
+    GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&d), static_cast<size_t>(n) * 16));
+    hipError_t e = hipMemcpy(d, keys, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice);
+    unsigned long long* sorted = d;
+    if (e == hipSuccess) e = gsim::launch_sort_desc(d, d + n, n, nullptr, &sorted);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(keys, sorted, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "sort");
+    return GSIM_OK;
+}
+
 int gsim_debug_prefilter_constants(int device, int metric, float alpha, float beta, uint32_t max_qa, int has_cutoff,
                                    float cutoff, float* out)
 {

@@ -300,6 +300,11 @@ int gsim_debug_score_table(int device, int metric, float alpha, float beta, uint
 int gsim_debug_prefilter_constants(int device, int metric, float alpha, float beta, uint32_t max_qa,
                                    int has_cutoff, float cutoff, float* out);
 
+/* The device sort behind k > 8192 and the folded tables' re-score (launch_sort_desc: tiles sorted in LDS, positions by
+ * counting): keys[0 .. n), n a power of two, sorted in place, descending; equal keys (the callers pad with zeros) keep a
+ * deterministic order.  For the parity tests. */
+int gsim_debug_sort_desc(int device, unsigned long long* keys, uint32_t n);
+
 const char* gsim_last_error(void);
 const char* gsim_version(void);
 

@@ -535,6 +535,30 @@ def test_large_tables_of_other_widths_whole_table_against_oracle(nrows, W):
     del host
 
 
+@pytest.mark.parametrize("lg", [1, 2, 5, 10, 11, 12, 13, 15, 16, 18])
+def test_device_sort_of_the_large_k_and_folded_paths(lg):
+    """launch_sort_desc (tiles of 2048 keys sorted in LDS, then every key's position by counting over the other tiles): random
+    unique 64-bit keys, zero padding of any length (equal keys: a permutation all the same), keys that differ in the low or
+    the high word only, already sorted and reversed inputs -- against numpy's sort."""
+    n = 1 << lg
+    rng = np.random.default_rng(0x50B7 + lg)
+    cases = []
+    a = rng.integers(1, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    cases.append(a)
+    b = a.copy()
+    b[rng.integers(0, n, size=max(1, n // 3))] = 0  # padding anywhere, any amount
+    cases.append(b)
+    cases.append(np.zeros(n, dtype=np.uint64))
+    cases.append((np.uint64(0x3F800000) << np.uint64(32)) | np.arange(n, dtype=np.uint64))  # one score, rows 0 .. n - 1
+    cases.append(np.sort(a))
+    cases.append(np.sort(a)[::-1].copy())
+    cases.append(np.arange(n, dtype=np.uint64) << np.uint64(32))
+    for i, keys in enumerate(cases):
+        got = capi.debug_sort_desc(keys)
+        want = np.sort(keys)[::-1]
+        assert (got == want).all(), "n = 2^%d, case %d" % (lg, i)
+
+
 def test_folded_search_host_rescore_route_and_nan_scores():
     """The re-score of a folded table's candidates runs on the device when the full fingerprints are in HBM as well;
     the host route (the reference's, fingerprintdb_cuda.cu:307-331) stays: forced here through GSIM_FOLD_RESCORE=host in a
