@@ -9,7 +9,7 @@ echo "== other widths, 100 M rows (2048-bit: 60 M) =="
 for b in 128 256 512; do TS_BITS=$b TS_REPS=50 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/bits $b  /"; done
 TS_BITS=2048 TS_REPS=50 python scripts/time_single.py 60000000 2>&1 | grep rows | sed "s/^/bits 2048  /"
 TS_BITS=4096 TS_REPS=50 python scripts/time_single.py 30000000 2>&1 | grep rows | sed "s/^/bits 4096  /"
-echo "== generic widths (scan_generic_kernel, four-kernel pipeline) =="
+echo "== widths off the power-of-two template (word-streamed 160 / 192-bit, register-streamed 896 / 1536-bit: inside the single launch) =="
 for b in 160 192 896 1536; do TS_BITS=$b TS_REPS=30 python scripts/time_single.py 50000000 2>&1 | grep rows | sed "s/^/bits $b  /"; done
 echo "== four-kernel pipeline for comparison (GSIM_FUSED=0), 1024-bit =="
 GSIM_FUSED=0 TS_REPS=50 python scripts/time_single.py 1000000 10000000 100000000 2>&1 | grep rows
