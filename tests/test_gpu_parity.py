@@ -329,6 +329,41 @@ def test_large_k_path():
     check_against_oracle(t, db, q, 50_000, 0.04, ctx="large k cutoff")
 
 
+def test_large_k_with_ties_in_the_boundary_bin():
+    """k > 8192 where the k-th score is shared by tens of thousands of rows: the one-workgroup route's boundary bin holds more
+    keys than its LDS (its radix passes read global memory), the grid route histograms them; then ordinary tables right
+    after, so that the route guessed from the previous query's finalist count is wrong in both directions."""
+    base = O.synth_rows(0x71E7, 0, 0, 8, 32)
+    n = 300_000
+    tied = np.ascontiguousarray(base[np.random.default_rng(5).integers(0, 8, size=n)])  # ~37 k copies of each fingerprint
+    t = make_table(tied)
+    for k in (9_000, 20_000, 60_000, 100_000):
+        check_against_oracle(t, tied, base[3], k, 0.0, ctx="tied large k=%d" % k)
+    t.close()
+    db = O.synth_rows(0xB17, 0, 0, 200_000, 32)
+    t = make_table(db)
+    t2 = make_table(tied)
+    for i, k in enumerate((9_000, 50_000, 8_500, 150_000, 9_500)):  # few finalists, many, few, many ... (each table has its own hint)
+        check_against_oracle(t, db, db[100 + i], k, 0.0, ctx="alternating k=%d" % k)
+        check_against_oracle(t2, tied, base[i % 8], 10_000 + 7_000 * i, 0.0, ctx="alternating tied %d" % i)
+    t.close()
+    t2.close()
+
+
+def test_large_k_routes_forced():
+    """GSIM_LARGEK_ONE_BLOCK_MAX (read once per process: child processes) forces the one-workgroup route for every finalist
+    count and the grid route for every count: the large-k, tie and folded tests pass either way."""
+    import subprocess
+    import sys
+    for val in ("0", "2000000000"):
+        env = dict(os.environ, GSIM_LARGEK_ONE_BLOCK_MAX=val)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
+                            "test_large_k_path or test_large_k_with_ties_in_the_boundary_bin or test_folded_search_matches or test_folded"],
+                           env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, val + ": " + r.stdout[-2000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
 def test_tversky_matches_oracle():
     for W, kind in ((64, 0), (32, 1)):
         db = O.synth_rows(0x7E25, kind, 0, 80_000, W)
