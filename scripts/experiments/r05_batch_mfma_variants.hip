@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
@@ -68,6 +69,17 @@ constexpr int kMStage = 96;            // raw candidates staged per wave (proces
 #ifndef GSIM_MF_TIMING
 #define GSIM_MF_TIMING 0
 #endif
+// GSIM_MF_WHATIF: timing-only builds (WRONG results) -- bit 0: the contraction reads no row fragments from LDS (zeros the
+// compiler cannot see through), bit 1: no epilogue, bit 2: no plane expansion, bit 3: no threshold upkeep, bit 4: no MFMAs
+// (their operands are still produced)
+#ifndef GSIM_MF_WHATIF
+#define GSIM_MF_WHATIF 0
+#endif
+#if GSIM_MF_WHATIF & 1
+#define GSIM_LDSROW(x) opaque_zero()
+#else
+#define GSIM_LDSROW(x) (x)
+#endif
 #if GSIM_MF_TIMING
 #define MF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define MF_ACC(slot, t0, t1) tacc[slot] += (t1) - (t0)
@@ -86,15 +98,25 @@ struct MfmaShared {
     uint32_t qpop[kMWaves][32 * kMaxMT];
 };
 
-// LDS of the contraction kernel.  BC = 16-byte chunks per row block; `rows` is a ring of RING blocks: the DMA fills slot
-// (n + RING - 1) % RING while the waves read slot n % RING.
-template <int WORDS, int BC, int RING> struct MfmaRing {
-    static constexpr int CPR = WORDS / 4, RB = BC / CPR, RP = RING;
-    static constexpr int HB = (WORDS <= 16 && BC == kMChunks) ? 1 : 2; // histogram staging buffers (512-bit rows in 64 KB blocks: the LDS is full)
+// LDS of the contraction kernel.  BC = 16-byte chunks per row block.
+//   NPL == 0  `rows` is a ring of RING blocks: the DMA fills slot (n + RING - 1) % RING while the waves read slot n % RING --
+//             RING - 1 blocks in flight, for the batches that are bound by the HBM stream (few query tiles).
+//   NPL > 0   `rows[2]` are the DMA's landing buffers; while block n is consumed, the workgroup expands block n + 1 ONCE into
+//             `cons[(n + 1) & 1]`: a copy of the raw chunks followed by NPL class planes (plane 0: class 3 = (x >> 3) & 0x11111111,
+//             plane 1: class 2 = x & 0x44444444), same chunk positions, so that a wave reads a plane's fragment with the raw
+//             fragment's address + a constant and spends no vector instruction on that class (round 5; the eight waves of a
+//             workgroup stream the same rows against different query tiles and each used to expand every fragment itself:
+//             5 of its 7.6 vector instructions per MFMA).
+template <int WORDS, int BC, int RING, int NPL, bool ROT> struct MfmaRing {
+    static constexpr int CPR = WORDS / 4, RB = BC / CPR;
+    static constexpr int NCONS = NPL ? 2 : 1;
+    static constexpr int RP = NPL ? 3 : RING;
     u32x4 rows[RING][BC];
+    u32x4 cons[NCONS][NPL ? (1 + NPL) * BC : 1];
     uint16_t rpop[RP][RB];            // popc(row) of a block's rows, from the table's side array
     uint32_t tau_poll[kMWaves][64];   // the queries' table-wide thresholds, polled by DMA (no register, no wait)
-    uint32_t hist[HB][kBBins];         // a query's table-wide histogram, fetched by DMA for the threshold refresh
+    uint32_t hist[2][kBBins];         // a query's table-wide histogram, fetched by DMA for the threshold refresh
+    uint32_t simd_waves[4];           // rotated waves: arrivals per SIMD (the second wave of a SIMD takes role B)
     // pre-filter constants in accumulator order: [query tile of the wave][lane half][acc register]
     float kap_a[kMWaves][kMaxMT][2][16];
     float kap_b[kMWaves][kMaxMT][2][16];
@@ -126,8 +148,19 @@ template <int CLS> __device__ __forceinline__ v4i fp4_class(u32x4 x, const Class
                static_cast<int>(fp4_word<CLS>(x.z, k)), static_cast<int>(fp4_word<CLS>(x.w, k))};
 }
 
+[[maybe_unused]] __device__ __forceinline__ u32x4 opaque_zero()
+{
+    u32x4 z = {0, 0, 0, 0};
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
 template <int CLS> __device__ __forceinline__ v16f mfma_class(v4i qa, v4i rb, v16f acc)
 {
+#if GSIM_MF_WHATIF & 16
+    asm volatile("" ::"v"(qa), "v"(rb));
+    return acc;
+#endif
     const v8i A = {qa.x, qa.y, qa.z, qa.w, 0, 0, 0, 0};
     const v8i B = {rb.x, rb.y, rb.z, rb.w, 0, 0, 0, 0};
     constexpr int sc = CLS == 1 ? kScale0 : (CLS == 2 ? kScaleM : kScale1);
@@ -143,6 +176,27 @@ __device__ __forceinline__ float pick16(const v16f& v, int r)
     return t[r];
 }
 
+// The MFMA as inline assembly with the QUERY operand in an accumulation register (four-wave workgroups: a wave has 256
+// AGPRs beside its 256 VGPRs, and hipcc, given the builtin, parks the expanded queries there only to copy them back before
+// every use).  FIRST: the chain starts here (C = 0).  Hazards the compiler cannot see inside the statement: two wait states
+// in front (a VALU result read as B, the previous MFMA of the chain), mfma_asm_settle() before the vector ALU reads a result.
+template <int CLS> __device__ __forceinline__ void mfma_class_agpr(const v4i& qa, v4i rb, v16f& acc, bool first)
+{
+    const int sc = CLS == 1 ? kScale0 : (CLS == 2 ? kScaleM : kScale1);
+    if (first) // (a compile-time fact once the group loop is unrolled)
+        asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                     : "=&v"(acc)
+                     : "a"(qa), "v"(rb), "v"(sc));
+    else
+        asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                     : "+v"(acc)
+                     : "a"(qa), "v"(rb), "v"(sc));
+}
+__device__ __forceinline__ void mfma_asm_settle(v16f& x)
+{
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x)); // (an 8-pass MFMA's result: 11 wait states before a VALU read)
+}
+
 // s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
 template <int N> __device__ __forceinline__ void wait_vm_outstanding()
 {
@@ -154,34 +208,45 @@ template <int N> __device__ __forceinline__ void wait_vm_outstanding()
 
 // MT = query tiles per wave: the expanded row operand of a tile is used by MT MFMAs per class, so
 // the operand work per MFMA is 5 / MT instructions; 2 W MT registers hold the queries.
-// NT = row tiles in flight per wave (accumulators: 16 MT NT registers; two independent MFMA chains
-// per wave are worth having).  BC / RING: the row block and the ring (MfmaRing).
+// NT = row tiles in flight per wave (accumulators: 16 MT NT KS registers; two independent MFMA chains
+// per wave are worth having).  KS = 2 (NT = 1): the two chains are the even and the odd 256-bit groups of ONE row tile,
+// added at the end -- a wave then needs one row tile, not a pair, so that with few query tiles (several waves per tile,
+// splitting the rows of a block) every wave finds work in a small block.
+// BC / RING / NPL: the row block, the ring and the shared class planes (MfmaRing).
 // DN = the dense-cutoff variant (MT = 1): the rows at or above a cutoff that keeps a sizeable part of the table are COUNTED
 // from the accumulators (gsim_prefilter.h cutoff_band: two fused multiply-adds and two compares per pair, sixteen counters
 // per lane) instead of going through the exact path one by one; only pairs inside the band, and the top-k candidates at the
 // queries' current thresholds, are staged.  Its constants share the LDS arrays of the plain variant's two query tiles:
 // kap_u/kap_v[.][0] = tile test at the top-k threshold, kap_u/kap_v[.][1] = "surely kept", kap_a[.][0]/[1] = u, v of "surely not".
-template <int WORDS, int MT, int NT, int BC, int RING, bool DN>
-__global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nblocks)
+template <int WORDS, int MT, int NT, int KS, int BC, int RING, int NPL, bool DN, bool ROT = false, int WV = kMWaves>
+__global__ __launch_bounds__(WV * 64) void batch_mfma_kernel(BatchArgs a, u64 nblocks, int rs_arg)
 {
     static_assert(!DN || MT == 1, "the dense-cutoff variant holds one query tile per wave");
-    static_assert(RING >= 2 && RING <= 4, "ring geometry");
-    using Ring = MfmaRing<WORDS, BC, RING>;
-    constexpr int WV = kMWaves;
-    constexpr int kWBlock = kMBlock;
+    static_assert(KS == 1 || (KS == 2 && NT == 1), "K-interleaved chains are for single row tiles");
+    static_assert(NPL == 0 || RING == 2, "class planes: two landing buffers");
+    static_assert(NPL >= 0 && NPL <= 2 && RING >= 2 && RING <= 4, "ring geometry");
+    static_assert(!ROT || NPL > 0, "staggered waves: shared planes");
+    using Ring = MfmaRing<WORDS, BC, RING, NPL, ROT>;
+    // WV = waves per workgroup: eight (two per SIMD, 256 registers each), or four with 512 registers each -- two query tiles per
+    // wave at 2048 bits (the expanded queries alone are 256 registers), four MFMA chains, every row fragment used twice
+    static_assert(WV == 4 || WV == kMWaves, "waves per workgroup");
+    static_assert(WV == kMWaves || (NPL > 0 && KS == 1), "four waves: shared planes, whole-K chains (the first MFMA of a chain is the first plane class of group 0)");
+    constexpr int kWBlock = WV * 64;
+    constexpr bool AGA = WV == 4; // queries in AGPRs, MFMAs as inline assembly
     constexpr int QW = 32 * MT;         // queries per wave
     constexpr int KG = WORDS / 8;       // 256-bit groups per row
     constexpr int CPR = WORDS / 4;      // 16-byte chunks per row
     constexpr int RPLN = 16 / CPR;      // rows per 256-byte LDS line
     constexpr int RB = BC / CPR;        // rows per LDS block
     constexpr int NTB = RB / 32;        // 32-row tiles per block
-    constexpr int NA = NT;              // accumulator sets per query tile
+    constexpr int NA = NT * KS;         // accumulator sets per query tile
     constexpr int LPW = BC / kWBlock;   // row loads per wave and block
     constexpr int PCH = RB / 8;         // 16-byte chunks of row popcounts per block
     constexpr int NPW = (PCH + 63) / 64; // waves that load them
-    constexpr int AHEAD = RING - 1;     // blocks requested ahead of the one being consumed
+    constexpr int AHEAD = NPL ? 2 : RING - 1; // blocks requested ahead of the one being consumed
     static_assert(WORDS % 8 == 0 && CPR <= 16 && NTB >= 1 && NTB % NT == 0 && BC % kWBlock == 0 && RB % 8 == 0, "unsupported row width");
-    static_assert(2 * WORDS * MT <= 128, "query operands must fit in registers");
+    static_assert(KG % KS == 0, "chains split the 256-bit groups");
+    static_assert(2 * WORDS * MT <= (WV == 4 ? 256 : 128), "query operands must fit in registers");
     static_assert((AHEAD - 1) * (LPW + 2) < 64, "vmcnt");
     static_assert(sizeof(Ring) <= 160 * 1024, "LDS");
     __shared__ Ring sh;
@@ -212,10 +277,22 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     // A cutoff that keeps a sizeable fraction of the table (estimated by the sample pass, bit 3 of
     // the flags) would send that fraction of all pairs through the exact path: the plain variant leaves such a
     // batch alone, the dense variant -- launched right behind it -- every other one.
+    if (WV < kMWaves && lane == 0) rr.seg_count[w + WV] = 0; // the candidate segments of the waves that do not exist
     const bool dense_batch = has_cutoff && (*((g_u32p) rr.flags) & 8u) != 0;
     if (DN ? !dense_batch : dense_batch) {
         if (lane == 0 && !DN) rr.seg_count[w] = 0;
         return;
+    }
+
+    // staggered waves: which of the waves of its SIMD is this one?  (HW_ID bits 5:4 = SIMD; the dispatcher's placement is
+    // not assumed)
+    bool role_b = false;
+    if constexpr (WV == kMWaves) {
+        if (threadIdx.x < 4) sh.simd_waves[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t arrival = 0;
+        if (lane == 0) arrival = atomicAdd(&sh.simd_waves[__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))], 1u);
+        role_b = (__builtin_amdgcn_readfirstlane(arrival) & 1u) != 0;
     }
 
     // ---- A operand: this wave's 32 queries, expanded once ----------------------------------
@@ -233,6 +310,10 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
             aexp[m][g][1] = fp4_class<1>(x, km);
             aexp[m][g][2] = fp4_class<2>(x, km);
             aexp[m][g][3] = fp4_class<3>(x, km);
+            if constexpr (AGA) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) asm volatile("" : "+a"(aexp[m][g][c]));
+            }
         }
     }
     // per-query constants of this wave (wave-private LDS: no workgroup barrier needed)
@@ -362,7 +443,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     };
     // all but the youngest AHEAD - 1 groups of requests (a group = one iteration's poll + block) have landed
     auto wait_for_next_block = [&]() {
-        if constexpr (AHEAD == 1) {
+        if constexpr (AHEAD == 1 || NPL > 0) {
             wait_vm_outstanding<0>();
         } else {
             const int extra = (polls ? 1 : 0) + (wq < NPW ? 1 : 0);
@@ -372,50 +453,177 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
         }
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Class planes: this wave's share of a landed block -> the raw copy and the planes the eight waves read, TRANSPOSED on
+    // the way: chunk c of row r goes to position c * RB + r of its plane.  A lane of the contraction (row i of a tile, half h)
+    // then finds chunk 2 g + h of every class at ONE address + a compile-time offset -- no per-read address arithmetic, no
+    // swizzle (consecutive lanes read consecutive 16-byte chunks) -- and the landing buffer's XOR swizzle makes the
+    // producer's column reads conflict-free as well.
+    auto exp_read = [&](int from, int j) -> u32x4 {
+        const int p = (j * WV + wq) * 64 + lane; // (row, chunk) pair of this lane: consecutive lanes, consecutive rows
+        const int row = p % RB, c = p / RB;
+        const int line = row / RPLN;
+        return sh.rows[from][line * 16 + (row % RPLN) * CPR + (c ^ (line % CPR))];
+    };
+    auto exp_write = [&](int to, int j, u32x4 x) {
+        const int p = (j * WV + wq) * 64 + lane;
+        sh.cons[to][p] = x;
+        const v4i c3 = fp4_class<3>(x, km);
+        sh.cons[to][BC + p] = u32x4{static_cast<uint32_t>(c3.x), static_cast<uint32_t>(c3.y), static_cast<uint32_t>(c3.z), static_cast<uint32_t>(c3.w)};
+        if constexpr (NPL > 1) {
+            const v4i c2 = fp4_class<2>(x, km);
+            sh.cons[to][2 * BC + p] = u32x4{static_cast<uint32_t>(c2.x), static_cast<uint32_t>(c2.y), static_cast<uint32_t>(c2.z), static_cast<uint32_t>(c2.w)};
+        }
+    };
+    auto expand_block = [&](int from, int to) {
+#if GSIM_MF_WHATIF & 4
+        return;
+#endif
+        if constexpr (NPL > 0) {
+#pragma unroll
+            for (int j = 0; j < LPW; j++) exp_write(to, j, exp_read(from, j));
+        }
+    };
+
     uint32_t kcnt[DN ? 16 : 1]; // dense variant: rows surely at or above the cutoff, per accumulator slot (= query) of this lane
 #pragma unroll
     for (int r = 0; r < (DN ? 16 : 1); r++) kcnt[r] = 0;
     u64 blk = blockIdx.x;
-    // ---- prologue: the first AHEAD blocks are requested, the first one has landed ----
+    // ---- prologue: the first AHEAD blocks are requested, the first one has landed (and is expanded) ----
 #pragma unroll
     for (int d = 0; d < AHEAD; d++) issue_block(blk + static_cast<u64>(d) * gridDim.x, d % RING, d % Ring::RP);
-    if constexpr (AHEAD == 1) {
-        wait_vm_outstanding<0>();
+    if constexpr (AHEAD == 1 || NPL > 0) {
+        if constexpr (NPL > 0) {
+            if (wq < NPW) wait_vm_outstanding<LPW + 1>();
+            else wait_vm_outstanding<LPW>();
+        } else {
+            wait_vm_outstanding<0>();
+        }
     } else {
         if (wq < NPW) wait_vm_outstanding<(AHEAD - 1) * (LPW + 1)>();
         else wait_vm_outstanding<(AHEAD - 1) * LPW>();
     }
     lds_barrier();
+    if constexpr (NPL > 0) {
+        expand_block(0, 0);
+        wait_vm_outstanding<0>();
+        lds_barrier();
+    }
 
 #if GSIM_MF_TIMING
     unsigned long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     constexpr int PER = kBBins / 64; // histogram bins per lane in a threshold update
-    // Threshold refresh: every 2^RS blocks ONE wave of the workgroup (in rotation; the workgroups staggered) requests the
-    // table-wide histogram of one of its queries by DMA and, LAT blocks later (when the waits at the block ends have seen it
-    // land), derives the query's threshold from it.  HB staging buffers: event e + HB may only be requested after event e has
-    // been read, HB 2^RS > LAT.  As often as that allows -- every block with two buffers and one block in flight: the rate is
-    // worth more than the thresholds it produces (125 M x 2048-bit rows, 256 queries, thresholds already final: every other
-    // block 25.8 ms, every fourth 27.2, every eighth 30.3; 512-bit rows, every fourth block: 20.9 ms against 15.3 --
-    // profiles/r05_batch_mfma_experiments.txt).
+    // Threshold refresh: every 2^rs blocks ONE wave of the workgroup (in rotation; the workgroups staggered) requests the
+    // table-wide histogram of one of its queries by DMA and, AHEAD + 1 blocks later, derives the query's threshold from it.
     uint32_t turn = blockIdx.x;
-    constexpr int LAT = AHEAD;                                   // blocks from a histogram's request to its use
-    constexpr int RS = (LAT + Ring::HB) / Ring::HB <= 2 ? 1 : 2; // (every block -- possible with two buffers -- was slower than every other one: 27.5 ms)
-    int slot = 0, pslot = 0;                   // ring slot / popcount slot of the block being consumed
+    constexpr int RSMIN = AHEAD >= 3 ? 2 : 1; // (two staging buffers: an event's histogram is read AHEAD + 1 blocks after its request)
+    const int prio_mode = rs_arg >= 0 ? (rs_arg >> 8) : 0;
+    rs_arg = rs_arg >= 0 ? (rs_arg & 255) : rs_arg;
+    if (prio_mode == 2) {
+        if (role_b) __builtin_amdgcn_s_setprio(1);
+    }
+    if (prio_mode == 3) {
+        if (!role_b) __builtin_amdgcn_s_setprio(1);
+    }
+    const int rs = rs_arg >= RSMIN ? rs_arg : (nblocks >= 64ull * gridDim.x * (kMChunks / BC) ? 2 : RSMIN);
+    int slot = 0, pslot = 0, par = 0;          // ring slot / popcount slot / landing buffer of the block being consumed
+    int ccur = 0;                              // planes: the block's buffer in `cons`
     int pend_q = -1, pend_buf = 0;             // refresh under way: the query whose histogram was requested, its staging buffer
     uint32_t pend_at = 0;
     uint32_t it = 0;
 
     // ---- the work on one group of row tiles (NT tiles from t2 on), in pieces the main loop arranges ----
     v16f acc[MT][NA];
-    // contraction over the rows of NT tiles
-    auto contract = [&](const u32x4* cbase, int t2) __attribute__((always_inline)) {
+    // contraction over the 256-bit groups G0 .. G1 - 1 of the tiles' rows (G0 == 0: the accumulators start at zero)
+    auto contract = [&](auto g0c, auto g1c, const u32x4* cbase, int t2) __attribute__((always_inline)) {
+        constexpr int G0 = decltype(g0c)::value, G1 = decltype(g1c)::value;
         MF_T(tk0);
+        if constexpr (G0 == 0 && !AGA) {
 #pragma unroll
-        for (int m = 0; m < MT; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int c = 0; c < NA; c++) acc[m][c] = v16f{};
-        {
+                for (int c = 0; c < NA; c++) acc[m][c] = v16f{};
+        }
+        if constexpr (NPL > 0) {
+            // ---- shared planes: one address, compile-time offsets, the next group's fragments requested while
+            // this group's MFMAs run (planes: behind their own MFMAs; raw: behind the last expansion) ----
+            const u32x4* crow = cbase + h * RB + t2 * 32 + i;
+            // PD groups of fragments in flight (single row tiles: two, a pair of tiles: one -- the registers)
+            constexpr int PD = (NT == 1 || AGA) ? 2 : 1;
+            u32x4 R[PD][NT], P[PD][NPL][NT];
+#pragma unroll
+            for (int d = 0; d < PD; d++) {
+                if (G0 + d < G1) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; tt++) {
+#pragma unroll
+                        for (int p = 0; p < NPL; p++) P[d][p][tt] = GSIM_LDSROW(crow[(1 + p) * BC + 2 * (G0 + d) * RB + tt * 32]);
+                        R[d][tt] = GSIM_LDSROW(crow[2 * (G0 + d) * RB + tt * 32]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0); // (the first requests are not part of the pipeline below)
+#pragma unroll
+            for (int g = G0; g < G1; g++) {
+                constexpr int kPD = PD;
+                const int bf = (g - G0) % kPD;
+#define GSIM_PLANE_CLASS(PL)                                                                                           \
+    if constexpr ((PL) < NPL) {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MT; m++) _Pragma("unroll") for (int tt = 0; tt < NT; tt++)               \
+        {                                                                                                              \
+            const u32x4 pl = P[bf][(PL) < NPL ? (PL) : 0][tt];                                                         \
+            const v4i plv{static_cast<int>(pl.x), static_cast<int>(pl.y), static_cast<int>(pl.z), static_cast<int>(pl.w)};       \
+            if constexpr (AGA)                                                                                         \
+                mfma_class_agpr<3 - (PL)>(aexp[m][g][3 - (PL)], plv, acc[m][tt * KS + ((3 - (PL)) % KS)], g == 0 && (PL) == 0); \
+            else                                                                                                       \
+                acc[m][tt * KS + ((3 - (PL)) % KS)] = mfma_class<3 - (PL)>(aexp[m][g][3 - (PL)], plv, acc[m][tt * KS + ((3 - (PL)) % KS)]); \
+        }                                                                                                              \
+    }
+                GSIM_PLANE_CLASS(0)
+                GSIM_PLANE_CLASS(1)
+#undef GSIM_PLANE_CLASS
+                if (g + PD < G1) {
+#pragma unroll
+                    for (int p = 0; p < NPL; p++)
+#pragma unroll
+                        for (int tt = 0; tt < NT; tt++) P[bf][p][tt] = GSIM_LDSROW(crow[(1 + p) * BC + 2 * (g + PD) * RB + tt * 32]);
+                }
+#define GSIM_RAW_CLASS(C)                                                                                              \
+    if constexpr ((C) < 4 - NPL) {                                                                                     \
+        v4i e[NT];                                                                                                     \
+        _Pragma("unroll") for (int tt = 0; tt < NT; tt++) e[tt] = fp4_class<C>(R[bf][tt], km);                         \
+        if ((C) == 3 - NPL && g + PD < G1) {                                                                           \
+            _Pragma("unroll") for (int tt = 0; tt < NT; tt++) R[bf][tt] = GSIM_LDSROW(crow[2 * (g + PD) * RB + tt * 32]); \
+        }                                                                                                              \
+        _Pragma("unroll") for (int m = 0; m < MT; m++) _Pragma("unroll") for (int tt = 0; tt < NT; tt++)               \
+        {                                                                                                              \
+            if constexpr (AGA)                                                                                         \
+                mfma_class_agpr<C>(aexp[m][g][C], e[tt], acc[m][tt * KS + ((C) % KS)], false);                        \
+            else                                                                                                       \
+                acc[m][tt * KS + ((C) % KS)] = mfma_class<C>(aexp[m][g][C], e[tt], acc[m][tt * KS + ((C) % KS)]);      \
+        }                                                                                                              \
+    }
+                GSIM_RAW_CLASS(0)
+                GSIM_RAW_CLASS(1)
+                GSIM_RAW_CLASS(2)
+#undef GSIM_RAW_CLASS
+                // the order the scheduler is to keep: every MFMA but the last class's followed by its share of the
+                // expansions, the plane requests behind the plane classes' MFMAs, the raw requests behind the last expansion
+                {
+                    constexpr int MPC = MT * NT;               // MFMAs per class
+                    constexpr int VAL = (4 - NPL) * 4 * NT;    // expansion instructions per group
+                    constexpr int SLOTS = 4 * MPC - MPC;       // MFMAs that have expansions behind them
+                    constexpr int VPS = (VAL + SLOTS - 1) / SLOTS;
+#pragma unroll
+                    for (int s = 0; s < 4 * MPC; s++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (s < SLOTS) __builtin_amdgcn_sched_group_barrier(0x002, VPS, 0);
+                        if (s == NPL * MPC - 1 && g + PD < G1) __builtin_amdgcn_sched_group_barrier(0x100, NPL * NT, 0);
+                        if (s == SLOTS - 1 && g + PD < G1) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                    }
+                }
+            }
+        } else {
             const u32x4* lrow[NT];
             int xr[NT];
 #pragma unroll
@@ -439,7 +647,7 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
     _Pragma("unroll") for (int tt = 0; tt < NT; tt++) e[tt] = fp4_class<C>(b[tt], km);                     \
     _Pragma("unroll") for (int m = 0; m < MT; m++)                                                         \
         _Pragma("unroll") for (int tt = 0; tt < NT; tt++)                                                  \
-            acc[m][tt] = mfma_class<C>(aexp[m][g][C], e[tt], acc[m][tt]);                                  \
+            acc[m][tt * KS + ((C) % KS)] = mfma_class<C>(aexp[m][g][C], e[tt], acc[m][tt * KS + ((C) % KS)]);  \
 }
                 GSIM_MFMA_CLASS(0)
                 GSIM_MFMA_CLASS(1)
@@ -451,20 +659,37 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
                 if (MT > 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (MT > 1) {
-            // all accumulators are complete HERE: without this hipcc sinks the MFMA chain of the
-            // second query tile below the epilogue of the first and keeps every expanded row
-            // operand alive for it
+        if constexpr (G1 == KG && AGA) {
 #pragma unroll
-            for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]));
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int c = 0; c < NA; c++) mfma_asm_settle(acc[m][c]);
+        }
+        if constexpr (G1 == KG) {
+            if (KS > 1) {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int tt = 0; tt < NT; tt++) acc[m][tt * KS] = acc[m][tt * KS] + acc[m][tt * KS + 1];
+            }
+            if (MT > 1) {
+                // all accumulators are complete HERE: without this hipcc sinks the MFMA chain of the
+                // second query tile below the epilogue of the first and keeps every expanded row
+                // operand alive for it
+#pragma unroll
+                for (int m = 0; m < MT; m++) asm volatile("" : "+v"(acc[m][0]));
+            }
         }
         MF_T(tk1);
         MF_ACC(0, tk0, tk1);
     };
-#define ACC(m, tt) acc[m][tt]
+#define ACC(m, tt) acc[m][(tt) * KS]
     // the tiles' epilogue: linear pre-filter, exact path only for tiles with a passing pair (blk: the block the tiles belong
     // to, ps: its slot of row popcounts)
     auto tile_epilogue = [&](u64 blk, int t2, int ps) __attribute__((always_inline)) {
+#if GSIM_MF_WHATIF & 2
+        if (acc[0][0][0] != 12345.0f) return;
+#endif
         MF_T(tk1);
         uint32_t pb[NT];
 #pragma unroll
@@ -689,43 +914,13 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
         MF_ACC(1, tk1, tk2);
     };
     // the polled thresholds (landed some blocks ago) and, when its histogram has landed, the refreshed one
-    // Rows of up to 512 bits with more than 64 queries, 1024-bit rows with more than 128 (two query tiles per wave) and the
-    // dense-cutoff variant keep round 4's upkeep: EVERY wave re-derives one of its queries'
-    // thresholds every fourth block from the table-wide histogram, loaded straight into registers (the wait for those loads
-    // drains the row DMA -- harmless where a block is long; the staged refresh's rate, one wave per two blocks, cost these
-    // batches 8-35 %).
-    const bool direct_refresh = (WORDS <= 16 && nq > 64) || (WORDS == 32 && nq > 128) || DN;
-    const int rshift = nblocks >= 64ull * gridDim.x ? 2 : 0;
     auto thresholds = [&]() __attribute__((always_inline)) {
+#if GSIM_MF_WHATIF & 8
+        return;
+#endif
         MF_T(tr0);
         // the polled thresholds (landed some blocks ago) and, when its histogram has landed, the refreshed one
-        uint32_t gt = (lane < QW && ((it & 3u) == 0 || direct_refresh)) ? sh.tau_poll[wq][lane] : 0u;
-        if constexpr (WORDS <= 32 || DN) {
-            const int qref = q0t + static_cast<int>(((turn >> rshift) + rgroup * (QW / ngroups)) & (QW - 1));
-            if (direct_refresh && qref < nq && (turn & ((1u << rshift) - 1u)) == 0) {
-                uint32_t hh[PER];
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(qstate[qref].ghist, 0, kBBins * 4, 0x00020000);
-                uint32_t sum = 0;
-#pragma unroll
-                for (int v = 0; v < PER / 4; v++) {
-                    const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * PER * 4 + v * 16, 0, /*sc1*/ 16);
-                    hh[4 * v + 0] = v4.x;
-                    hh[4 * v + 1] = v4.y;
-                    hh[4 * v + 2] = v4.z;
-                    hh[4 * v + 3] = v4.w;
-                    sum += v4.x + v4.y + v4.z + v4.w;
-                }
-                uint32_t bin_k, cnt;
-                threshold_from_counts<PER>(hh, sum, a.k, lane, bin_k, cnt);
-                bin_k = __builtin_amdgcn_readfirstlane(bin_k);
-                cnt = __builtin_amdgcn_readfirstlane(cnt);
-                if (cnt >= a.k) {
-                    if (lane == 0)
-                        __hip_atomic_fetch_max((g_u32p) &qstate[qref].gtau, bin_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (lane == (qref & (QW - 1)) && bin_k > gt) gt = bin_k;
-                }
-            }
-        }
+        uint32_t gt = (lane < QW && (it & 3u) == 0) ? sh.tau_poll[wq][lane] : 0u;
         if (pend_q >= 0 && it >= pend_at) {
             uint32_t hh[PER];
             const u32x4* hp = reinterpret_cast<const u32x4*>(&sh.hist[pend_buf][lane * PER]);
@@ -754,20 +949,26 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
         MF_T(tr9);
         MF_ACC(3, tr0, tr9);
     };
+    constexpr std::integral_constant<int, 0> kG0{};
+    constexpr std::integral_constant<int, KG> kG1{};
 
     for (; blk < nblocks; blk += gridDim.x, turn++, it++) {
         MF_T(tb0);
         // ---- this iteration's requests ----
         issue_poll();
-        issue_block(blk + static_cast<u64>(AHEAD) * gridDim.x, (slot + AHEAD) % RING, (slot + AHEAD) % RING);
-        const uint32_t ev = turn >> RS;
-        const bool on_duty = wave_has_queries && !direct_refresh && (turn & ((1u << RS) - 1u)) == 0 && static_cast<int>(ev % WV) == wq && pend_q < 0;
+        {
+            const u64 ahead = blk + static_cast<u64>(AHEAD) * gridDim.x;
+            if constexpr (NPL > 0) issue_block(ahead, par, (pslot + 2) % Ring::RP);
+            else issue_block(ahead, (slot + AHEAD) % RING, (slot + AHEAD) % RING);
+        }
+        const uint32_t ev = turn >> rs;
+        const bool on_duty = wave_has_queries && (turn & ((1u << rs) - 1u)) == 0 && static_cast<int>(ev % WV) == wq && pend_q < 0;
         if (on_duty) {
             const int qref = q0t + static_cast<int>(((ev / WV) + rgroup * (QW / ngroups)) & (QW - 1));
             if (qref < nq) {
                 pend_q = qref;
-                pend_buf = static_cast<int>(ev & static_cast<uint32_t>(Ring::HB - 1));
-                pend_at = it + LAT;
+                pend_buf = static_cast<int>(ev & 1u);
+                pend_at = it + AHEAD + 1;
                 const u32x4* hsrc = reinterpret_cast<const u32x4*>(qstate[qref].ghist);
 #pragma unroll
                 for (int v = 0; v < kBBins / 256; v++)
@@ -776,13 +977,44 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
         }
         MF_T(tb2);
         MF_ACC(7, tb0, tb2);
-        if (wave_has_queries) {
+        const int cnext = ccur + 1 == Ring::NCONS ? 0 : ccur + 1;
+        if constexpr (!ROT) {
+            // every wave expands its share of the next block, then works through its tiles of this one
+            if constexpr (NPL > 0) expand_block(par ^ 1, cnext);
+            if (wave_has_queries) {
+                const u32x4* cbase = NPL > 0 ? sh.cons[ccur] : sh.rows[slot];
 #pragma unroll 1
-            for (int t2 = NT * rgroup; t2 < NTB; t2 += NT * ngroups) {
-                contract(sh.rows[slot], t2);
-                tile_epilogue(blk, t2, pslot);
+                for (int t2 = NT * rgroup; t2 < NTB; t2 += NT * ngroups) {
+                    // the two waves of a SIMD take turns at being preferred by the instruction arbiter: left alone it always
+                    // picks the older one, which then waits at the block barrier while the other finishes on its own
+                    if (prio_mode == 1) {
+                        if ((((t2 / (NT * ngroups)) & 1) != 0) == role_b) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+                    contract(kG0, kG1, cbase, t2);
+                    tile_epilogue(blk, t2, pslot);
+                }
+                thresholds();
             }
-            thresholds();
+        } else {
+            // Staggered waves (round 5).  With all eight waves in step at the block barrier, the two waves of a SIMD went
+            // through their vector-only phases -- epilogue, their share of the next block's planes, thresholds -- together
+            // and the matrix pipe idled for a third of every block.  The second wave of every SIMD (role B) now does that
+            // work BEFORE its tiles, the first one (role A) after them: one wave's vector-only phase lies beside the
+            // other's MFMAs.
+#pragma unroll 1
+            for (int phase = 0; phase < 2; phase++) {
+                if ((phase == 0) == role_b) {
+                    expand_block(par ^ 1, cnext);
+                    if (wave_has_queries) thresholds();
+                } else if (wave_has_queries) {
+#pragma unroll 1
+                    for (int t2 = NT * rgroup; t2 < NTB; t2 += NT * ngroups) {
+                        contract(kG0, kG1, sh.cons[ccur], t2);
+                        tile_epilogue(blk, t2, pslot);
+                    }
+                }
+            }
         }
         MF_T(tr1);
         wait_for_next_block();
@@ -791,6 +1023,8 @@ __global__ __launch_bounds__(kMBlock) void batch_mfma_kernel(BatchArgs a, u64 nb
         lds_barrier();
         slot = slot + 1 == RING ? 0 : slot + 1;
         pslot = pslot + 1 == Ring::RP ? 0 : pslot + 1;
+        par ^= 1;
+        ccur = cnext;
         MF_T(tb1);
         MF_ACC(5, tw, tb1);
         MF_ACC(2, tb0, tb1);
@@ -1125,36 +1359,62 @@ bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff)
 // The scan of one pass (a.nq <= kMfmaQueries queries from a.q0); with a cutoff only after
 // launch_batch_mfma_sample (it flags cutoffs that keep too many rows); thresholds come
 // from the sample passes launched before it, finish with launch_batch_finish.
-template <int WORDS, int MT, int NT, int BC, int RING, bool DN>
+//
+// Variants (MT, NT, KS, BC, RING, NPL -- batch_mfma_kernel):
+//   five to eight query tiles (the batch is bound by the matrix cores / instruction issue): 16 KB row blocks, expanded once
+//     per workgroup into shared class planes;
+//   three or four tiles: the same with one row tile per wave (two waves per query tile split a block's rows);
+//   one or two tiles (the batch is bound by the HBM stream): 32 KB blocks in a ring of four, three in flight, no planes.
+template <int WORDS, int MT, int NT, int KS, int BC, int RING, int NPL, bool DN, bool ROT = false, int WV = kMWaves>
 static void launch_variant(const BatchArgs& a, int num_cus, hipStream_t s)
 {
     constexpr int RB = BC / (WORDS / 4);
     const u64 nblocks = (a.nrows + RB - 1) / RB;
-    hipLaunchKernelGGL((batch_mfma_kernel<WORDS, MT, NT, BC, RING, DN>), dim3(num_cus), dim3(kMBlock), 0, s, a, nblocks);
+    hipLaunchKernelGGL((batch_mfma_kernel<WORDS, MT, NT, KS, BC, RING, NPL, DN, ROT, WV>), dim3(num_cus), dim3(WV * 64), 0, s, a, nblocks,
+                       std::getenv("GSIM_MF_RS") ? std::atoi(std::getenv("GSIM_MF_RS")) : -1);
 }
 
 hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s)
 {
     if (a.nq > static_cast<uint32_t>(kMfmaQueries) || a.nrows == 0) return hipErrorInvalidValue;
-    // 64 KB row blocks, two buffers: the geometry that won for every batch size at 1024 and 2048 bits (round 5: smaller
-    // blocks in deeper rings, class planes shared through LDS, staggered waves, four-wave workgroups -- all measured,
-    // profiles/r05_batch_mfma_experiments.txt); 256-bit rows: 32 KB blocks, three buffers (their popcount slots are large).
-    if (a.W == 64) {
-        // (with one query tile only four of the eight row groups find a pair of row tiles; single
-        // tiles for all eight waves -- NT = 1 -- were 20-50 % slower: one MFMA chain per wave)
-        launch_variant<64, 1, 2, kMChunks, 2, false>(a, num_cus, s);
+    static const int npl_env = std::getenv("GSIM_BATCH_MFMA_PLANES") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_PLANES")) : 1;
+    const bool two = npl_env == 2, none = npl_env == 0;
+    if (a.W == 64 && npl_env >= 10) { // (experiments: one geometry for every batch size)
+        if (npl_env == 10) launch_variant<64, 1, 2, 1, 4096, 2, 0, false>(a, num_cus, s);
+        else if (npl_env == 11) launch_variant<64, 1, 1, 2, 2048, 4, 0, false>(a, num_cus, s);
+        else if (npl_env == 12) launch_variant<64, 1, 2, 1, 2048, 4, 0, false>(a, num_cus, s);
+        else if (npl_env == 13) launch_variant<64, 1, 1, 2, 4096, 2, 0, false>(a, num_cus, s);
+        else launch_variant<64, 1, 1, 2, 1024, 4, 0, false>(a, num_cus, s);
+    } else if (a.W == 64) {
+        if (a.nq > 128) {
+            if (none) launch_variant<64, 1, 2, 1, 4096, 2, 0, false>(a, num_cus, s);
+            else if (two) launch_variant<64, 1, 2, 1, 1024, 2, 2, false, true>(a, num_cus, s);
+            else if (npl_env == 3) launch_variant<64, 1, 2, 1, 1024, 2, 1, false>(a, num_cus, s);
+            else if (npl_env == 4) launch_variant<64, 1, 2, 1, 1024, 2, 2, false>(a, num_cus, s);
+            else if (npl_env == 5) launch_variant<64, 1, 1, 2, 1024, 2, 1, false>(a, num_cus, s);
+            else if (npl_env == 6) launch_variant<64, 1, 1, 2, 1024, 2, 1, false, true>(a, num_cus, s);
+            else if (npl_env == 7) launch_variant<64, 1, 1, 2, 1024, 2, 2, false, true>(a, num_cus, s);
+            else if (npl_env == 8) launch_variant<64, 2, 2, 1, 1024, 2, 1, false, false, 4>(a, num_cus, s);
+            else if (npl_env == 9) launch_variant<64, 2, 2, 1, 1024, 2, 2, false, false, 4>(a, num_cus, s);
+            else launch_variant<64, 1, 2, 1, 1024, 2, 1, false, true>(a, num_cus, s);
+        } else if (a.nq > 64) {
+            launch_variant<64, 1, 1, 2, 1024, 2, 1, false>(a, num_cus, s);
+        } else {
+            launch_variant<64, 1, 1, 2, 2048, 4, 0, false>(a, num_cus, s);
+        }
     } else if (a.W == 32) {
         // two query tiles per wave halve the operand work: 8 % faster at 256 queries, even at 128,
         // slower below (fewer row groups per query tile)
-        if (a.nq > 128) launch_variant<32, 2, 1, kMChunks, 2, false>(a, num_cus, s);
-        else launch_variant<32, 1, 2, kMChunks, 2, false>(a, num_cus, s);
+        if (a.nq > 128) launch_variant<32, 2, 1, 1, 1024, 2, 1, false>(a, num_cus, s);
+        else if (a.nq > 64) launch_variant<32, 1, 2, 1, 1024, 2, 1, false>(a, num_cus, s);
+        else launch_variant<32, 1, 1, 2, 2048, 4, 0, false>(a, num_cus, s);
     } else if (a.W == 16) {
         // narrow rows: the epilogue outweighs the MFMAs, two query tiles per wave from 65 queries on
-        if (a.nq > 64) launch_variant<16, 2, 1, kMChunks, 2, false>(a, num_cus, s);
-        else launch_variant<16, 1, 2, kMChunks, 2, false>(a, num_cus, s);
+        if (a.nq > 64) launch_variant<16, 2, 1, 1, 2048, 3, 0, false>(a, num_cus, s);
+        else launch_variant<16, 1, 2, 1, 2048, 3, 0, false>(a, num_cus, s);
     } else if (a.W == 8) {
-        if (a.nq > 64) launch_variant<8, 2, 1, kMChunks / 2, 3, false>(a, num_cus, s);
-        else launch_variant<8, 1, 2, kMChunks / 2, 3, false>(a, num_cus, s);
+        if (a.nq > 64) launch_variant<8, 2, 1, 1, 2048, 3, 0, false>(a, num_cus, s);
+        else launch_variant<8, 1, 2, 1, 2048, 3, 0, false>(a, num_cus, s);
     } else {
         return hipErrorInvalidValue;
     }
@@ -1163,10 +1423,10 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
     // runs the batch; any other batch it leaves alone.  Weights without a usable band (cutoff_band): the VALU pass,
     // re-enqueued by the host when it finds flag 8 without flag 16.
     if (a.cutoff > 0.0f && batch_mfma_dense_applies(a.metric, a.alpha, a.beta, a.cutoff)) {
-        if (a.W == 64) launch_variant<64, 1, 1, kMChunks, 2, true>(a, num_cus, s);
-        else if (a.W == 32) launch_variant<32, 1, 2, kMChunks, 2, true>(a, num_cus, s);
-        else if (a.W == 16) launch_variant<16, 1, 2, kMChunks, 2, true>(a, num_cus, s);
-        else launch_variant<8, 1, 2, kMChunks / 2, 3, true>(a, num_cus, s);
+        if (a.W == 64) launch_variant<64, 1, 1, 1, 1024, 2, 1, true>(a, num_cus, s);
+        else if (a.W == 32) launch_variant<32, 1, 2, 1, 1024, 2, 1, true>(a, num_cus, s);
+        else if (a.W == 16) launch_variant<16, 1, 2, 1, 2048, 3, 0, true>(a, num_cus, s);
+        else launch_variant<8, 1, 2, 1, 2048, 3, 0, true>(a, num_cus, s);
     }
     return hipGetLastError();
 }
