@@ -368,6 +368,31 @@ def table_uses_fused(k, tm):
     return k <= 8192 and os.environ.get("GSIM_FUSED", "1") != "0" and tm["handed_back"] < max(1, tm["queries"])
 
 
+# The matrix-core batch kernel against its OTHER roofline ("report it against both"): instruction issue.  Two waves per
+# SIMD share one issue port with the MFMAs; scripts/mfma_fp4_probe.hip (profiles/r01_mfma_fp4_probe.txt) measured the cycles per
+# MFMA and SIMD (at the nominal 2.4 GHz the 10 PF peak is quoted on: 32 = the peak) for n extra vector instructions per MFMA:
+MFMA_ISSUE_PROBE = ((0, 38.2), (4, 38.1), (8, 57.6), (12, 69.7))
+# ... and the shipped 2048-bit kernel's vector instructions per MFMA, SQ_INSTS_VALU / SQ_INSTS_MFMA
+# (profiles/r05_batch_mfma_pmc_raw.txt; 5 of them are the operand expansion, round 5 could not take them out: DESIGN.md section 3)
+BATCH_VALU_PER_MFMA = {64: 7.8}
+
+
+def issue_roofline(W, frac):
+    n = BATCH_VALU_PER_MFMA.get(W)
+    if n is None or not frac:
+        return None
+    pts = MFMA_ISSUE_PROBE
+    cyc = pts[-1][1]
+    for (n0, c0), (n1, c1) in zip(pts, pts[1:]):
+        if n0 <= n <= n1:
+            cyc = c0 + (c1 - c0) * (n - n0) / (n1 - n0)
+            break
+    ceiling = 32.0 / cyc
+    return {"valu_per_mfma": n, "issue_ceiling_frac_of_peak": ceiling, "issue_frac": frac / ceiling,
+            "source": "profiles/r01_mfma_fp4_probe.txt (cycles per MFMA at n vector instructions, two waves per SIMD) and "
+                      "profiles/r05_batch_mfma_pmc_raw.txt (SQ_INSTS_VALU / SQ_INSTS_MFMA of this kernel)"}
+
+
 def time_batches(ctx, table, total_rows, R, fp_bits, kind, k, Q, steps, warmup, sharded, cutoff=0.0):
     """BASELINE configs[4]: Tversky(0.3, 0.7), Q-query batches, top-k per query; a step = one batch.
     Rows shard over the ranks, every rank scores all Q queries against its shard (the matrix-core
@@ -425,10 +450,124 @@ def time_batches(ctx, table, total_rows, R, fp_bits, kind, k, Q, steps, warmup, 
         "roofline": {"kernel": "batch_mfma_kernel<%d> (MX-FP4 contraction of the packed bits, f32 accumulate: exact)" % W,
                      "bound": "mfma", "achieved": tf_kernel, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf_kernel / MFMA_FP4_PEAK_TFLOPS, "traffic": None, "kernel_ms_avg": kms,
+                     "issue": issue_roofline(W, tf_kernel / MFMA_FP4_PEAK_TFLOPS) if not cutoff else None,
                      "whole_step_tflops": flops / per / 1e12,
                      "timed_with_hip_events": tm["batches"],
                      "table_bytes_read_once_per_batch_GBs": R * fp_bits / 8 / per / 1e9},
     }
+
+
+def in_process(args):
+    """`bench.py --gpus N --in-process`: the multi-GPU routes ONE process drives (FingerprintDB::search's fan-out and merge,
+    fingerprintdb_cuda.cu:356-380; `gpusimserver --gpus N [--merge rccl]`).  One handle over N devices, the table generated shard
+    by shard in HBM; per route the same queries (gsim_db_search_each: single queries, nothing shares a table pass), identical hits
+    asserted between the routes:
+      host_merge   every shard's kernels write their block into pinned host memory, k-way merge on the host (the default),
+                   eight queries enqueued ahead on every shard;
+      gsim_comm    blocks stay in HBM, one grouped ncclAllGather over the shards' streams, merge_kernel on the root's device;
+      twin         the first shard's rows alone on its device (what one GPU of the N does on its own);
+      torch_route  this script's one-process-per-GPU mode (RCCL through torch.distributed) as a child process, its own line.
+    On a one-GPU box the test-hooks build presents N logical devices (GSIM_LIB=gpusimilarity_amd/testhooks/libgsim_hip.so
+    GSIM_TEST_ALIAS_DEVICES=N): the code path is the product's, the devices are one GPU, the numbers are not a scaling curve."""
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch  # noqa: F401  (first: one HIP runtime in the process, see capi.load)
+    from gpusimilarity_amd import capi
+    N = args.gpus
+    if capi.device_count() < N:
+        raise SystemExit("--gpus %d --in-process but only %d device(s) visible" % (N, capi.device_count()))
+    aliased = bool(os.environ.get("GSIM_TEST_ALIAS_DEVICES"))
+    R = args.rows_per_gpu or (100_000_000 if N == 1 else 125_000_000)
+    total = R * N
+    kind = {"sparse": capi.SYNTH_SPARSE, "dense": capi.SYNTH_DENSE, "morgan": capi.SYNTH_MORGAN}[args.kind]
+    k, W = args.k, args.fp_bits // 32
+    qps = max(1, args.queries_per_step)
+    steps, warmup = args.steps, args.warmup
+    distinct = min((warmup + steps) * qps, 64)
+    queries = [synth_row(DB_SEED, kind, query_row(i, total), W) for i in range(distinct)]
+    steps_q = [np.ascontiguousarray(np.stack([queries[(s_ * qps + j) % distinct] for j in range(qps)])) for s_ in range(warmup + steps)]
+
+    def run(table, rows):
+        bufs = table.make_search_buffers(qps, k)
+        for s_ in range(warmup):
+            table.search_each_into(steps_q[s_], k, bufs)
+        table.enable_timing(True)
+        t0 = time.perf_counter()
+        for s_ in range(warmup, warmup + steps):
+            table.search_each_into(steps_q[s_], k, bufs)
+        el = time.perf_counter() - t0
+        tm = table.timing()
+        table.enable_timing(False)
+        nq = steps * qps
+        r = {"ms_per_query": 1e3 * el / nq, "fingerprints_per_s": rows * nq / el, "timed_region_s": el, "queries": nq,
+             "whole_path_hbm_frac": (rows * (args.fp_bits // 8) / (el / nq)) / (HBM_PEAK_GBS * 1e9 * max(1, table.shard_count())),
+             "kernel_ms_avg_first_shard": tm["scan_ms_sum"] / max(1, tm["queries"]), "queries_handed_back": tm["handed_back"]}
+        if tm["collectives"]:
+            r["gather_us_avg"] = 1e3 * tm["gather_ms_sum"] / tm["collectives"]
+            r["merge_us_avg"] = 1e3 * tm["merge_ms_sum"] / tm["collectives"]
+            r["collectives"] = tm["collectives"]
+        last = (bufs[0][:, :].copy(), bufs[1].copy(), bufs[2].copy())
+        return r, last
+
+    table = capi.Table(args.fp_bits).generate(DB_SEED, kind, 0, total, 0, ndevices=N)
+    routes = {}
+    routes["host_merge"], ref = run(table, total)
+    assert int(ref[1][-1]) == min(k, total) and int(ref[2][-1]) == total and ref[0][-1]["score"][0] == 1.0, "self hit missing"
+    comm = None
+    try:
+        comm = capi.Comm(list(range(table.shard_count())))
+        table.set_comm(comm)
+        routes["gsim_comm"], got = run(table, total)
+        routes["gsim_comm"]["transport"] = "loop-back copies (aliased devices)" if aliased and N > 1 else "RCCL ncclAllGather, world %d" % table.shard_count()
+        assert got[0].tobytes() == ref[0].tobytes() and (got[1] == ref[1]).all() and (got[2] == ref[2]).all(), "gsim_comm route differs from the host merge"
+        routes["gsim_comm"]["identical_to_host_merge"] = True
+        table.set_comm(None)
+    except capi.GsimError as e:
+        routes["gsim_comm"] = {"error": str(e)}
+    shards = table.shard_count()
+    table.close()
+    if comm is not None:
+        comm.close()
+    # the first shard's rows alone (row indices 0 .. R-1: the queries that are rows of other shards are fresh fingerprints to it)
+    twin = capi.Table(args.fp_bits).generate(DB_SEED, kind, 0, R, 0)
+    routes["twin"], _ = run(twin, R)
+    twin.close()
+    if not args.no_torch_route:
+        env = dict(os.environ)
+        if aliased and N > 1:
+            env["GSIM_BENCH_SHARE_GPU"] = "1"  # (one physical GPU: the ranks share cuda:0 over gloo -- test mode, see main())
+            for name in ("GSIM_TEST_ALIAS_DEVICES", "GSIM_LIB"):
+                env.pop(name, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(N), "--steps", str(steps), "--warmup", str(warmup), "--queries-per-step", str(qps),
+               "--rows-per-gpu", str(R), "--k", str(k), "--fp-bits", str(args.fp_bits), "--kind", args.kind, "--no-configs", "--no-cpu-baseline",
+               "--no-server-latency", "--no-pmc"] + (["--force-sharded-path"] if N == 1 else [])
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, timeout=1800)
+            line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            routes["torch_route"] = {"ms_per_query": line["ms_per_query"], "fingerprints_per_s": line["value"], "timed_region_s": line["timed_region_s"],
+                                     "backend": line["collective"]["backend"], "per_rank": line["collective"].get("per_rank"),
+                                     "shared_gpu_test_mode": line["collective"].get("shared_gpu_test_mode", False)}
+        except Exception as e:  # a report, never a reason to lose the in-process numbers
+            routes["torch_route"] = {"error": repr(e)}
+    hm = routes["host_merge"]
+    out = {
+        "timed_region_s": hm["timed_region_s"],
+        "metric": "fingerprints scanned/sec (1024-bit Tanimoto top-1000)", "value": hm["fingerprints_per_s"], "unit": "fingerprints/s",
+        "n_gpus": N, "steps": steps, "warmup": warmup, "ms_per_step": hm["ms_per_query"] * qps, "queries_per_step": qps,
+        "ms_per_query": hm["ms_per_query"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%d x %d-bit %s synthetic fingerprints per GPU x %d GPU(s) in ONE process (gsim_db_generate_sharded), Tanimoto top-%d, "
+                               "cutoff 0, %d single queries per step; value = the host-merge route (the product's default)" % (R, args.fp_bits, args.kind, N, k, qps),
+                   "rows_per_gpu": R, "fp_bits": args.fp_bits, "k": k, "shards": shards,
+                   "parallelism": "row shards on %d devices of one process, host merge | gsim_comm all-gather + merge_kernel" % N,
+                   "devices": "aliased: %d logical devices on one physical GPU (test hook) -- not a scaling measurement" % N if aliased else "physical"},
+        "whole_path_hbm_frac": hm["whole_path_hbm_frac"],
+        "roofline": {"kernel": "fused_kernel (per shard)", "bound": "hbm", "achieved": R * (args.fp_bits // 8) / (hm["kernel_ms_avg_first_shard"] * 1e-3) / 1e9 if hm["kernel_ms_avg_first_shard"] else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (R * (args.fp_bits // 8) / (hm["kernel_ms_avg_first_shard"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if hm["kernel_ms_avg_first_shard"] else None,
+                     "traffic": None, "kernel_ms_avg": hm["kernel_ms_avg_first_shard"]},
+        "routes": routes,
+    }
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def main():
@@ -453,12 +592,20 @@ def main():
                          "queries per step (use with --fp-bits 2048); a step is one batch")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the process rocprofv3 counts (pmc_traffic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--in-process", action="store_true",
+                    help="the one-process multi-GPU routes of the product (gpusimserver --gpus N): ONE handle sharded over --gpus "
+                         "devices -- host merge and the C-ABI collective (gsim_comm: RCCL all-gather + merge_kernel) -- each next to the "
+                         "first shard's single-GPU twin, and the one-process-per-GPU torch route as a child process")
+    ap.add_argument("--no-torch-route", action="store_true", help="--in-process: skip the torch.distributed child run")
     ap.add_argument("--force-sharded-path", action="store_true",
                     help="run the N>1 code path (device result blocks, all-gather, device merge) even at N=1")
     args = ap.parse_args()
 
     if args.pmc_child:
         pmc_child(args.rows_per_gpu or 100_000_000, args.fp_bits, {"sparse": 0, "dense": 1, "morgan": 2}[args.kind], args.k)
+        return
+    if args.in_process:
+        in_process(args)
         return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))  # no launcher: start the ranks ourselves
@@ -684,6 +831,20 @@ def main():
             except Exception as e:  # never lose the headline over it
                 widths.append({"fp_bits": bits, "error": repr(e)})
         out["widths"] = widths
+        # north_star's target sentence names THIS table: 1 B x 1024-bit rows (128 GB of the 288) on one GPU, the single launch
+        try:
+            t1b = make_table(1_000_000_000, 1024, 0)
+            r1b, _ = time_queries(ctx, t1b, 1_000_000_000, 1_000_000_000, 1024, kind, 1000, 3, 1, 4, False)
+            t1b.close()
+            c1b = {"name": "1B x 1024-bit on ONE MI355X (north_star's target table), Tanimoto top-1000, single launch", "rows_per_gpu": 1_000_000_000,
+                   "fp_bits": 1024, "k": 1000, "ms_per_query": r1b["ms_per_query"], "queries_per_step": 4, "ms_per_step": 4 * r1b["ms_per_query"],
+                   "value": r1b["fingerprints_per_s"], "unit": "fingerprints/s", "timed_region_s": r1b["seconds"],
+                   "whole_path_hbm_frac": r1b["whole_path_hbm_frac"], "roofline": r1b["roofline"]}
+            if r1b["sync_latency"]:
+                c1b.update(r1b["sync_latency"])
+            cfgs.append(c1b)
+        except Exception as e:  # never lose the headline over it
+            cfgs.append({"name": "1B x 1024-bit on one GPU", "error": repr(e)})
         out["configs"] = cfgs
         out["configs_note"] = ("configs[0] (small.fsim, CPU path) is timed under cpu_baseline.parts; configs[3] (1B rows over 8 GPUs) "
                                "is this script at --gpus 8")
@@ -705,6 +866,25 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "fingerprints/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": "failed: %r" % (e,)}
+        # LAST in the line, and short: the driver keeps the tail of stdout (8 KB), and round 4's record lost configs[1] to it
+        if "configs" in out:
+            short = []
+            for c in out["configs"]:
+                if "error" in c:
+                    short.append({"name": c["name"][:60], "error": c["error"][:80]})
+                    continue
+                rf = c.get("roofline") or {}
+                e = {"name": c["name"][:72], "ms": round(c.get("ms_per_query", c.get("ms_per_step", 0.0)), 5), "per": "query" if "ms_per_query" in c else "batch",
+                     "kernel_ms": round(rf.get("kernel_ms_avg") or 0.0, 5), "frac": round(rf.get("frac") or 0.0, 4), "bound": rf.get("bound")}
+                if c.get("sync_ms_median") is not None:
+                    e["sync_ms_median"] = round(c["sync_ms_median"], 5)
+                if rf.get("issue"):
+                    e["issue_frac"] = round(rf["issue"]["issue_frac"], 3)
+                if rf.get("queries_handed_back") is not None:
+                    e["handed_back"] = rf["queries_handed_back"]
+                short.append(e)
+            out["summary"] = {"configs": short, "traffic_over_algorithmic": out["roofline"].get("traffic_over_algorithmic"),
+                              "cpu_baseline_fp_per_s": (out.get("cpu_baseline") or {}).get("value")}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()

@@ -47,12 +47,12 @@ _lib = None
 EXPORTS = [
     "gsim_device_count", "gsim_device_free_bytes", "gsim_available_device_bytes", "gsim_next_device",
     "gsim_db_create", "gsim_db_add_rows", "gsim_db_finalize", "gsim_db_set_fold_factor", "gsim_db_fold_factor", "gsim_db_set_fold_full_on_device",
-    "gsim_fold_fingerprint", "gsim_db_generate", "gsim_synth_row", "gsim_db_attach_device_rows",
+    "gsim_fold_fingerprint", "gsim_db_generate", "gsim_db_generate_sharded", "gsim_synth_row", "gsim_db_attach_device_rows",
     "gsim_db_destroy", "gsim_db_count", "gsim_db_fp_bits", "gsim_db_data_bytes", "gsim_db_row",
     "gsim_db_shard_count", "gsim_db_shard_device", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_timed", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
     "gsim_merge_device_batch", "gsim_merge_host",
-    "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm",
+    "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm", "gsim_db_set_comm_root",
     "gsim_db_enable_timing",
     "gsim_db_get_timing", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
 ]
@@ -88,6 +88,7 @@ def load():
         "gsim_db_set_fold_full_on_device": (C.c_int, [vp, C.c_int]),
         "gsim_fold_fingerprint": (C.c_int, [u32p, C.c_uint32, C.c_uint32, u32p]),
         "gsim_db_generate": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
+        "gsim_db_generate_sharded": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
         "gsim_synth_row": (C.c_int, [C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, u32p]),
         "gsim_db_attach_device_rows": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
         "gsim_db_destroy": (C.c_int, [vp]),
@@ -117,6 +118,7 @@ def load():
         "gsim_comm_destroy": (C.c_int, [vp]),
         "gsim_comm_size": (C.c_int, [vp]),
         "gsim_db_set_comm": (C.c_int, [vp, vp]),
+        "gsim_db_set_comm_root": (C.c_int, [vp, C.c_int]),
         "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
@@ -211,8 +213,12 @@ class Table:
         check(self._L.gsim_db_finalize(self._h, device, ndevices))
         return self
 
-    def generate(self, seed: int, kind: int, first_row: int, nrows: int, device: int = 0):
-        check(self._L.gsim_db_generate(self._h, seed, kind, first_row, nrows, device))
+    def generate(self, seed: int, kind: int, first_row: int, nrows: int, device: int = 0, ndevices: int = 1):
+        """The synthetic table in HBM; ndevices > 1: split over that many GPUs like finalize(device, ndevices)."""
+        if ndevices > 1:
+            check(self._L.gsim_db_generate_sharded(self._h, seed, kind, first_row, nrows, device, ndevices))
+        else:
+            check(self._L.gsim_db_generate(self._h, seed, kind, first_row, nrows, device))
         return self
 
     def attach_device_rows(self, ptr: int, nrows: int, device: int = 0):
@@ -319,6 +325,10 @@ class Table:
         """Route multi-shard searches through `comm` (a :class:`Comm`; None: back to the host merge)."""
         check(self._L.gsim_db_set_comm(self._h, comm._h if comm is not None else None))
         self._comm = comm  # (keeps it alive)
+
+    def set_comm_root(self, shard: int):
+        """The shard whose device merges the gathered blocks (every device holds them all after the all-gather)."""
+        check(self._L.gsim_db_set_comm_root(self._h, shard))
 
     def enable_timing(self, enable=True):
         check(self._L.gsim_db_enable_timing(self._h, 1 if enable else 0))

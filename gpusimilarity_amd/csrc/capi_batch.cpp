@@ -10,8 +10,8 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
 {
     GSIM_HIP(set_device(s.device));
     if (s.bq_cap == 0) {
-        const int wpc = env_int("GSIM_BATCH_WAVES_PER_CU", 12);
-        s.bgeo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, 8);
+        const int wpc = db->knobs.batch_waves_per_cu;
+        s.bgeo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, 8, db->knobs.scan_ragged != 0);
         const uint64_t nchunks = (s.nrows + 63) / 64;
         uint64_t nw = static_cast<uint64_t>(s.num_cus) * static_cast<uint64_t>(wpc);
         if (nw > nchunks) nw = nchunks ? nchunks : 1;
@@ -29,11 +29,11 @@ int ensure_batch_buffers(gsim_db* db, Shard& s, uint32_t k)
             cap = std::max<uint64_t>(cap, (s.nrows / static_cast<uint64_t>(s.num_cus) + 512) * 32);
             nw = std::max<uint64_t>(nw, mfma_waves);
         }
-        const uint64_t lim = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP", 65536));
+        const uint64_t lim = static_cast<uint64_t>(db->knobs.batch_seg_cap);
         if (cap > lim) cap = lim;
         if (cap < 256) cap = 256;
         s.bseg_max = static_cast<uint32_t>(cap);
-        const uint64_t init = static_cast<uint64_t>(env_int("GSIM_BATCH_SEG_CAP_INIT", 4096));
+        const uint64_t init = static_cast<uint64_t>(db->knobs.batch_seg_cap_init);
         if (cap > init) cap = init < 16 ? 16 : init;
         s.bseg_cap = static_cast<uint32_t>(cap);
         s.bseg_waves = static_cast<uint32_t>(nw);
@@ -113,7 +113,8 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
     a.metric = metric;
     a.alpha = alpha;
     a.beta = beta;
-    const uint32_t sample = static_cast<uint32_t>(env_int("GSIM_BATCH_SAMPLE_CHUNKS", 8));
+    const uint32_t sample = static_cast<uint32_t>(db->knobs.batch_sample_chunks);
+    a.opts = (db->knobs.batch_mfma_sample ? 1u : 0u) | (db->knobs.batch_mfma_dense ? 2u : 0u) | ((static_cast<uint32_t>(db->knobs.batch_rpl) & 255u) << 8);
     // One contraction pass on the matrix cores for all of them (gsim_batch_mfma.hip: with fewer
     // than 8 x 32 queries the waves of a workgroup share query tiles and split the rows).  With a
     // cutoff it needs the matrix-core sample pass (large tables), which also estimates how many
@@ -131,10 +132,10 @@ int enqueue_batch(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, u
         bev = &s.bev[2 * s.bev_used];
         s.bev_used++;
     }
-    static const int mfma_min_q = env_int("GSIM_BATCH_MFMA_MIN_Q", 4);
+    const int mfma_min_q = db->knobs.batch_mfma_min_q;
     if (allow_mfma && mfma_min_q > 0 && nq >= static_cast<uint32_t>(mfma_min_q) &&
         nq <= static_cast<uint32_t>(gsim::kMfmaQueries) && gsim::batch_mfma_supported(s.W) &&
-        (!(cutoff > 0.0f) || gsim::batch_mfma_sample_applies(s.W, s.nrows, nq, k, s.num_cus))) {
+        (!(cutoff > 0.0f) || gsim::batch_mfma_sample_applies(s.W, s.nrows, nq, k, s.num_cus, db->knobs.batch_mfma_sample != 0))) {
         a.q0 = 0;
         a.nq = nq;
         // the rows' popcounts: once per table; borrowed rows (gsim_db_attach_device_rows) may have changed since the
@@ -259,7 +260,7 @@ int search_batched(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         for (auto& s : db->shards) {
             if (s.nrows == 0) continue;
             if (s.h_bflags[0] & 1u) overflow = true;
-            if (std::getenv("GSIM_DEBUG_BATCH")) { // counters of instrumented builds (GSIM_MF_TIMING)
+            if (db->knobs.debug_batch) { // counters of instrumented builds (GSIM_MF_TIMING)
                 std::fprintf(stderr, "batch flags %u dbg", s.h_bflags[0]);
                 for (int d = 2; d < 16; d++) std::fprintf(stderr, " %u", s.h_bflags[d]);
                 std::fprintf(stderr, "\n");
@@ -336,7 +337,7 @@ int gsim_db_search_batch_device(gsim_db* db, const uint32_t* queries, uint32_t n
     const size_t blk = gsim_result_block_bytes(k);
     unsigned char* out = static_cast<unsigned char*>(d_results);
     const bool batched = nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 && gsim::batch_supported(db->W) &&
-                         s.nrows > 0 && env_int("GSIM_BATCH", 1) != 0;
+                         s.nrows > 0 && db->knobs.batch != 0;
     for (uint32_t base = 0; base < nq; base += kBatchMaxQ) {
         const uint32_t nb = std::min<uint32_t>(kBatchMaxQ, nq - base);
         const uint32_t* qb = queries + static_cast<size_t>(base) * db->W;

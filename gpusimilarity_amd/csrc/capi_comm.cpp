@@ -50,7 +50,7 @@ int ensure_gather(gsim_db* db, size_t per_shard)
         }
         if (!s.gather_ev) GSIM_HIP(hipEventCreateWithFlags(&s.gather_ev, hipEventDisableTiming));
     }
-    Shard& s0 = db->shards[0];
+    Shard& s0 = db->shards[db->comm_root]; // (the shard whose device merges and answers the host)
     GSIM_HIP(set_device(s0.device));
     for (auto& e : s0.cev)
         if (!e) GSIM_HIP(hipEventCreate(&e));
@@ -64,27 +64,42 @@ int all_gather(gsim_db* db, size_t per_shard)
     const gsim_comm* c = db->comm;
     const size_t n = db->shards.size();
     if (!c->loopback) {
-        GSIM_NCCL(ncclGroupStart());
-        for (size_t i = 0; i < n; i++) {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; i++) {
             Shard& s = db->shards[i];
-            const ncclResult_t r = ncclAllGather(s.d_gather + i * per_shard, s.d_gather, per_shard, ncclChar, c->comms[i], s.stream);
-            if (r != ncclSuccess) {
-                (void) ncclGroupEnd();
-                return fail_nccl(r, "ncclAllGather");
-            }
+            r = ncclAllGather(s.d_gather + i * per_shard, s.d_gather, per_shard, ncclChar, c->comms[i], s.stream);
         }
-        GSIM_NCCL(ncclGroupEnd());
+        const ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) {
+            // the shards' kernels of this query are enqueued and their per-query state is not known to be clean: let the
+            // streams drain and have the next enqueue re-zero it
+            for (auto& s : db->shards) {
+                (void) set_device(s.device);
+                (void) hipStreamSynchronize(s.stream);
+                s.state_dirty = true;
+            }
+            return fail_nccl(r, "ncclAllGather");
+        }
         return GSIM_OK;
     }
-    // loop-back: only the first shard's buffer is read afterwards
-    Shard& s0 = db->shards[0];
-    for (size_t i = 1; i < n; i++) {
+    // Loop-back (aliased devices: RCCL refuses two ranks on one GPU): what the in-place all-gather does, with copies --
+    // EVERY shard's buffer receives every other shard's slot, on the receiver's own stream, behind an event on the sender's
+    // stream: the layout, the stream order and the merge input are the real route's, only the transport differs.
+    for (size_t i = 0; i < n; i++) {
         Shard& s = db->shards[i];
         GSIM_HIP(set_device(s.device));
         GSIM_HIP(hipEventRecord(s.gather_ev, s.stream));
-        GSIM_HIP(set_device(s0.device));
-        GSIM_HIP(hipStreamWaitEvent(s0.stream, s.gather_ev, 0));
-        GSIM_HIP(hipMemcpyAsync(s0.d_gather + i * per_shard, s.d_gather + i * per_shard, per_shard, hipMemcpyDeviceToDevice, s0.stream));
+    }
+    for (size_t j = 0; j < n; j++) {
+        Shard& d = db->shards[j];
+        GSIM_HIP(set_device(d.device));
+        for (size_t i = 0; i < n; i++) {
+            if (i == j) continue;
+            Shard& s = db->shards[i];
+            GSIM_HIP(hipStreamWaitEvent(d.stream, s.gather_ev, 0));
+            GSIM_HIP(hipMemcpyAsync(d.d_gather + i * per_shard, s.d_gather + i * per_shard, per_shard, hipMemcpyDeviceToDevice, d.stream));
+        }
     }
     return GSIM_OK;
 }
@@ -92,7 +107,8 @@ int all_gather(gsim_db* db, size_t per_shard)
 // the shards other than the first: their part of the gather is done (the next query reuses the buffers)
 int wait_others(gsim_db* db)
 {
-    for (size_t i = 1; i < db->shards.size(); i++) {
+    for (size_t i = 0; i < db->shards.size(); i++) {
+        if (i == db->comm_root) continue;
         Shard& s = db->shards[i];
         GSIM_HIP(set_device(s.device));
         const int rc = wait_stream(s.stream);
@@ -103,7 +119,7 @@ int wait_others(gsim_db* db)
 
 int fold_comm_timing(gsim_db* db)
 {
-    Shard& s0 = db->shards[0];
+    Shard& s0 = db->shards[db->comm_root]; // (the shard whose device merges and answers the host)
     float g = 0.f, m = 0.f;
     GSIM_HIP(hipEventElapsedTime(&g, s0.cev[0], s0.cev[1]));
     GSIM_HIP(hipEventElapsedTime(&m, s0.cev[1], s0.cev[2]));
@@ -132,7 +148,7 @@ int search_one_comm(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff
     const size_t blk = gsim_result_block_bytes(k);
     int rc = ensure_gather(db, blk);
     if (rc != GSIM_OK) return rc;
-    Shard& s0 = db->shards[0];
+    Shard& s0 = db->shards[db->comm_root]; // (the shard whose device merges and answers the host)
     rc = ensure_result_capacity(s0, k);
     if (rc != GSIM_OK) return rc;
     for (size_t i = 0; i < n; i++) {
@@ -171,7 +187,7 @@ int search_batch_comm(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_
 {
     const size_t n = db->shards.size();
     const size_t blk = gsim_result_block_bytes(k);
-    Shard& s0 = db->shards[0];
+    Shard& s0 = db->shards[db->comm_root]; // (the shard whose device merges and answers the host)
     std::vector<unsigned char> host;
     for (uint32_t base = 0; base < nq; base += kBatchMaxQ) {
         const uint32_t nb = std::min<uint32_t>(kBatchMaxQ, nq - base);
@@ -291,6 +307,16 @@ int gsim_db_set_comm(gsim_db* db, gsim_comm* comm)
             if (comm->devices[i] != db->shards[i].device) return fail(GSIM_ERR_INVALID, "the communicator's devices differ from the shards' devices");
     }
     db->comm = comm;
+    db->comm_root = 0;
+    return GSIM_OK;
+}
+
+int gsim_db_set_comm_root(gsim_db* db, int shard)
+{
+    if (!db || !db->finalized) return fail(GSIM_ERR_STATE, "table not finalized");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    if (shard < 0 || static_cast<size_t>(shard) >= db->shards.size()) return fail(GSIM_ERR_INVALID, "no such shard");
+    db->comm_root = static_cast<size_t>(shard);
     return GSIM_OK;
 }
 

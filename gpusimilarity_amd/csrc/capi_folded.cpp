@@ -40,9 +40,12 @@ void fold_rows_mt(const uint32_t* rows, uint64_t nrows, uint32_t W, uint32_t F, 
 // re-score those with the full fingerprints on the host (:307-314), stable partial bubble sort
 // (:315), keep min(k, .) and stop at the first re-scored value below the cutoff (:317-331);
 // then FingerprintDB::search's merge over the storages (:363-380).
-int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, float cutoff, gsim_hit* hits,
+int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t kout, float cutoff, gsim_hit* hits,
                   uint32_t* counts, uint64_t* approx)
 {
+    // kout is only the stride of the caller's hits array: every buffer and the selection are sized by the count clamped
+    // to the table (a count from a socket must not size pinned and device blocks; the answer is the same)
+    const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(kout, db->nrows));
     const uint32_t F = db->fold, W = db->W, Wf = W / F;
     int lg = 0;
     while ((1u << (lg + 1)) <= 2 * F) lg++;
@@ -53,7 +56,7 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
     std::vector<float> sc;
     // The re-score runs on the device when every storage also holds its full fingerprints in HBM (gsim_db_finalize puts
     // them there when they fit) and the candidate list fits the device sort; GSIM_FOLD_RESCORE=host forces the host path.
-    static const bool force_host = std::getenv("GSIM_FOLD_RESCORE") && std::string(std::getenv("GSIM_FOLD_RESCORE")) == "host";
+    const bool force_host = db->knobs.fold_rescore_host != 0;
     bool on_device = !force_host && want <= 65536 && k > 0;
     for (auto& s : db->shards) on_device = on_device && s.d_full != nullptr;
     // the host path for one storage: its folded candidates (in s.h_result) re-scored with the host copy of the full rows
@@ -171,7 +174,7 @@ int search_folded(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k,
         }
         if (db->shards.size() > 1) std::stable_sort(merged.begin(), merged.end(), hit_before);
         const uint32_t n = static_cast<uint32_t>(std::min<size_t>(merged.size(), k));
-        if (n) std::memcpy(hits + static_cast<size_t>(q) * k, merged.data(), sizeof(gsim_hit) * n);
+        if (n) std::memcpy(hits + static_cast<size_t>(q) * kout, merged.data(), sizeof(gsim_hit) * n);
         counts[q] = n;
         if (approx) approx[q] = ap;
     }

@@ -41,8 +41,12 @@ int fail_hip(hipError_t e, const char* what);
     } while (0)
 
 
+gsim::Knobs read_knobs(); // (the one place that calls getenv for tuning knobs; gsim_db_create)
+#ifdef GSIM_TEST_HOOKS
 int env_int(const char* name, int dflt);
-// Test hook (no production use): GSIM_TEST_ALIAS_DEVICES=N makes the library present N logical devices that all
+#endif
+// Test hook (compiled only with -DGSIM_TEST_HOOKS: testhooks/libgsim_hip.so, never the shipped library):
+// GSIM_TEST_ALIAS_DEVICES=N makes the library present N logical devices that all
 // live on physical device 0, so that the in-process multi-device code -- gsim_db_finalize(db, dev, n > 1), the shard
 // fan-out and host merge of search_one / the batch path / folded tables, gsim_next_device's round robin,
 // gpusimserver --gpus N -- runs on a one-GPU box exactly as it would on N GPUs (own stream, state and scratch per
@@ -106,6 +110,7 @@ struct Shard {
     uint32_t epoch = 0;
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
     uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
+    bool slot_rerun[kPipe] = {};    // ... but behind a launch that left the per-query state dirty: not to be trusted, run again
     char* h_pipe = nullptr;          // kPipe pinned result blocks (gsim_db_search_each)
     size_t h_pipe_block = 0;
     // Tables whose scores tie heavily (narrow or very sparse fingerprints) make the single-launch path hand every
@@ -186,6 +191,7 @@ struct gsim_db {
     uint32_t fold = 1;                 // effective factor (divides W), fixed at finalize
     bool fold_full_on_device = true;   // gsim_db_set_fold_full_on_device
     uint32_t row_base = 0;
+    gsim::Knobs knobs;                 // the environment's tuning knobs as gsim_db_create found them
     bool timing = false;
     gsim_timing acc{};
     unsigned long long dense_batches = 0; // multi-query passes whose dense cutoff the matrix-core pass counted itself
@@ -193,6 +199,7 @@ struct gsim_db {
     unsigned long long blocks_checked = 0, blocks_rechecked = 0, blocks_torn = 0; // single launch, synchronous callers: result blocks whose checksum
                                                                // did not match at first sight / never did (re-run)
     gsim_comm* comm = nullptr; // gsim_db_set_comm: shard results meet through an RCCL all-gather + merge_kernel instead of on the host
+    size_t comm_root = 0;      // ... on this shard's device (every device's buffer holds all blocks after the gather)
     // One search at a time per handle (the reference serialises searches behind a function-static
     // mutex, fingerprintdb_cuda.cu:236): concurrent callers queue here.
     std::mutex search_mutex;

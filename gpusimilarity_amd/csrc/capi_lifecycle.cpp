@@ -20,11 +20,50 @@ int fail_hip(hipError_t e, const char* what)
     return GSIM_ERR_HIP;
 }
 
-int env_int(const char* name, int dflt)
+namespace
+{
+int env_value(const char* name, int dflt)
 {
     const char* v = std::getenv(name);
     if (!v || !*v) return dflt;
     return std::atoi(v);
+}
+} // namespace
+
+gsim::Knobs read_knobs()
+{
+    gsim::Knobs k;
+    k.scan_waves_per_cu = env_value("GSIM_SCAN_WAVES_PER_CU", k.scan_waves_per_cu);
+    k.scan_unroll = env_value("GSIM_SCAN_UNROLL", k.scan_unroll);
+    k.scan_ragged = env_value("GSIM_SCAN_RAGGED", k.scan_ragged);
+    k.sample_chunks = env_value("GSIM_SAMPLE_CHUNKS", k.sample_chunks);
+    k.sample_shift = env_value("GSIM_SAMPLE_SHIFT", k.sample_shift);
+    k.fused = env_value("GSIM_FUSED", k.fused);
+    if (const char* v = std::getenv("GSIM_FUSED_MAX_ROWS")) k.fused_max_rows = std::atoll(v);
+    k.fused_debug = env_value("GSIM_FUSED_DEBUG", k.fused_debug);
+    k.fused_flags = env_value("GSIM_FUSED_FLAGS", k.fused_flags);
+    k.fused_seed_narrow = env_value("GSIM_FUSED_SEED_NARROW", k.fused_seed_narrow);
+    k.largek_one_block_max = env_value("GSIM_LARGEK_ONE_BLOCK_MAX", k.largek_one_block_max);
+    k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
+    k.batch = env_value("GSIM_BATCH", k.batch);
+    k.batch_waves_per_cu = env_value("GSIM_BATCH_WAVES_PER_CU", k.batch_waves_per_cu);
+    k.batch_seg_cap = env_value("GSIM_BATCH_SEG_CAP", k.batch_seg_cap);
+    k.batch_seg_cap_init = env_value("GSIM_BATCH_SEG_CAP_INIT", k.batch_seg_cap_init);
+    k.batch_sample_chunks = env_value("GSIM_BATCH_SAMPLE_CHUNKS", k.batch_sample_chunks);
+    k.batch_rpl = env_value("GSIM_BATCH_RPL", k.batch_rpl);
+    k.batch_mfma_min_q = env_value("GSIM_BATCH_MFMA_MIN_Q", k.batch_mfma_min_q);
+    k.batch_mfma_sample = env_value("GSIM_BATCH_MFMA_SAMPLE", k.batch_mfma_sample);
+    k.batch_mfma_dense = env_value("GSIM_BATCH_MFMA_DENSE", k.batch_mfma_dense);
+    k.debug_batch = std::getenv("GSIM_DEBUG_BATCH") ? 1 : 0;
+    k.fold_full_on_device = env_value("GSIM_FOLD_FULL_ON_DEVICE", k.fold_full_on_device);
+    if (const char* v = std::getenv("GSIM_FOLD_RESCORE")) k.fold_rescore_host = std::string(v) == "host" ? 1 : 0;
+    return k;
+}
+
+#ifdef GSIM_TEST_HOOKS
+int env_int(const char* name, int dflt)
+{
+    return env_value(name, dflt);
 }
 
 int alias_devices()
@@ -32,6 +71,12 @@ int alias_devices()
     static const int n = env_int("GSIM_TEST_ALIAS_DEVICES", 0);
     return n > 0 ? n : 0;
 }
+#else
+int alias_devices()
+{
+    return 0;
+}
+#endif
 
 int phys_device(int logical)
 {
@@ -109,13 +154,12 @@ int setup_shard(gsim_db* db, Shard& s)
     s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     GSIM_HIP(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
     s.stream = s.own_stream;
-    const int wpc = env_int("GSIM_SCAN_WAVES_PER_CU", 4);
-    const int unroll = env_int("GSIM_SCAN_UNROLL", 8);
+    const gsim::Knobs& kn = db->knobs;
     if (s.W == 0) s.W = db->W;
-    s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, wpc, unroll);
-    s.sample_chunks = env_int("GSIM_SAMPLE_CHUNKS", 4);
+    s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, kn.scan_waves_per_cu, kn.scan_unroll, kn.scan_ragged != 0);
+    s.sample_chunks = kn.sample_chunks;
     s.fgeo = s.geo;
-    (void) gsim::fused_word_geometry(s.nrows, s.W, s.num_cus, &s.fgeo); // (rows of 3 ... 11 or twice that many words: the single launch's own)
+    (void) gsim::fused_word_geometry(s.nrows, s.W, s.num_cus, &s.fgeo, kn.scan_ragged != 0); // (rows of 3 ... 11 or twice that many words: the single launch's own)
     if (s.fgeo.nchunks < 4ull * s.fgeo.nwaves) { // small table: threshold checkpoints need a few trips per wave
         // (narrow rows: a chunk is 512 rows and a wave's LDS store holds 2048 -- three chunks per wave, so that a store
         // cannot fill before the one threshold such a table sees, the one after the loop)
@@ -304,6 +348,7 @@ int gsim_db_create(uint32_t fp_bits, gsim_db** out)
     if (!db) return fail(GSIM_ERR_NOMEM, "out of host memory");
     db->fp_bits = fp_bits;
     db->W = fp_bits / 32;
+    db->knobs = read_knobs(); // (once per handle; no search entry point reads the environment)
     *out = db;
     return GSIM_OK;
 }
@@ -404,7 +449,7 @@ int gsim_db_finalize(gsim_db* db, int device, int ndevices)
         // later storages' folded rows and the search scratch were budgeted for.  Per device: the full rows
         // of its storages + 24 B per folded row (the four-kernel pipeline's scratch, allocated on first use) + 2 GB.
         // Without them the re-score runs on the host, as in the reference (fingerprintdb_cuda.cu:307-331).
-        static const int full_on_device = env_int("GSIM_FOLD_FULL_ON_DEVICE", 1);
+        const int full_on_device = db->knobs.fold_full_on_device;
         bool keep_full = full_on_device != 0 && db->fold_full_on_device && db->nrows > 0;
         if (keep_full) {
             std::vector<size_t> need(static_cast<size_t>(ndev), 0);
@@ -496,6 +541,44 @@ int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row, u
     if (rc != GSIM_OK) return rc;
     GSIM_HIP(gsim::launch_generate(s.d_rows, seed, kind, first_row, nrows, db->W, s.stream));
     GSIM_HIP(hipStreamSynchronize(s.stream));
+    db->finalized = true;
+    return GSIM_OK;
+}
+
+int gsim_db_generate_sharded(gsim_db* db, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows, int device, int ndevices)
+{
+    if (!db) return fail(GSIM_ERR_INVALID, "db is NULL");
+    if (db->finalized || db->nrows) return fail(GSIM_ERR_STATE, "table already holds rows");
+    if (kind != GSIM_SYNTH_SPARSE && kind != GSIM_SYNTH_DENSE && kind != GSIM_SYNTH_MORGAN)
+        return fail(GSIM_ERR_INVALID, "unknown synthetic kind");
+    if (kind == GSIM_SYNTH_MORGAN && db->W > 12288) return fail(GSIM_ERR_INVALID, "Morgan-shaped rows: fp_bits too large");
+    if (nrows > 0xFFFFFFFFull) return fail(GSIM_ERR_INVALID, "more than 2^32-1 rows");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (ndev == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");
+    if (ndevices < 1 || device < 0 || device + ndevices > ndev) return fail(GSIM_ERR_NO_DEVICE, "device range exceeds the GPUs present");
+    if (static_cast<uint64_t>(ndevices) > nrows && nrows > 0) ndevices = static_cast<int>(nrows);
+    // the same contiguous split as gsim_db_finalize(db, device, ndevices)
+    const uint64_t per = (nrows + ndevices - 1) / ndevices;
+    db->nrows = nrows;
+    db->shards.resize(static_cast<size_t>(ndevices));
+    for (int i = 0; i < ndevices; i++) {
+        Shard& s = db->shards[static_cast<size_t>(i)];
+        s.device = device + i;
+        s.first_row = std::min<uint64_t>(per * i, nrows);
+        s.nrows = std::min<uint64_t>(per, nrows - s.first_row);
+        GSIM_HIP(set_device(s.device));
+        const size_t bytes = static_cast<size_t>(s.nrows) * db->W * 4;
+        GSIM_HIP(hipMalloc(&s.d_rows, bytes ? bytes : 16));
+        s.owns_rows = true;
+        int rc = setup_shard(db, s);
+        if (rc != GSIM_OK) return rc;
+        if (s.nrows) GSIM_HIP(gsim::launch_generate(s.d_rows, seed, kind, first_row + s.first_row, s.nrows, db->W, s.stream));
+    }
+    for (auto& s : db->shards) {
+        GSIM_HIP(set_device(s.device));
+        GSIM_HIP(hipStreamSynchronize(s.stream));
+    }
     db->finalized = true;
     return GSIM_OK;
 }

@@ -47,10 +47,10 @@ int ensure_result_capacity(Shard& s, uint32_t k)
     return GSIM_OK;
 }
 
-bool fused_applies(const Shard& s, uint32_t k)
+bool fused_applies(const gsim_db* db, const Shard& s, uint32_t k)
 {
-    static const int enabled = env_int("GSIM_FUSED", 1);
-    static const long long max_rows = std::getenv("GSIM_FUSED_MAX_ROWS") ? std::atoll(std::getenv("GSIM_FUSED_MAX_ROWS")) : -1;
+    const int enabled = db->knobs.fused;
+    const long long max_rows = db->knobs.fused_max_rows;
     if (!enabled || k == 0 || k > gsim::kFusedMaxK || s.nrows == 0 || !gsim::fused_supported(s.fgeo)) return false;
     // thresholds need >= k summary keys; without them every row is published (tiny tables only)
     if ((gsim::fused_summary_keys(s.fgeo.nwaves, k) == 0 || gsim::fused_final_keys(s.fgeo.nwaves / 4, k) == 0) && s.nrows > 8192) return false;
@@ -81,7 +81,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
         s.state_dirty = false;
     }
-    bool fused = mode == kAuto && fused_applies(s, k);
+    bool fused = mode == kAuto && fused_applies(db, s, k);
     if (fused && caller_syncs && s.fused_skip) {
         s.fused_skip--;
         fused = false;
@@ -152,12 +152,12 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.epoch = ++s.epoch & 0xFFFFFFu;
         if (f.epoch == 0) f.epoch = ++s.epoch & 0xFFFFFFu; // 0: what a clean header holds
         if (caller_syncs) static_cast<gsim_result_header*>(out)->flags = 0;
-        static const int dbg_on = env_int("GSIM_FUSED_DEBUG", 0);
+        const int dbg_on = db->knobs.fused_debug;
         if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
         f.dbg = s.d_dbg;
         // grid-wide waits give up after 2 ms + four scan times at 4 TB/s (only reached when the GPU is shared)
         f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
-        static const int xflags = env_int("GSIM_FUSED_FLAGS", 0);
+        const int xflags = db->knobs.fused_flags;
         f.xflags = static_cast<uint32_t>(xflags);
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
         // Narrow rows (128 / 256 bits): a wave meets 512 / 256 rows per trip and its LDS store (2048 slots) is full after a
@@ -165,11 +165,12 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         // (1/64 of the queries at 256 bits, nearly all at 128: scanned twice).  A strided sample first (K0: the
         // four-kernel pipeline's own) leaves a valid starting threshold in QueryState::gtau as a coarse BIN; the single
         // launch turns it into a score key (xflags bit 2).
-        static const int seed_narrow = env_int("GSIM_FUSED_SEED_NARROW", 1);
+        const int seed_narrow = db->knobs.fused_seed_narrow;
         if (seed_narrow && ((s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2) || s.fgeo.ragged_words) && s.nrows > 1500ull * s.fgeo.nwaves &&
             s.sample_chunks > 0 && k > 0) {
-            GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream)); // (sample_rows_kernel: 64 Ki ... 1 Mi rows, by k and the table)
-            f.xflags |= 4u;
+            bool seeded = false;
+            GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream, &seeded, db->knobs.sample_shift)); // (sample_rows_kernel: 64 Ki ... 1 Mi rows, by k and the table)
+            if (seeded) f.xflags |= 4u; // (the launcher has its own size rule: the flag says a threshold WAS left in gtau)
         }
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
         if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
@@ -185,7 +186,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         a.gate = &s.d_state->redo; // the classic kernels behind it run only if it handed the query back
     }
     if (s.nrows > 0 && s.sample_chunks > 0)
-        GSIM_HIP(gsim::launch_sample(a, s.geo, static_cast<uint32_t>(s.sample_chunks), s.stream));
+        GSIM_HIP(gsim::launch_sample(a, s.geo, static_cast<uint32_t>(s.sample_chunks), s.stream, nullptr, db->knobs.sample_shift));
     if (ev && !fused) GSIM_HIP(hipEventRecord(ev[0], s.stream));
     if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
     if (!caller_syncs) { // the ring slot is free once the scan has run
@@ -215,7 +216,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         // one launch -- two reads of the finalists, the radix passes in LDS over the keys of the boundary bin: select + gather
         // 56 us instead of 87 at k = 10 000 -- up to 32 Ki finalists, the grid's eight passes + gather beyond (52 k finalists, a
         // boundary bin of more than 16 Ki keys: 121 us either way).  A wrong guess is slower, never wrong)
-        static const int one_block_max = env_int("GSIM_LARGEK_ONE_BLOCK_MAX", 32768);
+        const int one_block_max = db->knobs.largek_one_block_max;
+        static_assert(kPipe <= 15, "the large-k hint word shares h_done's 64-byte block with the pipeline's completion words");
         uint32_t* hint = s.h_done + 15;
         const bool one_block = *static_cast<volatile uint32_t*>(hint) <= static_cast<uint32_t>(one_block_max);
         GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, hint, one_block, s.stream));
@@ -260,6 +262,14 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
 {
     if (!s.slot_fused[pipe_slot]) return wait_stream(s.stream);
     s.slot_fused[pipe_slot] = false;
+    if (s.slot_rerun[pipe_slot]) {
+        // enqueued behind a single launch that ended without closing its query (below): this one ran on per-query state
+        // nobody had re-zeroed, and its block's checksum only covers the block's own hits -- run it again
+        s.slot_rerun[pipe_slot] = false;
+        const int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
+        if (rc != GSIM_OK) return rc;
+        return wait_stream(s.stream);
+    }
     volatile uint32_t* flag = &static_cast<gsim_result_header*>(out)->flags; // (flags | epoch << 8: one 16-byte store with the rest of the header)
     const uint32_t want = s.slot_epoch[pipe_slot];
     bool done = false;
@@ -289,8 +299,12 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         // stays wrong is re-run on the four-kernel pipeline (gsim_timing.blocks_rechecked / blocks_torn count both).
         // (test hook, no production use: GSIM_TEST_TORN_EVERY=n makes every n-th block fail its check for good, so that the
         // re-run of a torn block -- with later queries of the call already enqueued behind it -- is exercised)
+#ifdef GSIM_TEST_HOOKS
         static const int torn_every = env_int("GSIM_TEST_TORN_EVERY", 0);
         const uint32_t spoil = (torn_every > 0 && ++db->blocks_checked % static_cast<unsigned>(torn_every) == 0) ? 1u : 0u;
+#else
+        const uint32_t spoil = 0;
+#endif
         auto block_ok = [&]() -> bool {
             const uint32_t n = h->count <= k ? h->count : k;
             const volatile uint32_t* w = reinterpret_cast<const volatile uint32_t*>(h + 1);
@@ -326,7 +340,13 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         s.redo_streak = s.redo_streak < 6 ? s.redo_streak + 1 : 6;
         if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
     }
-    if (!done) s.state_dirty = true; // the launch ended without closing the query: the state is re-zeroed
+    if (!done) {
+        // the launch ended without closing the query: the state is re-zeroed, and the later queries of a pipelined call --
+        // the stream has drained, so they have all run already, on that state -- are run again
+        s.state_dirty = true;
+        for (uint32_t j = 0; j < static_cast<uint32_t>(kPipe); j++)
+            if (j != pipe_slot && s.slot_fused[j]) s.slot_rerun[j] = true;
+    }
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
     int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
     if (rc != GSIM_OK) return rc;
@@ -376,34 +396,60 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
 // stream, one per-query state), but up to kPipe of them are enqueued ahead of the one the host is waiting for, each with
 // its own pinned result block and completion word -- the next kernel starts when the previous one retires instead of
 // after a host round trip (flag seen, hits copied, next launch: ~8 us per query).
-int search_each_pipelined(gsim_db* db, Shard& s, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff,
-                          int metric, float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
+int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff, int metric,
+                          float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
 {
-    GSIM_HIP(set_device(s.device));
+    // every shard of the handle (round 5: a multi-device handle used to pay a host round trip per query -- enqueue on all
+    // shards, wait, merge, next query): up to kPipe queries are enqueued ahead on EVERY shard's stream, each with its own
+    // pinned block per shard; the host merges query q's blocks while the devices run q + 1 ... q + kPipe - 1
+    const size_t nsh = db->shards.size();
     const size_t blk = gsim_result_block_bytes(k);
-    if (blk > s.h_pipe_block) {
-        if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
-        s.h_pipe = nullptr;
-        s.h_pipe_block = 0;
-        GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, kHostPolled));
-        s.h_pipe_block = blk;
+    for (auto& s : db->shards) {
+        GSIM_HIP(set_device(s.device));
+        if (blk > s.h_pipe_block) {
+            if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
+            s.h_pipe = nullptr;
+            s.h_pipe_block = 0;
+            GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, kHostPolled));
+            s.h_pipe_block = blk;
+        }
     }
-    const uint32_t row_base = db->row_base + static_cast<uint32_t>(s.first_row);
+    std::vector<gsim_hit> merged;
+    std::vector<size_t> ends;
     uint32_t issued = 0;
     for (uint32_t done = 0; done < nq; done++) {
         for (; issued < nq && issued - done < static_cast<uint32_t>(kPipe); issued++) {
-            const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta, row_base,
-                                         s.h_pipe + (issued % kPipe) * s.h_pipe_block, true, kAuto, issued % kPipe);
-            if (rc != GSIM_OK) return rc;
+            for (auto& s : db->shards) {
+                if (s.nrows == 0) continue;
+                const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta,
+                                             db->row_base + static_cast<uint32_t>(s.first_row), s.h_pipe + (issued % kPipe) * s.h_pipe_block, true,
+                                             kAuto, issued % kPipe);
+                if (rc != GSIM_OK) return rc;
+            }
         }
-        void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
-        const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta, row_base,
-                                         out, done % kPipe);
-        if (rc != GSIM_OK) return rc;
-        const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
-        std::memcpy(hits + static_cast<size_t>(done) * kout, h + 1, sizeof(gsim_hit) * h->count);
-        counts[done] = h->count;
-        if (approx) approx[done] = h->approx;
+        uint64_t ap = 0;
+        merged.clear();
+        ends.clear();
+        for (auto& s : db->shards) {
+            if (s.nrows == 0) continue;
+            GSIM_HIP(set_device(s.device));
+            void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
+            const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta,
+                                             db->row_base + static_cast<uint32_t>(s.first_row), out, done % kPipe);
+            if (rc != GSIM_OK) return rc;
+            const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
+            const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
+            ap += h->approx;
+            if (nsh == 1) {
+                std::memcpy(hits + static_cast<size_t>(done) * kout, hh, sizeof(gsim_hit) * h->count);
+                counts[done] = h->count;
+            } else {
+                merged.insert(merged.end(), hh, hh + h->count);
+                ends.push_back(merged.size());
+            }
+        }
+        if (nsh > 1) counts[done] = merge_canonical_lists(merged, ends, k, hits + static_cast<size_t>(done) * kout); // fingerprintdb_cuda.cu:363-380
+        if (approx) approx[done] = ap;
     }
     return GSIM_OK;
 }
@@ -440,14 +486,14 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         return search_folded(db, queries, nq, kout, cutoff, hits, counts, approx);
     }
     const bool batched = !g_force_each && nq >= 4 && k <= static_cast<uint32_t>(gsim::kSelectCap) && k > 0 &&
-                         gsim::batch_supported(db->W) && env_int("GSIM_BATCH", 1) != 0;
+                         gsim::batch_supported(db->W) && db->knobs.batch != 0;
     if (batched)
         return db->comm ? search_batch_comm(db, queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx)
                         : search_batched(db, queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
-    static const int pipelined = env_int("GSIM_EACH_PIPELINE", 1);
-    if (g_force_each && pipelined && nsh == 1 && !db->comm && nq > 1 && k > 0 && db->shards[0].nrows > 0 && !db->shards[0].d_dbg &&
-        !std::getenv("GSIM_FUSED_DEBUG"))
-        return search_each_pipelined(db, db->shards[0], queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
+    const int pipelined = db->knobs.each_pipeline;
+    if (g_force_each && pipelined && nsh >= 1 && !db->comm && nq > 1 && k > 0 && db->nrows > 0 && !db->shards[0].d_dbg &&
+        !db->knobs.fused_debug)
+        return search_each_pipelined(db, queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
         rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout, &counts[q],

@@ -484,7 +484,7 @@ hipError_t launch_batch_t(const BatchArgs& a, const ScanGeometry& g, uint32_t sa
 hipError_t launch_batch_scan(const BatchArgs& a, const ScanGeometry& g, uint32_t sample_chunks, hipStream_t s,
                              bool sample_only)
 {
-    static const int rpl_env = std::getenv("GSIM_BATCH_RPL") ? std::atoi(std::getenv("GSIM_BATCH_RPL")) : 0;
+    const int rpl_env = static_cast<int>((a.opts >> 8) & 255u);
     const int rpl = rpl_env ? rpl_env : (a.W >= 64 ? 1 : (a.W >= 32 ? 2 : 4)); // rows per lane (scripts/bench_batch.py)
     switch (a.W) {
     case 4: return launch_batch_t<4, 4>(a, g, sample_chunks, s, sample_only);

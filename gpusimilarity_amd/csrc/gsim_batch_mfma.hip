@@ -40,7 +40,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "../../include/gpusim_hip.h"
 #include "gsim_device_common.h"
@@ -1081,9 +1080,8 @@ static uint32_t batch_mfma_sample_blocks(uint32_t W, uint64_t nrows)
 
 // Does the matrix-core sample pass apply to this table?  (Large tables only; batches with a cutoff
 // need it: it also estimates how many rows the cutoff keeps.)
-bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus)
+bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus, bool enabled)
 {
-    static const int enabled = std::getenv("GSIM_BATCH_MFMA_SAMPLE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_SAMPLE")) : 1;
     if (!enabled || k == 0 || nq > static_cast<uint32_t>(kMfmaQueries) || !batch_mfma_supported(W)) return false;
     const uint32_t rb = kMChunks / (W / 4);
     const u64 nblocks = (nrows + rb - 1) / rb;
@@ -1097,7 +1095,7 @@ bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t
 bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err)
 {
     *err = hipSuccess;
-    if (!batch_mfma_sample_applies(a.W, a.nrows, a.nq, a.k, num_cus)) return false;
+    if (!batch_mfma_sample_applies(a.W, a.nrows, a.nq, a.k, num_cus, (a.opts & 1u) != 0)) return false;
     const uint32_t rb = kMChunks / (a.W / 4);
     const u64 nblocks = (a.nrows + rb - 1) / rb;
     const uint32_t nsb = batch_mfma_sample_blocks(a.W, a.nrows);
@@ -1115,10 +1113,8 @@ bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hi
 }
 
 // Is there a band for the dense-cutoff variant (the same for every query of a batch up to 2048-bit rows)?
-bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff)
+bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff, bool enabled)
 {
-    static const int enabled = std::getenv("GSIM_BATCH_MFMA_DENSE") ? std::atoi(std::getenv("GSIM_BATCH_MFMA_DENSE")) : 1;
-    if (std::getenv("GSIM_BATCH_MFMA_DENSE_OFF_FOR_TEST")) return false; // (read at every call: a test compares the two routes in one process)
     return enabled && cutoff_band(metric == GSIM_METRIC_TVERSKY, alpha, beta, 2048u, cutoff, true).on;
 }
 
@@ -1162,7 +1158,7 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
     // above has returned at once, the dense variant -- one query tile per wave, the kept rows counted in registers --
     // runs the batch; any other batch it leaves alone.  Weights without a usable band (cutoff_band): the VALU pass,
     // re-enqueued by the host when it finds flag 8 without flag 16.
-    if (a.cutoff > 0.0f && batch_mfma_dense_applies(a.metric, a.alpha, a.beta, a.cutoff)) {
+    if (a.cutoff > 0.0f && batch_mfma_dense_applies(a.metric, a.alpha, a.beta, a.cutoff, (a.opts & 2u) != 0)) {
         if (a.W == 64) launch_variant<64, 1, 1, kMChunks, 2, true>(a, num_cus, s);
         else if (a.W == 32) launch_variant<32, 1, 2, kMChunks, 2, true>(a, num_cus, s);
         else if (a.W == 16) launch_variant<16, 1, 2, kMChunks, 2, true>(a, num_cus, s);

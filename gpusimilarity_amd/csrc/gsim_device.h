@@ -130,13 +130,42 @@ uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k);
 uint32_t fused_final_keys(uint32_t nwg, uint32_t k);
 
 // Geometry of the scan grid for a table (host side, no device work).
-ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll);
+// Every tuning knob of the library, read from the environment ONCE per handle -- by gsim_db_create -- and nowhere else
+// (INTEGRATION.md lists them with their meaning; nothing under a search entry point calls getenv).
+struct Knobs {
+    int scan_waves_per_cu = 4;       // GSIM_SCAN_WAVES_PER_CU
+    int scan_unroll = 8;             // GSIM_SCAN_UNROLL
+    int scan_ragged = 1;             // GSIM_SCAN_RAGGED         0: odd widths take the LDS-staged generic scan
+    int sample_chunks = 4;           // GSIM_SAMPLE_CHUNKS
+    int sample_shift = 15;           // GSIM_SAMPLE_SHIFT
+    int fused = 1;                   // GSIM_FUSED               0: every query through the four-kernel pipeline
+    long long fused_max_rows = -1;   // GSIM_FUSED_MAX_ROWS
+    int fused_debug = 0;             // GSIM_FUSED_DEBUG         in-kernel phase stamps
+    int fused_flags = 0;             // GSIM_FUSED_FLAGS
+    int fused_seed_narrow = 1;       // GSIM_FUSED_SEED_NARROW
+    int largek_one_block_max = 32768; // GSIM_LARGEK_ONE_BLOCK_MAX
+    int each_pipeline = 1;           // GSIM_EACH_PIPELINE       0: gsim_db_search_each waits for every query before the next
+    int batch = 1;                   // GSIM_BATCH               0: no shared table passes
+    int batch_waves_per_cu = 12;     // GSIM_BATCH_WAVES_PER_CU
+    int batch_seg_cap = 65536;       // GSIM_BATCH_SEG_CAP
+    int batch_seg_cap_init = 4096;   // GSIM_BATCH_SEG_CAP_INIT
+    int batch_sample_chunks = 8;     // GSIM_BATCH_SAMPLE_CHUNKS
+    int batch_rpl = 0;               // GSIM_BATCH_RPL           rows per lane of the VALU pass (0: by width)
+    int batch_mfma_min_q = 4;        // GSIM_BATCH_MFMA_MIN_Q    0: batches never take the matrix cores
+    int batch_mfma_sample = 1;       // GSIM_BATCH_MFMA_SAMPLE
+    int batch_mfma_dense = 1;        // GSIM_BATCH_MFMA_DENSE    0: dense cutoffs go to the VALU pass
+    int debug_batch = 0;             // GSIM_DEBUG_BATCH         print the batch flags (instrumented builds: phase counters)
+    int fold_full_on_device = 1;     // GSIM_FOLD_FULL_ON_DEVICE
+    int fold_rescore_host = 0;       // GSIM_FOLD_RESCORE=host
+};
+
+ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll, bool ragged = true);
 // ... of the single launch where it differs from the four-kernel pipeline's: rows of 3, 5, 7, 9, 11 or twice that many WORDS
 // (false: it does not -- use scan_geometry's)
-bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out);
+bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out, bool ragged = true);
 
 // Optional K0: starting threshold from a strided sample of chunks_per_wave chunks per scan wave.
-hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s);
+hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s, bool* launched = nullptr, int sample_shift = 15);
 hipError_t launch_scan(const ScanArgs& a, const ScanGeometry& g, hipStream_t s);
 
 // Compaction of candidates at or above the k-th best coarse bin into `finalists`.
@@ -223,6 +252,8 @@ struct BatchArgs {
     float cutoff;
     int metric;
     float alpha, beta;
+    uint32_t opts;           // host side only -- bit 0: matrix-core sample pass allowed, bit 1: dense-cutoff variant allowed,
+                             // bits 8-15: rows per lane of the VALU pass (0: by width) -- the handle's Knobs
 };
 
 bool batch_supported(uint32_t W);
@@ -238,9 +269,9 @@ hipError_t launch_row_popcounts(const void* rows, uint64_t nrows, uint32_t W, ui
 inline size_t row_popcount_bytes(uint64_t nrows) { return static_cast<size_t>((nrows + 7) / 8 + 1) * 16; }
 uint32_t batch_mfma_waves(int num_cus);
 hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s);
-bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff);
+bool batch_mfma_dense_applies(int metric, float alpha, float beta, float cutoff, bool enabled);
 bool launch_batch_mfma_sample(const BatchArgs& a, int num_cus, hipStream_t s, hipError_t* err);
-bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus);
+bool batch_mfma_sample_applies(uint32_t W, uint64_t nrows, uint32_t nq, uint32_t k, int num_cus, bool enabled);
 hipError_t launch_batch_mfma_pass(const BatchArgs& a, const ScanGeometry& g, int num_cus, uint32_t sample_chunks,
                                   uint32_t row_base, void* results, size_t block_bytes, hipStream_t s,
                                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);

@@ -1358,10 +1358,9 @@ hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedA
 
 // Rows of 3, 5, 7, 9, 11 or twice that many 32-bit words: the single launch streams them through registers at word granularity
 // (scan_rows_wragged); the four-kernel pipeline keeps its LDS-staged scan and its own geometry for them.
-bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out)
+bool fused_word_geometry(uint64_t nrows, uint32_t W, int num_cus, ScanGeometry* out, bool ragged)
 {
-    static const int enabled = std::getenv("GSIM_SCAN_RAGGED") ? std::atoi(std::getenv("GSIM_SCAN_RAGGED")) : 1;
-    if (!enabled || W % 4 == 0 || W == 0) return false;
+    if (!ragged || W % 4 == 0 || W == 0) return false;
     uint32_t odd = W;
     while (odd % 2 == 0) odd /= 2;
     if ((odd != 3 && odd != 5 && odd != 7 && odd != 9 && odd != 11) || W / odd > 2) return false; // (13, 15: no LDS left for their words)

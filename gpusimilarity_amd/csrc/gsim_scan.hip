@@ -770,9 +770,8 @@ static bool is_pow2(uint32_t x)
 
 // loads per chunk of scan_ragged_kernel for rows of L sixteen-byte units: the odd part of L when that is 3, 5, ... 15, a
 // chunk holds at least one whole row (64 P / L >= 1) and a row's bits fit the packed counts' 16-bit fields, else 0
-static uint32_t ragged_loads_of(uint32_t L)
+static uint32_t ragged_loads_of(uint32_t L, bool enabled)
 {
-    static const int enabled = std::getenv("GSIM_SCAN_RAGGED") ? std::atoi(std::getenv("GSIM_SCAN_RAGGED")) : 1;
     if (!enabled || L == 0) return 0;
     uint32_t odd = L;
     while (odd % 2 == 0) odd /= 2;
@@ -780,7 +779,7 @@ static uint32_t ragged_loads_of(uint32_t L)
     return (64u * odd) % L == 0 && 64u * odd / L >= 1 ? odd : 0;
 }
 
-ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll)
+ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_per_cu, int unroll, bool ragged)
 {
     ScanGeometry g{};
     const uint32_t lpr = (W % 4 == 0 && is_pow2(W / 4) && W / 4 <= 64) ? W / 4 : 0;
@@ -789,9 +788,9 @@ ScanGeometry scan_geometry(uint64_t nrows, uint32_t W, int num_cus, int waves_pe
         if (unroll != 4 && unroll != 8 && unroll != 16) unroll = 8;
         g.unroll = static_cast<uint32_t>(unroll);
         g.chunk_rows = g.unroll * (64 / lpr);
-    } else if (W % 4 == 0 && ragged_loads_of(W / 4) != 0) {
+    } else if (W % 4 == 0 && ragged_loads_of(W / 4, ragged) != 0) {
         // whole 16-byte units per row, odd part 3 ... 15: streamed through registers (scan_ragged_kernel)
-        g.ragged_loads = ragged_loads_of(W / 4);
+        g.ragged_loads = ragged_loads_of(W / 4, ragged);
         g.unroll = g.ragged_loads == 3 ? 3 : (g.ragged_loads == 5 ? 2 : 1); // sub-chunks per trip: 9, 10 or P loads in flight
         g.chunk_rows = g.unroll * (64u * g.ragged_loads / (W / 4));
     } else {
@@ -824,15 +823,16 @@ hipError_t launch_sample_t(const ScanArgs& a, uint32_t nsample, uint64_t stride,
 }
 
 // Starting threshold from a strided sample (large tables only).
-hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s)
+hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chunks_per_wave, hipStream_t s, bool* launched, int sample_shift)
 {
+    if (launched) *launched = false;
     if (a.k == 0 || chunks_per_wave == 0) return hipSuccess;
     if (g.lanes_per_row == 0 || g.lanes_per_row <= 2) {
         // sample_rows_kernel, chunks of 64 rows.  The k-th best of a sample of S rows out of N leaves ~k N / S rows above it:
         // S = k N / 2^15 keeps that at ~32 Ki rows (a few dozen per scan wave) -- at least 64 Ki rows, at most 1 Mi, never
         // more than 1/8 of the table (down to 16 Ki rows, tables of 131 k rows: sparse 128-bit tables of 0.5 M rows were
         // handed back one query in ten without a seed); under that the scan's own warm-up is cheaper.
-        static const int shift = std::getenv("GSIM_SAMPLE_SHIFT") ? std::atoi(std::getenv("GSIM_SAMPLE_SHIFT")) : 15;
+        const int shift = sample_shift > 0 && sample_shift < 40 ? sample_shift : 15;
         uint64_t want = (static_cast<uint64_t>(a.k) * a.nrows) >> shift;
         if (want < 65536) want = 65536;
         if (want > (1u << 20)) want = 1u << 20;
@@ -843,6 +843,7 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
         uint32_t nblocks = 64;
         if (nblocks > nsample / (kSampleRowsBlock / 64)) nblocks = nsample / (kSampleRowsBlock / 64);
         hipLaunchKernelGGL(sample_rows_kernel, dim3(nblocks), dim3(kSampleRowsBlock), 0, s, a, nsample, stride);
+        if (launched) *launched = true;
         return hipGetLastError();
     }
     const uint32_t chunk_rows = g.chunk_rows;
@@ -851,6 +852,7 @@ hipError_t launch_sample(const ScanArgs& a, const ScanGeometry& g, uint32_t chun
     const uint64_t fit = nfull / (8ull * g.nwaves);
     if (fit < chunks_per_wave) chunks_per_wave = static_cast<uint32_t>(fit);
     if (chunks_per_wave == 0) return hipSuccess;
+    if (launched) *launched = true;
     const uint64_t want = static_cast<uint64_t>(g.nwaves) * chunks_per_wave;
     const uint64_t stride = nfull / want;
     const uint32_t nsample = static_cast<uint32_t>(want);

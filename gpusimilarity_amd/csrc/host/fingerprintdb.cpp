@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <map>
+#include <mutex>
 #include <thread>
 
 #include "../../../include/gpusim_hip.h"
@@ -117,33 +119,76 @@ FingerprintDB::FingerprintDB(int fp_bitcount, unsigned long long fp_count, const
     std::fprintf(stderr, "Synthetic database of %d molecules (kind %d, %d bits)\n", m_total_count, kind, fp_bitcount);
 }
 
+namespace
+{
+// One communicator per distinct device list, shared by every database that spans those devices (RCCL keeps device and host
+// buffers per communicator, and ncclCommInitAll takes seconds on a full node; the server answers one request at a time, so
+// the databases never use it concurrently) -- ADVICE r04.
+struct SharedComm {
+    gsim_comm* comm = nullptr;
+    int users = 0;
+};
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, SharedComm> g_comms;
+
+gsim_comm* acquire_comm(const std::vector<int>& devs)
+{
+    std::lock_guard<std::mutex> guard(g_comm_mutex);
+    SharedComm& sc = g_comms[devs];
+    if (!sc.comm && gsim_comm_create(devs.data(), static_cast<int>(devs.size()), &sc.comm) != GSIM_OK) {
+        g_comms.erase(devs);
+        return nullptr;
+    }
+    sc.users++;
+    return sc.comm;
+}
+
+void release_comm(gsim_comm* comm)
+{
+    std::lock_guard<std::mutex> guard(g_comm_mutex);
+    for (auto it = g_comms.begin(); it != g_comms.end(); ++it) {
+        if (it->second.comm != comm) continue;
+        if (--it->second.users == 0) {
+            gsim_comm_destroy(comm);
+            g_comms.erase(it);
+        }
+        return;
+    }
+}
+} // namespace
+
 FingerprintDB::~FingerprintDB()
 {
     if (m_db && m_comm) gsim_db_set_comm(m_db, nullptr);
     if (m_db) gsim_db_destroy(m_db);
-    if (m_comm) gsim_comm_destroy(m_comm);
+    if (m_comm) release_comm(m_comm);
 }
 
 void FingerprintDB::copyToGPU(unsigned int fold_factor, int ndevices, bool full_on_device, bool rccl_merge)
 {
-    if (m_synthetic) { // generated in HBM, one device (the one get_next_gpu picks)
+    if (m_synthetic) { // generated in HBM: on the device get_next_gpu picks, or split over the first `ndevices` like an uploaded table
         (void) fold_factor;
-        (void) ndevices;
-        (void) rccl_merge;
-        const unsigned int dev = get_next_gpu(m_total_data_size);
-        if (gsim_db_generate(m_db, m_seed, m_kind, 0, static_cast<uint64_t>(m_total_count), static_cast<int>(dev)) != GSIM_OK)
-            throw_last("copyToGPU (synthetic)");
-        m_on_gpu = true;
-        return;
+        if (ndevices > 1) {
+            if (gsim_db_generate_sharded(m_db, m_seed, m_kind, 0, static_cast<uint64_t>(m_total_count), 0, ndevices) != GSIM_OK)
+                throw_last("copyToGPU (synthetic, sharded)");
+        } else {
+            const unsigned int dev = get_next_gpu(m_total_data_size);
+            if (gsim_db_generate(m_db, m_seed, m_kind, 0, static_cast<uint64_t>(m_total_count), static_cast<int>(dev)) != GSIM_OK)
+                throw_last("copyToGPU (synthetic)");
+        }
+        m_fold_factor = 1;
+    } else {
+        if (fold_factor > 1 && gsim_db_set_fold_factor(m_db, fold_factor) != GSIM_OK) throw_last("copyToGPU");
+        if (fold_factor > 1 && gsim_db_set_fold_full_on_device(m_db, full_on_device ? 1 : 0) != GSIM_OK) throw_last("copyToGPU");
+        if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
+        m_fold_factor = static_cast<int>(gsim_db_fold_factor(m_db));
     }
-    if (fold_factor > 1 && gsim_db_set_fold_factor(m_db, fold_factor) != GSIM_OK) throw_last("copyToGPU");
-    if (fold_factor > 1 && gsim_db_set_fold_full_on_device(m_db, full_on_device ? 1 : 0) != GSIM_OK) throw_last("copyToGPU");
-    if (gsim_db_finalize(m_db, ndevices == 1 ? -1 : 0, ndevices) != GSIM_OK) throw_last("copyToGPU");
-    m_fold_factor = static_cast<int>(gsim_db_fold_factor(m_db));
-    if (rccl_merge && m_fold_factor <= 1) {
+    // the collective only where there is something to gather: a single-shard table answers from its own block
+    if (rccl_merge && m_fold_factor <= 1 && gsim_db_shard_count(m_db) > 1) {
         std::vector<int> devs;
         for (int i = 0; i < gsim_db_shard_count(m_db); i++) devs.push_back(gsim_db_shard_device(m_db, i));
-        if (gsim_comm_create(devs.data(), static_cast<int>(devs.size()), &m_comm) != GSIM_OK) throw_last("copyToGPU (gsim_comm_create)");
+        m_comm = acquire_comm(devs);
+        if (!m_comm) throw_last("copyToGPU (gsim_comm_create)");
         if (gsim_db_set_comm(m_db, m_comm) != GSIM_OK) throw_last("copyToGPU (gsim_db_set_comm)");
     }
     m_on_gpu = true;

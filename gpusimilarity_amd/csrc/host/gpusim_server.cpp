@@ -286,10 +286,14 @@ void GPUSimServer::searchDatabases(const Fingerprint& query, int results_request
         char* id;           // the first hit's id (the database's string)
         std::string joined; // ... or, once a second hit has the same SMILES, the ids joined by ";:;"
     };
+    // (sized by what the lists can yield, not by the count a client wrote on the socket: INT_MAX would ask for ~150 GB)
+    size_t available = 0;
+    for (const List& l : lists) available += l.scores.size();
+    const size_t cap = std::min(static_cast<size_t>(results_requested), available);
     std::vector<Result> results;
-    results.reserve(static_cast<size_t>(results_requested));
+    results.reserve(cap);
     std::unordered_map<std::string_view, size_t> by_smiles;
-    by_smiles.reserve(static_cast<size_t>(results_requested) * 2);
+    by_smiles.reserve(cap * 2);
     while (!heap.empty()) {
         std::pop_heap(heap.begin(), heap.end(), later);
         List& l = lists[heap.back()];

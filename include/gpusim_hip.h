@@ -153,6 +153,12 @@ int gsim_fold_fingerprint(const uint32_t* fingerprint, uint32_t words, uint32_t 
  * Replaces add_rows+finalize for benchmark tables that exceed host memory. */
 int gsim_db_generate(gsim_db* db, uint64_t seed, int kind, uint64_t first_row,
                      uint64_t nrows, int device);
+/* The same table split over `ndevices` GPUs (device .. device + ndevices - 1) exactly as
+ * gsim_db_finalize(db, device, ndevices) splits uploaded rows -- contiguous, equal shares -- each
+ * shard generated on its own device: the one-process multi-GPU handle of fingerprintdb_cuda.cu:176-182
+ * for tables that exceed host memory (bench.py --in-process, gpusimserver synthetic:... --gpus N). */
+int gsim_db_generate_sharded(gsim_db* db, uint64_t seed, int kind, uint64_t first_row,
+                             uint64_t nrows, int device, int ndevices);
 /* Row `row` of that synthetic table, computed on the host by the generator's own code (benchmark
  * queries are rows of the table; no device, no handle needed). */
 int gsim_synth_row(uint64_t seed, int kind, uint64_t row, uint32_t fp_bits, uint32_t* out_words);
@@ -282,6 +288,9 @@ int gsim_comm_size(const gsim_comm* comm);
 /* Route gsim_db_search / gsim_db_search_each of this handle through the communicator (NULL: back to the host
  * merge).  The communicator's devices must be the shards' devices, in order.  Not for folded tables. */
 int gsim_db_set_comm(gsim_db* db, gsim_comm* comm);
+/* Which shard's device merges the gathered blocks and answers the host (default 0; after the all-gather every
+ * device holds all blocks, so any of them can). */
+int gsim_db_set_comm_root(gsim_db* db, int shard);
 
 /* ---- instrumentation ------------------------------------------------------ */
 int gsim_db_enable_timing(gsim_db* db, int enable); /* resets the accumulators */

@@ -34,9 +34,8 @@ for _ in range(REPS):
     t.search(qs, K, CUTOFF, **kw)
 el = (time.perf_counter() - t0) / REPS
 # single-query path for comparison (a few queries)
-os.environ["GSIM_BATCH"] = "0"
 t1 = time.perf_counter()
-t.search(qs[:4], K, 0.0, **kw)
+t.search_each_into(np.ascontiguousarray(qs[:4]), K, t.make_search_buffers(4, K), 0.0, **kw)
 single = (time.perf_counter() - t1) / 4
 pairs = Q * N / el
 mfma = int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "4")) > 0 and Q >= int(os.environ.get("GSIM_BATCH_MFMA_MIN_Q", "4")) and W in (32, 64)

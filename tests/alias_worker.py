@@ -62,6 +62,19 @@ def main():
             if route == "comm":
                 tm = t.timing()
                 assert tm["collectives"] in (6 + 70 + 1, 6 + 70 + 70) and tm["gather_ms_sum"] > 0 and tm["merge_ms_sum"] > 0, tm
+                # the gather fills EVERY shard's buffer (like the real all-gather): merge on each of the other devices in
+                # turn -- single query and batch -- and expect the same answer
+                for root in range(1, t.shard_count()):
+                    t.set_comm_root(root)
+                    hits, approx = t.search(qs[1], 1000, 0.0)
+                    want, wap = O.search(qs[1], db, 1000, 0.0, nthreads=8)
+                    same(hits[0], approx[0], want, wap, ("comm root", root, kind, n, W, ndevices))
+                    bufs = t.make_search_buffers(len(qs), 50)
+                    t.search_into(np.ascontiguousarray(qs), 50, bufs, 0.0)
+                    for i in (0, 33, 69):
+                        want, wap = O.search(qs[i], db, 50, 0.0, nthreads=8)
+                        same(bufs[0][i, :bufs[1][i]], bufs[2][i], want, wap, ("comm root batch", root, kind, n, W, ndevices, i))
+                t.set_comm_root(0)
                 t.set_comm(None)  # back to the host merge: same answer
                 hits, approx = t.search(qs[0], 1000, 0.0)
                 want, wap = O.search(qs[0], db, 1000, 0.0, nthreads=8)
@@ -70,6 +83,20 @@ def main():
                 comm.close()
                 continue
             t.close()
+    # a synthetic table generated shard by shard on its devices == the same table generated on one device
+    for kind, n, W in ((0, 1_000_003, 32), (2, 500_001, 64)):
+        one = capi.Table(W * 32).generate(0x5EED0003, kind, 7, n, 0)
+        many = capi.Table(W * 32).generate(0x5EED0003, kind, 7, n, 0, ndevices=ndev)
+        assert many.shard_count() == ndev and one.shard_count() == 1
+        qs = np.stack([O.synth_rows(0x5EED0003, kind, 7 + O.query_row(i, n), 1, W)[0] for i in range(20)])
+        for route in ("each", "batch"):
+            b1, b2 = one.make_search_buffers(len(qs), 200), many.make_search_buffers(len(qs), 200)
+            (one.search_each_into if route == "each" else one.search_into)(np.ascontiguousarray(qs), 200, b1, 0.0)
+            (many.search_each_into if route == "each" else many.search_into)(np.ascontiguousarray(qs), 200, b2, 0.0)
+            assert (b1[1] == b2[1]).all() and (b1[2] == b2[2]).all(), route
+            assert b1[0].tobytes() == b2[0].tobytes(), route
+        one.close()
+        many.close()
     # a folded table of three storages: one shard per add_rows slice, placed round robin (:184-194)
     n, W = 90_000, 32
     db = O.synth_rows(0xF01D, 2, 0, n, W)

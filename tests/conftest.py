@@ -9,6 +9,20 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# The library built with -DGSIM_TEST_HOOKS (GSIM_TEST_ALIAS_DEVICES, GSIM_TEST_TORN_EVERY): the shipped libgsim_hip.so has no
+# test hooks, so the tests that need one run a child process against this build -- Python children through GSIM_LIB,
+# gpusimserver through LD_LIBRARY_PATH (same soname, found before the binary's RUNPATH).
+HOOKS_DIR = os.path.join(ROOT, "gpusimilarity_amd", "testhooks")
+HOOKS_LIB = os.path.join(HOOKS_DIR, "libgsim_hip.so")
+
+
+def hooks_env(**extra):
+    """Environment of a child process that is to load the test-hooks build of the library."""
+    env = dict(os.environ, GSIM_LIB=HOOKS_LIB, **extra)
+    env["LD_LIBRARY_PATH"] = HOOKS_DIR + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+    return env
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

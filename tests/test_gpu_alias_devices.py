@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_in_process_multi_device_shards_on_aliased_devices():
-    env = dict(os.environ, GSIM_TEST_ALIAS_DEVICES="4")
+    from conftest import hooks_env
+    env = hooks_env(GSIM_TEST_ALIAS_DEVICES="4")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "alias_worker.py")], env=env, capture_output=True,
                          timeout=1500)
     assert out.returncode == 0, (out.stdout.decode("utf-8", "replace")[-2000:] + out.stderr.decode("utf-8", "replace")[-4000:])
@@ -66,7 +67,10 @@ def test_server_shards_over_aliased_devices(gpus, merge, monkeypatch, tmp_path):
     the host or through the C ABI's collective (aliased devices: its loop-back gather; one device: a real world-1 RCCL
     communicator) -- replies byte-identical to the golden frames."""
     import test_host_cpp as H
-    monkeypatch.setenv("GSIM_TEST_ALIAS_DEVICES", "4")
+    from conftest import hooks_env
+    for name, value in hooks_env(GSIM_TEST_ALIAS_DEVICES="4").items():  # (the server inherits the environment)
+        if name in ("GSIM_TEST_ALIAS_DEVICES", "LD_LIBRARY_PATH", "GSIM_LIB"):
+            monkeypatch.setenv(name, value)
     import shutil
     pair = (str(tmp_path / "small.fsim"), str(tmp_path / "small_copy.fsim"))
     for f in pair:

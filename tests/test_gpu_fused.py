@@ -254,6 +254,7 @@ assert tm["blocks_torn"] == int(os.environ.get("WANT_TORN", "0")), tm
 t.close()
 """ % (ROOT, os.path.join(ROOT, "tests"))
     for hook, want_torn in (("5", 16), ("0", 0)):
-        env = dict(os.environ, GSIM_TEST_TORN_EVERY=hook, WANT_TORN=str(want_torn))
+        from conftest import hooks_env
+        env = hooks_env(GSIM_TEST_TORN_EVERY=hook, WANT_TORN=str(want_torn))
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
         assert out.returncode == 0, out.stdout.decode()[-1500:] + out.stderr.decode()[-3000:]

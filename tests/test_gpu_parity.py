@@ -1042,12 +1042,18 @@ def test_matrix_core_pass_with_cutoff(W, n):
             assert int(approx[i]) == int(ap1[0]), "W=%d cutoff=%g q=%d approx %d vs %d" % (W, cutoff, i, approx[i], ap1[0])
             assert_hits_equal(hits[i], one[0], "W=%d cutoff=%g q=%d" % (W, cutoff, i))
         results.append((hits, approx))
-    # the same dense cutoff through the VALU pass (the route of weights without a band)
-    os.environ["GSIM_BATCH_MFMA_DENSE_OFF_FOR_TEST"] = "1"
+    # the same dense cutoff through the VALU pass (the route of weights without a band): a second handle on the same rows,
+    # created with GSIM_BATCH_MFMA_DENSE=0 in the environment (the knobs are read per handle, by gsim_db_create)
+    os.environ["GSIM_BATCH_MFMA_DENSE"] = "0"
     try:
-        hits_v, approx_v = t.search(qs, 100, np.float32(0.02))
+        tv_off = capi.Table(W * 32)
     finally:
-        del os.environ["GSIM_BATCH_MFMA_DENSE_OFF_FOR_TEST"]
+        del os.environ["GSIM_BATCH_MFMA_DENSE"]
+    tv_off.generate(0x5EED0001, capi.SYNTH_SPARSE, 0, n, 0)
+    before = tv_off.timing()["batches_dense_cutoff"]
+    hits_v, approx_v = tv_off.search(qs, 100, np.float32(0.02))
+    assert tv_off.timing()["batches_dense_cutoff"] == before, "the dense variant ran although it was switched off"
+    tv_off.close()
     assert [int(x) for x in approx_v] == [int(x) for x in results[2][1]]
     for i in range(len(qs)):
         assert_hits_equal(hits_v[i], results[2][0][i], "VALU route q=%d" % i)
