@@ -23,6 +23,24 @@ def hooks_env(**extra):
     return env
 
 
+# Which parity level did the full-size tests reach on THIS box?  The tests record it, the session prints it after the
+# summary line -- the driver's record keeps the tail of the output, and "249 passed" alone does not say whether the
+# 1 B-row table was compared with the oracle over all its rows or only through its size-independent properties.
+PARITY_LEVELS = []
+
+
+def record_parity(test, level, detail=""):
+    PARITY_LEVELS.append((test, level, detail))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_LEVELS:
+        return
+    terminalreporter.write_line("parity level reached by the full-size tests on this box:")
+    for test, level, detail in PARITY_LEVELS:
+        terminalreporter.write_line("  %-58s %-18s %s" % (test, level, detail))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -498,7 +498,9 @@ def test_baseline_sizes_whole_table_against_oracle(nrows, kind):
     size-independent properties on top: idempotence, prefix, pipelined == one at a time."""
     W, k, seed = 32, 1000, 0x5EED0001
     if capi.device_free_bytes(0) < nrows * 128 * 1.3:
-        pytest.skip("not enough free HBM")
+        pytest.skip("not enough free HBM: %d rows x 1024-bit, kind %d NOT compared with the oracle on this box" % (nrows, kind))
+    from conftest import record_parity
+    record_parity("configs[%d] %d M x 1024-bit, kind %d" % (1 if nrows == 1_000_000 else 2, nrows // 1_000_000, kind), "oracle_all_rows")
     nt = os.cpu_count() or 1
     host = O.synth_rows_mt(seed, kind, 0, nrows, W, nt)  # 12.8 GB at 100 M rows
     t = capi.Table(1024)
