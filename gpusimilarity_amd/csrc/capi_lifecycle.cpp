@@ -34,7 +34,6 @@ gsim::Knobs read_knobs()
 {
     gsim::Knobs k;
     k.scan_waves_per_cu = env_value("GSIM_SCAN_WAVES_PER_CU", k.scan_waves_per_cu);
-    k.scan_unroll = env_value("GSIM_SCAN_UNROLL", k.scan_unroll);
     k.scan_ragged = env_value("GSIM_SCAN_RAGGED", k.scan_ragged);
     k.sample_chunks = env_value("GSIM_SAMPLE_CHUNKS", k.sample_chunks);
     k.sample_shift = env_value("GSIM_SAMPLE_SHIFT", k.sample_shift);
@@ -156,7 +155,7 @@ int setup_shard(gsim_db* db, Shard& s)
     s.stream = s.own_stream;
     const gsim::Knobs& kn = db->knobs;
     if (s.W == 0) s.W = db->W;
-    s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, kn.scan_waves_per_cu, kn.scan_unroll, kn.scan_ragged != 0);
+    s.geo = gsim::scan_geometry(s.nrows, s.W, s.num_cus, kn.scan_waves_per_cu, 8, kn.scan_ragged != 0);
     s.sample_chunks = kn.sample_chunks;
     s.fgeo = s.geo;
     (void) gsim::fused_word_geometry(s.nrows, s.W, s.num_cus, &s.fgeo, kn.scan_ragged != 0); // (rows of 3 ... 11 or twice that many words: the single launch's own)

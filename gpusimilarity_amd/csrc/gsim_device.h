@@ -134,7 +134,6 @@ uint32_t fused_final_keys(uint32_t nwg, uint32_t k);
 // (INTEGRATION.md lists them with their meaning; nothing under a search entry point calls getenv).
 struct Knobs {
     int scan_waves_per_cu = 4;       // GSIM_SCAN_WAVES_PER_CU
-    int scan_unroll = 8;             // GSIM_SCAN_UNROLL
     int scan_ragged = 1;             // GSIM_SCAN_RAGGED         0: odd widths take the LDS-staged generic scan
     int sample_chunks = 4;           // GSIM_SAMPLE_CHUNKS
     int sample_shift = 15;           // GSIM_SAMPLE_SHIFT

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Run on the GPU box after collect_profiles.sh / sweeps.sh: phase profiles, soak, the two-rank test mode, the smaller reports.
 set -uo pipefail
-OUT=gpurun_out/rest_r04
+OUT=gpurun_out/rest_r05
 rm -rf "$OUT"; mkdir -p "$OUT"
 GSIM_FUSED_DEBUG=1 python scripts/time_single.py 1000000 2>&1 | tail -30 > $OUT/fused_phases_1M.txt
 GSIM_FUSED_DEBUG=1 TS_REPS=20 python scripts/time_single.py 100000000 2>&1 | tail -30 > $OUT/fused_phases_100M.txt
