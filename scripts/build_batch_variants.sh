@@ -9,7 +9,7 @@ REV=${1:-HEAD}
 shift || true
 mkdir -p build_t ../../scripts/build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I. "
-OBJS=$(ls build/*.o | grep -v gsim_batch_mfma.o)
+OBJS=$(ls build/*.o | grep -v "gsim_batch_mfma.o\|_hooks.o")
 LINK="-L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib"
 /opt/rocm/bin/hipcc $FLAGS -DGSIM_MF_TIMING=1 -c -o build_t/gsim_batch_mfma_timing.o gsim_batch_mfma.hip &
 git show $REV:gpusimilarity_amd/csrc/gsim_batch_mfma.hip > build_t/gsim_batch_mfma_ref.hip
