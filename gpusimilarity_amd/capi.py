@@ -33,7 +33,8 @@ class GsimTiming(C.Structure):
                 ("candidates_sum", C.c_uint64), ("finalists_sum", C.c_uint64), ("handed_back", C.c_uint64),
                 ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64), ("batches_dense_cutoff", C.c_uint64),
                 ("collectives", C.c_uint64), ("gather_ms_sum", C.c_double), ("merge_ms_sum", C.c_double),
-                ("blocks_rechecked", C.c_uint64), ("blocks_torn", C.c_uint64), ("batches_regrown", C.c_uint64)]
+                ("blocks_rechecked", C.c_uint64), ("blocks_torn", C.c_uint64), ("batches_regrown", C.c_uint64),
+                ("large_k_single_scan", C.c_uint64)]
 
 
 class GsimError(RuntimeError):

@@ -175,6 +175,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
     db->acc.blocks_rechecked = db->blocks_rechecked;
     db->acc.blocks_torn = db->blocks_torn;
     db->acc.batches_regrown = db->batch_regrown;
+    db->acc.large_k_single_scan = db->large_k_published.load();
     *out = db->acc;
     return GSIM_OK;
 }

@@ -110,6 +110,7 @@ struct Shard {
     uint32_t epoch = 0;
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
     uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
+    bool slot_publish[kPipe] = {};  // the synchronous enqueue of the slot was a large-k query scanned by the single launch (header flag 2: run it again)
     bool slot_rerun[kPipe] = {};    // ... but behind a launch that left the per-query state dirty: not to be trusted, run again
     char* h_pipe = nullptr;          // kPipe pinned result blocks (gsim_db_search_each)
     size_t h_pipe_block = 0;
@@ -196,6 +197,7 @@ struct gsim_db {
     gsim_timing acc{};
     unsigned long long dense_batches = 0; // multi-query passes whose dense cutoff the matrix-core pass counted itself
     unsigned long long batch_regrown = 0; // batches run again with larger candidate segments
+    std::atomic<unsigned long long> large_k_published{0}; // shard queries with k > kSelectCap scanned by the single launch
     unsigned long long blocks_checked = 0, blocks_rechecked = 0, blocks_torn = 0; // single launch, synchronous callers: result blocks whose checksum
                                                                // did not match at first sight / never did (re-run)
     gsim_comm* comm = nullptr; // gsim_db_set_comm: shard results meet through an RCCL all-gather + merge_kernel instead of on the host

@@ -42,6 +42,7 @@ gsim::Knobs read_knobs()
     k.fused_debug = env_value("GSIM_FUSED_DEBUG", k.fused_debug);
     k.fused_flags = env_value("GSIM_FUSED_FLAGS", k.fused_flags);
     k.fused_seed_narrow = env_value("GSIM_FUSED_SEED_NARROW", k.fused_seed_narrow);
+    k.fused_publish = env_value("GSIM_FUSED_PUBLISH", k.fused_publish);
     k.largek_one_block_max = env_value("GSIM_LARGEK_ONE_BLOCK_MAX", k.largek_one_block_max);
     k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
     k.batch = env_value("GSIM_BATCH", k.batch);

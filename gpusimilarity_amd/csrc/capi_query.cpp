@@ -57,6 +57,21 @@ bool fused_applies(const gsim_db* db, const Shard& s, uint32_t k)
     return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
 }
 
+// k in (kSelectCap, kFusedPublishMaxK]: the single launch scans and publishes (kFusedPublishOnly), the large-k kernels rank
+// what it published.  Rows of 512 bits and more only: the narrow widths want the sampled seed (enqueue_query_impl), and their
+// scan is bound by the per-row arithmetic either way.
+bool fused_publish_applies(const gsim_db* db, const Shard& s, uint32_t k)
+{
+    if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(gsim::kSelectCap) || k > gsim::kFusedPublishMaxK || s.nrows == 0 ||
+        !gsim::fused_supported(s.fgeo))
+        return false;
+    if (s.fgeo.lanes_per_row < 4 || s.fgeo.ragged_words || s.fgeo.ragged_loads) return false;
+    if (gsim::fused_summary_keys(s.fgeo.nwaves, k, 64) == 0) return false; // (no thresholds: every row would be published)
+    if (s.nrows < 64ull * k) return false; // (a short table: the thresholds come late and most of it is published)
+    const long long max_rows = db->knobs.fused_max_rows;
+    return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
+}
+
 namespace
 {
 // Enqueue one query on one shard; the result block ends up at `out`, which is
@@ -86,6 +101,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         s.fused_skip--;
         fused = false;
     }
+    const bool publish = mode == kAuto && !fused && fused_publish_applies(db, s, k);
     const bool classic = !fused || !caller_syncs;
     if (classic) {
         const int rc = ensure_classic_scratch(s);
@@ -133,7 +149,10 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         }
         ev = &s.ev[3 * s.ev_used];
     }
-    if (caller_syncs) s.slot_fused[pipe_slot] = false;
+    if (caller_syncs) {
+        s.slot_fused[pipe_slot] = false;
+        s.slot_publish[pipe_slot] = false;
+    }
     if (fused) {
         gsim::FusedArgs f{};
         f.pub = s.d_pub;
@@ -185,16 +204,40 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         }
         a.gate = &s.d_state->redo; // the classic kernels behind it run only if it handed the query back
     }
-    if (s.nrows > 0 && s.sample_chunks > 0)
+    if (publish) {
+        // large k, first half: the single launch's scan with its in-loop thresholds (one read of the table at 0.88 of the HBM
+        // roofline instead of the classic scan's 0.82 + compaction), told to stop after publishing; the hand-off kernel makes
+        // its lists the finalists.  The classic kernels follow, gated as above: they run only for a query handed back.
+        gsim::FusedArgs f{};
+        f.pub = s.d_pub;
+        f.hdr = s.d_hdr;
+        f.arrive = s.d_summ + 4096 + kTicketWords;
+        f.summ = s.d_summ;
+        f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k, 64);
+        f.final_keys = 0; // (no end-of-scan reports: nobody elects a final threshold)
+        f.tickets = s.d_summ + 4096;
+        f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
+        f.xflags = (static_cast<uint32_t>(db->knobs.fused_flags) & ~4u) | gsim::kFusedPublishOnly;
+        if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+        GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
+        GSIM_HIP(gsim::launch_fused_handoff(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.stream));
+        a.gate = &s.d_state->redo;
+        db->large_k_published++;
+        if (caller_syncs) s.slot_publish[pipe_slot] = true;
+    }
+    // (a synchronous caller of the publishing launch learns of a hand-back from the block's header and runs the query again --
+    // finish_query_sync -- instead of paying for three gated launches, ~4.5 us each, behind every query)
+    const bool scan_classic = !(publish && caller_syncs);
+    if (scan_classic && s.nrows > 0 && s.sample_chunks > 0)
         GSIM_HIP(gsim::launch_sample(a, s.geo, static_cast<uint32_t>(s.sample_chunks), s.stream, nullptr, db->knobs.sample_shift));
-    if (ev && !fused) GSIM_HIP(hipEventRecord(ev[0], s.stream));
-    if (s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
+    if (ev && !fused && !publish) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+    if (scan_classic && s.nrows > 0) GSIM_HIP(gsim::launch_scan(a, s.geo, s.stream));
     if (!caller_syncs) { // the ring slot is free once the scan has run
         GSIM_HIP(hipEventRecord(s.q_ev[slot], s.stream));
         s.q_pending[slot] = true;
     }
     if (ev && !fused) GSIM_HIP(hipEventRecord(ev[1], s.stream));
-    if (s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
+    if (scan_classic && s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
     if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
         GSIM_HIP(gsim::launch_select(a, s.d_final, s.d_final_cb, s.final_cap, row_base, out, s.stream));
     } else {
@@ -222,7 +265,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         const bool one_block = *static_cast<volatile uint32_t*>(hint) <= static_cast<uint32_t>(one_block_max);
         GSIM_HIP(gsim::launch_largek_select(a, s.d_final, s.final_cap, s.d_lk, s.d_large, np2, hint, one_block, s.stream));
         // (tiles sorted, then positions by counting + the hits + the header + the state's reset in one launch)
-        GSIM_HIP(gsim::launch_largek_sort_emit(a, s.d_large, np2, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
+        GSIM_HIP(gsim::launch_largek_sort_emit(a, s.d_large, np2, s.d_lk, row_base, s.nrows, 1u | (publish && caller_syncs ? 0x80000000u : 0u), out, s.stream));
     }
     if (ev) {
         GSIM_HIP(hipEventRecord(ev[2], s.stream));
@@ -260,7 +303,16 @@ int wait_stream(hipStream_t st)
 int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
                       float beta, uint32_t row_base, void* out, uint32_t pipe_slot)
 {
-    if (!s.slot_fused[pipe_slot]) return wait_stream(s.stream);
+    if (!s.slot_fused[pipe_slot]) {
+        int rc = wait_stream(s.stream);
+        if (rc == GSIM_OK && s.slot_publish[pipe_slot] && (static_cast<const gsim_result_header*>(out)->flags & 2u)) {
+            // k above 8192, scanned by the single launch, handed back (heavy ties): the emission cleared the per-query state
+            rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
+            if (rc == GSIM_OK) rc = wait_stream(s.stream);
+        }
+        s.slot_publish[pipe_slot] = false;
+        return rc;
+    }
     s.slot_fused[pipe_slot] = false;
     if (s.slot_rerun[pipe_slot]) {
         // enqueued behind a single launch that ended without closing its query (below): this one ran on per-query state

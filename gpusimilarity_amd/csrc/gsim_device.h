@@ -97,6 +97,8 @@ struct ScanArgs {
 
 // ---- single-launch path: scan + publish + select in ONE kernel --------------------------------
 constexpr uint32_t kFusedMaxK = 8192;       // largest k the single-launch path serves
+constexpr uint32_t kFusedPublishMaxK = 32768; // ... and the largest it scans and publishes for (k > kSelectCap: the large-k kernels rank what it published)
+constexpr uint32_t kFusedPublishOnly = 2048u; // FusedArgs::xflags: scan + publish, no selection (launch_fused_handoff follows)
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
 constexpr int kFusedSelectors = 256;        // workgroups of the grid: every one of them ranks its share of the finalists
 constexpr uint32_t kFusedRegion = 4 * kFusedWaveCap; // published entries (16 B each) of one workgroup: its fixed region of the list
@@ -125,8 +127,12 @@ inline size_t fused_pub_bytes(uint32_t nwg) { return static_cast<size_t>(nwg) * 
 inline size_t fused_hdr_bytes(uint32_t nwg) { return static_cast<size_t>(nwg) * kFusedHeaderBytes; }
 
 hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s);
+// Behind a kFusedPublishOnly launch: the published rows of the coarse bins at or above the k-th best's become the finalists of
+// the large-k kernels (their keys into `finalists`, QueryState::nfinal set; ::ghist was filled by the launch) -- unless the
+// launch handed the query back (QueryState::redo != 0).
+hipError_t launch_fused_handoff(const ScanArgs& a, const FusedArgs& f, uint32_t nwg, unsigned long long* finalists, uint32_t cap, hipStream_t s);
 bool fused_supported(const ScanGeometry& g);
-uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k);
+uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k, uint32_t max_m = 16);
 uint32_t fused_final_keys(uint32_t nwg, uint32_t k);
 
 // Geometry of the scan grid for a table (host side, no device work).
@@ -142,6 +148,7 @@ struct Knobs {
     int fused_debug = 0;             // GSIM_FUSED_DEBUG         in-kernel phase stamps
     int fused_flags = 0;             // GSIM_FUSED_FLAGS
     int fused_seed_narrow = 1;       // GSIM_FUSED_SEED_NARROW
+    int fused_publish = 1;           // GSIM_FUSED_PUBLISH       0: k above 8192 scans with the four-kernel pipeline's scan
     int largek_one_block_max = 32768; // GSIM_LARGEK_ONE_BLOCK_MAX
     int each_pipeline = 1;           // GSIM_EACH_PIPELINE       0: gsim_db_search_each waits for every query before the next
     int batch = 1;                   // GSIM_BATCH               0: no shared table passes

@@ -826,6 +826,18 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                                                    blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
         }
     }
+    if (fa.xflags & kFusedPublishOnly) {
+        // ... and, when the large-k kernels rank the lists, what the four-kernel pipeline's scan leaves for them: the published
+        // rows counted per coarse bin in QueryState::ghist (fused_handoff_kernel and largek_one_block_kernel start from it)
+        static_assert(kFusedBins >= static_cast<uint32_t>(kScanBins), "the publish phase's bucket counters double as the coarse histogram");
+        __syncthreads(); // (the bucket order is done with the counters)
+        for (int i = tid; i < kScanBins; i += kScanBlock) sh.hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = lane; i < mine_n; i += 64) atomicAdd(&sh.hist[coarse_bin(key_score(static_cast<uint32_t>(f.skey[i] >> 32)))], 1u);
+        __syncthreads();
+        for (int i = tid; i < kScanBins; i += kScanBlock)
+            if (sh.hist[i]) atomicAdd(&st->ghist[i], sh.hist[i]);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries (and header parts) are out
     __syncthreads();
     if (tid == 0) {
@@ -836,13 +848,54 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         // pollers per line instead of 256 on every line (a flat count polled by all cost 7-10 us after the last arrival).
         const uint32_t x = blockIdx.x % 8u;
         const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
-        if (atomicAdd(&fa.arrive[x * 32u], 1u) == group_size - 1u && atomicAdd(&fa.arrive[8u * 32u], 1u) == ngroups - 1u) {
+        const bool publish_only = (fa.xflags & kFusedPublishOnly) != 0;
+        if (publish_only) atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (before the arrival: the next launch sums it up)
+        const bool last = atomicAdd(&fa.arrive[x * 32u], 1u) == group_size - 1u && atomicAdd(&fa.arrive[8u * 32u], 1u) == ngroups - 1u;
+        if (last && !publish_only) {
             for (uint32_t gq = 0; gq < 8u; gq++)
                 __hip_atomic_store(&fa.arrive[(9u + gq) * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (statistics: nobody waits for it)
+        if (!publish_only) atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (statistics: nobody waits for it)
+        sh.ticket = last ? 1u : 0u;
     }
     GSIM_STAMP(3);
+    // The exchange state of the single launch (checkpoint tickets, arrival words, in-loop summaries): zero again for the
+    // next query.  One workgroup does it when no other touches it any more.
+    auto rezero_exchange = [&]() __attribute__((always_inline)) {
+        if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
+        if (tid < static_cast<int>(kFusedArriveWords)) { // (the closing tickets are 64-bit)
+            fa.arrive[tid * 32] = 0;
+            fa.arrive[tid * 32 + 1] = 0;
+        }
+        uint4* sm = reinterpret_cast<uint4*>(fa.summ); // (16-byte stores)
+        const uint32_t n16 = (g.nwaves + 3) / 4;
+        for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0};
+    };
+    if (fa.xflags & kFusedPublishOnly) {
+        // k above kFusedMaxK: the scan and its thresholds are this launch's, the ranking is the large-k kernels' (they are sized by
+        // k, the selectors' LDS is not).  Nobody waits for anybody: the LAST workgroup to arrive -- every other one has
+        // published, its service waves are gone -- tidies up; launch_fused_handoff, next on the stream, reads the lists.
+        __syncthreads();
+        if (!sh.ticket) return;
+        if (tid == 0) {
+            const uint32_t why = agent_load(&st->redo); // (set before its workgroup's arrival)
+            if (why) { // handed back: the gated classic kernels behind this launch start from a clean state
+                st->redo_sum += 1u;
+                st->redo_why |= why;
+                __hip_atomic_store(&st->kept, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st->ncand_sum += __hip_atomic_load(&st->ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st->ncand, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&st->gtau, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&st->elected, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh.ok = why ? 0u : 1u;
+        }
+        rezero_exchange();
+        __syncthreads();
+        if (!sh.ok) // handed back: the histogram the other workgroups added to is the classic scan's to fill
+            for (int i = tid; i < kScanBins; i += kScanBlock) st->ghist[i] = 0;
+        return;
+    }
 
     // ---- 4. select: every workgroup of the grid (fused_supported: at most kFusedSelectors) ------
     const uint32_t nsel = nwg, r = blockIdx.x;
@@ -1328,21 +1381,69 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         // launch, possibly already enqueued, starts clean
         if (fa.done_flag) __hip_atomic_store(&st->redo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid < kFusedCheckpoints * 9) fa.tickets[tid * 32] = 0;
-    if (tid < static_cast<int>(kFusedArriveWords)) { // (the closing tickets are 64-bit)
-        fa.arrive[tid * 32] = 0;
-        fa.arrive[tid * 32 + 1] = 0;
-    }
-    { // the in-loop summaries: zero again for the next query (16-byte stores)
-        uint4* sm = reinterpret_cast<uint4*>(fa.summ);
-        const uint32_t n16 = (g.nwaves + 3) / 4;
-        for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0};
-    }
+    rezero_exchange();
     if (dbg && tid == 0) fa.dbg[static_cast<u64>(gridDim.x) * 24] = wall_clock64(); // the very end
 #undef GSIM_STAMP
 }
 
+// Behind a kFusedPublishOnly launch (k above kFusedMaxK): what the workgroups published becomes the finalist list of the
+// large-k kernels -- what the four-kernel pipeline's scan and compact_kernel leave behind.  The lists hold the rows at or above
+// the last IN-LOOP threshold -- taken at 3/4 of the scan from reports in the middle of their range: about 2.8 k rows -- and the
+// launch has counted them per coarse bin (QueryState::ghist): this kernel keeps the rows of the bins at or above B*, the bin
+// of the k-th best (about k + one bin's rows: what the one-workgroup large-k route is fast for; it starts from the same
+// histogram).  Handed back (QueryState::redo): nothing is kept -- the gated classic kernels behind this one produce the
+// finalists, or (synchronous callers) the emission reports it and the host runs the query again.
+__global__ __launch_bounds__(256) void fused_handoff_kernel(ScanArgs a, FusedArgs fa, u64* finalists, uint32_t cap)
+{
+    __shared__ uint32_t s_bstar, s_cnt, s_base, s_cur;
+    QueryState* st = a.state;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x == 0 && a.query_dev != a.query) // the device copy of the query the emission reads (the classic scan's job otherwise)
+        for (uint32_t i = tid; i < a.W; i += 256) a.query_dev[i] = a.query[i];
+    if (agent_load(&st->redo) != 0) return; // (set before the launch ended: every workgroup reads the same)
+    if (tid < 64) {
+        uint32_t bstar, cnt;
+        find_threshold(st->ghist, a.k, lane, bstar, cnt); // (fewer than k rows published: bin 0, every row is kept)
+        if (tid == 0) {
+            s_bstar = bstar;
+            s_cnt = 0;
+            s_cur = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t bstar = s_bstar;
+    const uint32_t n = static_cast<const uint32_t*>(fa.hdr)[blockIdx.x * (kFusedHeaderBytes / 4)] & 0x7FFFFFFFu;
+    const u32x4* reg = static_cast<const u32x4*>(fa.pub) + static_cast<size_t>(blockIdx.x) * kFusedRegion;
+    const uint32_t n256 = (n + 255u) & ~255u;
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < n256; i += 256) mine += (i < n && coarse_bin(key_score(reg[i].y)) >= bstar) ? 1u : 0u;
+    mine = wave_sum(mine);
+    if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (tid == 0) s_base = s_cnt ? atomicAdd(&st->nfinal, s_cnt) : 0u;
+    __syncthreads();
+    const uint32_t base = s_base;
+    for (uint32_t i = tid; i < n256; i += 256) {
+        u32x4 e{0, 0, 0, 0};
+        if (i < n) e = reg[i];
+        const bool take = i < n && coarse_bin(key_score(e.y)) >= bstar;
+        const u64 m = __ballot(take);
+        if (m == 0) continue;
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s_cur, static_cast<uint32_t>(__popcll(m)));
+        b = __builtin_amdgcn_readfirstlane(b);
+        const uint32_t pos = base + b + lane_rank(m);
+        if (take && pos < cap) finalists[pos] = (static_cast<u64>(e.y) << 32) | e.x; // (cap >= the table's rows: never short)
+    }
+}
+
 } // namespace
+
+hipError_t launch_fused_handoff(const ScanArgs& a, const FusedArgs& f, uint32_t nwg, unsigned long long* finalists, uint32_t cap, hipStream_t s)
+{
+    hipLaunchKernelGGL(fused_handoff_kernel, dim3(nwg), dim3(256), 0, s, a, f, finalists, cap);
+    return hipGetLastError();
+}
 
 template <int LPR, int U, bool WORDS = false>
 hipError_t launch_fused_t(const ScanArgs& a, const ScanGeometry& g, const FusedArgs& f, hipStream_t s)
@@ -1390,12 +1491,12 @@ bool fused_supported(const ScanGeometry& g)
 // r = ceil(k / M) sits in the middle of the reports; 0 when even M = 16 leaves r above the number of
 // waves (tiny grids: no thresholds, every row is published) or the reports would not fit the
 // electing wave's registers (64 x 64 keys).
-uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k)
+uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k, uint32_t max_m)
 {
     if (nwaves == 0 || nwaves > static_cast<uint32_t>(kFusedSelectors) * (kScanBlock / 64)) return 0;
     uint32_t m = (2 * k + nwaves - 1) / nwaves;
     if (m < 1) m = 1;
-    if (m > 16) m = 16;
+    if (m > max_m) m = max_m; // (16 for the single launch's own k; up to 64 when it only publishes: mth_best's M rounds)
     if ((k + m - 1) / m > nwaves) return 0;
     return m;
 }

@@ -617,8 +617,12 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__
     const uint32_t nkeys = em.lk->count < em.a.k ? em.lk->count : em.a.k;
     if (rank < nkeys) emit_hit(em.a, key, em.row_base, reinterpret_cast<gsim_hit*>(hdr + 1) + rank); // (rank < count: a gathered key, not padding)
     if (i == 0) {
-        hdr->count = nkeys;
-        hdr->flags = em.flags;
+        // (flags bit 31, synchronous callers of the single launch's large-k route: no gated classic kernels ran behind a launch
+        // that handed the query back -- QueryState::redo is still set -- so the block says "handed back" (flag 2) and the host
+        // runs the query again; read before this workgroup's ticket, cleared by the last one)
+        const bool back = (em.flags & 0x80000000u) != 0 && em.a.state->redo != 0;
+        hdr->count = back ? 0u : nkeys;
+        hdr->flags = (em.flags & 0x7FFFFFFFu) | (back ? 2u : 0u);
         hdr->approx = em.a.cutoff > 0.0f ? em.a.state->kept : em.approx_if_no_cutoff;
     }
     // the last workgroup re-zeroes the per-query state (every workgroup has used what it read of it before its ticket)

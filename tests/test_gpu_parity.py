@@ -350,6 +350,78 @@ def test_large_k_with_ties_in_the_boundary_bin():
     t2.close()
 
 
+def test_large_k_single_launch_scan():
+    """k in (8192, 32768] on a table of at least 64 k rows: the single launch scans and publishes, the hand-off kernel makes its
+    lists the finalists of the large-k kernels (gsim_timing.large_k_single_scan counts the route).  Whole-table oracle at
+    several widths and k, with a cutoff, with Tversky; a table of eight fingerprints (the k-th score is shared by 125 k rows); a table of ONE fingerprint, which the single
+    launch hands back (a wave's store overflows: the four-kernel pipeline's scan answers, handed_back counts it); ordinary queries
+    in between on the same handles."""
+    for W, n, ks in ((32, 2_200_000, (8193, 20_000, 32_768)), (16, 1_400_000, (12_000, 20_000)), (64, 700_000, (10_000,))):
+        db = O.synth_rows(0x5CA7 + W, 0, 0, n, W)
+        t = make_table(db)
+        before = t.timing()["large_k_single_scan"]
+        for i, k in enumerate(ks):
+            check_against_oracle(t, db, db[1000 + i], k, 0.0, ctx="single-scan large k W=%d k=%d" % (W, k))
+        check_against_oracle(t, db, db[5], ks[0], 0.08, ctx="single-scan large k cutoff W=%d" % W)
+        check_against_oracle(t, db, db[6], ks[0], 0.0, ctx="single-scan large k tversky W=%d" % W, metric=capi.METRIC_TVERSKY,
+                             alpha=np.float32(0.3), beta=np.float32(0.7))
+        tm = t.timing()
+        assert tm["large_k_single_scan"] - before == len(ks) + 2, tm
+        assert tm["handed_back"] == 0, tm
+        check_against_oracle(t, db, db[7], 100, 0.0, ctx="small k after large W=%d" % W)  # (the state was left clean)
+        check_against_oracle(t, db, db[8], 33_000, 0.0, ctx="k above the route's range W=%d" % W)
+        t.close()
+    base = O.synth_rows(0x71E8, 0, 0, 8, 32)
+    n = 1_000_000
+    tied = np.ascontiguousarray(base[np.random.default_rng(6).integers(0, 8, size=n)])  # 125 k copies of each fingerprint
+    t = make_table(tied)
+    for i, k in enumerate((9_000, 15_000)):
+        check_against_oracle(t, tied, base[i], k, 0.0, ctx="single-scan tied k=%d" % k)
+        check_against_oracle(t, tied, base[i + 2], 64, 0.0, ctx="small k on the tied table")
+    tm = t.timing()
+    assert tm["large_k_single_scan"] == 2, tm  # (125 k rows tie at the k-th score: the published lists hold them, nothing is handed back today)
+    t.close()
+    same = np.ascontiguousarray(np.tile(base[:1], (2_400_000, 1)))  # every wave meets more tied rows than its store holds
+    t = make_table(same)
+    for k in (9_000, 30_000):
+        h = check_against_oracle(t, same, base[0], k, 0.0, ctx="single-scan, all rows tie, k=%d" % k)
+        assert (h["row"] == np.arange(k)).all()
+        check_against_oracle(t, same, base[1], 500, 0.0, ctx="small k on the all-tie table")
+    check_against_oracle(t, same, base[2], 12_000, 0.01, ctx="single-scan, all rows tie, cutoff")
+    tm = t.timing()
+    assert tm["large_k_single_scan"] == 3 and tm["handed_back"] >= 3 and tm["handed_back_why"] & 1, tm
+    # the pipelined per-query entry point: handed-back large-k queries with later ones already enqueued behind them
+    qs = np.ascontiguousarray(np.stack([base[0], base[1], base[0], base[3], base[0]]))
+    bufs = t.make_search_buffers(len(qs), 8500)
+    t.search_each_into(qs, 8500, bufs)
+    hits, counts, approx = bufs
+    for i in range(len(qs)):
+        want, wap = O.search(qs[i], same, 8500, 0.0, nthreads=8)
+        assert int(approx[i]) == wap
+        assert_hits_equal(hits[i][:int(counts[i])], want, "pipelined all-tie large k, query %d" % i)
+    # enqueue-only callers (gsim_db_search_device: the RCCL route's shard step) cannot look at the block: the gated classic
+    # kernels run behind the publishing launch -- the all-tie table -- or return at once -- an ordinary one
+    import torch
+    rnd = O.synth_rows(0x71EB, 0, 0, 1_200_000, 32)
+    t2 = make_table(rnd)
+    st = torch.cuda.Stream(device=0)
+    for tab, db, q in ((t, same, base[0]), (t2, rnd, rnd[99])):
+        tab.set_stream(st.cuda_stream)
+        for k, cutoff in ((9_500, 0.0), (16_000, 0.02)):
+            blk = capi.result_block_bytes(k)
+            out = torch.zeros(blk, dtype=torch.uint8, device="cuda:0")
+            with torch.cuda.stream(st):
+                tab.search_device(q, k, out.data_ptr(), cutoff)
+            st.synchronize()
+            got, gap, _ = capi.parse_result_block(out.cpu().numpy().tobytes(), k)
+            want, wap = O.search(q, db, k, cutoff, nthreads=8)
+            assert gap == wap
+            assert_hits_equal(got, want, "device block, large k=%d cutoff=%g" % (k, cutoff))
+    assert t2.timing()["large_k_single_scan"] == 2 and t2.timing()["handed_back"] == 0
+    t2.close()
+    t.close()
+
+
 def test_large_k_routes_forced():
     """GSIM_LARGEK_ONE_BLOCK_MAX (read once per process: child processes) forces the one-workgroup route for every finalist
     count and the grid route for every count: the large-k, tie and folded tests pass either way."""
