@@ -374,7 +374,7 @@ def table_uses_fused(k, tm):
 MFMA_ISSUE_PROBE = ((0, 38.2), (4, 38.1), (8, 57.6), (12, 69.7))
 # ... and the shipped 2048-bit kernel's vector instructions per MFMA, SQ_INSTS_VALU / SQ_INSTS_MFMA
 # (profiles/r05_batch_mfma_pmc_raw.txt; 5 of them are the operand expansion, round 5 could not take them out: DESIGN.md section 3)
-BATCH_VALU_PER_MFMA = {64: 7.8}
+BATCH_VALU_PER_MFMA = {64: 7.6}
 
 
 def issue_roofline(W, frac):

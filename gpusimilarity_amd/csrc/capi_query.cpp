@@ -57,12 +57,14 @@ bool fused_applies(const gsim_db* db, const Shard& s, uint32_t k)
     return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
 }
 
-// k in (kSelectCap, kFusedPublishMaxK]: the single launch scans and publishes (kFusedPublishOnly), the large-k kernels rank
-// what it published.  Rows of 512 bits and more only: the narrow widths want the sampled seed (enqueue_query_impl), and their
-// scan is bound by the per-row arithmetic either way.
+// k in (fused_select_max_k, kFusedPublishMaxK]: the single launch scans and publishes (kFusedPublishOnly), the large-k kernels
+// rank what it published.  Rows of 512 bits and more only: the narrow widths want the sampled seed (enqueue_query_impl), and
+// their scan is bound by the per-row arithmetic either way.  From k = 4097, not 8193: the selectors' own ranking of that many
+// rows is issue-bound (one wave per SIMD; profiles/EXPERIMENTS.md) -- k = 8192 at 1 M rows 103 us a query inside the launch, 96
+// through the large-k kernels (Morgan-shaped rows 139 -> 96, and nothing is handed back for "too many finalists").
 bool fused_publish_applies(const gsim_db* db, const Shard& s, uint32_t k)
 {
-    if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(gsim::kSelectCap) || k > gsim::kFusedPublishMaxK || s.nrows == 0 ||
+    if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(db->knobs.fused_select_max_k) || k > gsim::kFusedPublishMaxK || s.nrows == 0 ||
         !gsim::fused_supported(s.fgeo))
         return false;
     if (s.fgeo.lanes_per_row < 4 || s.fgeo.ragged_words || s.fgeo.ragged_loads) return false;
@@ -96,12 +98,13 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
         s.state_dirty = false;
     }
-    bool fused = mode == kAuto && fused_applies(db, s, k);
+    // (k between the knob fused_select_max_k and kFusedMaxK: the single launch could rank it, the publishing route is preferred)
+    const bool publish = mode == kAuto && fused_publish_applies(db, s, k);
+    bool fused = mode == kAuto && !publish && fused_applies(db, s, k);
     if (fused && caller_syncs && s.fused_skip) {
         s.fused_skip--;
         fused = false;
     }
-    const bool publish = mode == kAuto && !fused && fused_publish_applies(db, s, k);
     const bool classic = !fused || !caller_syncs;
     if (classic) {
         const int rc = ensure_classic_scratch(s);
@@ -238,7 +241,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
     }
     if (ev && !fused) GSIM_HIP(hipEventRecord(ev[1], s.stream));
     if (scan_classic && s.nrows > 0) GSIM_HIP(gsim::launch_compact(a, s.geo, s.d_final, s.d_final_cb, s.final_cap, s.stream));
-    if (k <= static_cast<uint32_t>(gsim::kSelectCap)) {
+    if (k <= static_cast<uint32_t>(gsim::kSelectCap) && !publish) {
         GSIM_HIP(gsim::launch_select(a, s.d_final, s.d_final_cb, s.final_cap, row_base, out, s.stream));
     } else {
         // large k: the k-th largest finalist key by a radix select on the device (the finalist count never reaches the

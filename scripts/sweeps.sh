@@ -15,6 +15,9 @@ echo "== four-kernel pipeline for comparison (GSIM_FUSED=0), 1024-bit =="
 GSIM_FUSED=0 TS_REPS=50 python scripts/time_single.py 1000000 10000000 100000000 2>&1 | grep rows
 echo "== k sweep, 100 M x 1024-bit =="
 for k in 1 10 100 1000 2048 4096 8192 20000; do TS_K=$k TS_REPS=30 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/k $k  /"; done
+echo "== large k, 100 M x 1024-bit: the single launch scans and publishes (default) / the four-kernel pipeline's scan (GSIM_FUSED_PUBLISH=0) =="
+for k in 8193 20000 32768 50000; do for p in 1 0; do GSIM_FUSED_PUBLISH=$p TS_K=$k TS_REPS=30 python scripts/time_single.py 100000000 2>&1 | grep rows | sed "s/^/k $k publish $p  /"; done; done
+for n in 1000000 10000000; do for p in 1 0; do GSIM_FUSED_PUBLISH=$p TS_K=10000 TS_REPS=50 python scripts/time_single.py $n 2>&1 | grep rows | sed "s/^/k 10000 publish $p  /"; done; done
 echo "== k sweep, 1 M x 1024-bit (Morgan-shaped: second block) =="
 for k in 1 100 1000 2048 4096 8192; do TS_K=$k python scripts/time_single.py 1000000 2>&1 | grep rows | sed "s/^/k $k  /"; done
 for k in 1000 4096 8192; do TS_KIND=morgan TS_K=$k python scripts/time_single.py 1000000 2>&1 | grep rows | sed "s/^/morgan k $k  /"; done
