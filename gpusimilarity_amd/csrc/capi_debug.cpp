@@ -169,7 +169,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
         db->acc.candidates_sum += c - s.base_ncand;
         db->acc.finalists_sum += f - s.base_nfinal;
         db->acc.handed_back += r - s.base_nredo;
-        db->acc.handed_back_why |= s.h_state->redo_why & 31u; // (bit 5 = "a selector saw it fail": not a reason of its own)
+        db->acc.handed_back_why |= s.h_state->redo_why & (31u | gsim::kRedoBinTies); // (bit 5 = "a selector saw it fail": not a reason of its own)
     }
     db->acc.batches_dense_cutoff = db->dense_batches;
     db->acc.blocks_rechecked = db->blocks_rechecked;

@@ -102,6 +102,8 @@ struct Shard {
     unsigned long long* d_large = nullptr; // k > kSelectCap: the gathered top-k keys and the sort's second buffer, 2 x next_pow2(k) entries
     uint32_t large_cap = 0;
     gsim::LargeKState* d_lk = nullptr;
+    uint32_t* d_bincur = nullptr;    // kScanBins cursors of launch_fused_binsort (zero between queries)
+    uint32_t binrank_skip = 0;       // large-k queries left that take the radix tail: the bin-ranked one handed a query back (ties)
     bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)
     void* d_pub = nullptr;      // single-launch path: the workgroups' published-candidate regions (128 KB each)
     void* d_hdr = nullptr;      // ... and their headers (64 B each)
@@ -111,6 +113,7 @@ struct Shard {
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
     uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
     bool slot_publish[kPipe] = {};  // the synchronous enqueue of the slot was a large-k query scanned by the single launch (header flag 2: run it again)
+    bool slot_binrank[kPipe] = {};  // ... and ranked by coarse bin (a hand-back sends the next ones to the radix tail)
     bool slot_rerun[kPipe] = {};    // ... but behind a launch that left the per-query state dirty: not to be trusted, run again
     char* h_pipe = nullptr;          // kPipe pinned result blocks (gsim_db_search_each)
     size_t h_pipe_block = 0;

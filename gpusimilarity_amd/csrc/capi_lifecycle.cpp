@@ -43,6 +43,7 @@ gsim::Knobs read_knobs()
     k.fused_flags = env_value("GSIM_FUSED_FLAGS", k.fused_flags);
     k.fused_seed_narrow = env_value("GSIM_FUSED_SEED_NARROW", k.fused_seed_narrow);
     k.fused_publish = env_value("GSIM_FUSED_PUBLISH", k.fused_publish);
+    k.largek_binrank = env_value("GSIM_LARGEK_BINRANK", k.largek_binrank);
     k.fused_select_max_k = std::min(std::max(env_value("GSIM_FUSED_SELECT_MAX_K", k.fused_select_max_k), 4096), static_cast<int>(gsim::kFusedMaxK));
     k.largek_one_block_max = env_value("GSIM_LARGEK_ONE_BLOCK_MAX", k.largek_one_block_max);
     k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
@@ -110,6 +111,7 @@ int free_shard(Shard& s)
     if (s.d_cb2) (void) hipFree(s.d_cb2);
     if (s.d_large) (void) hipFree(s.d_large);
     if (s.d_lk) (void) hipFree(s.d_lk);
+    if (s.d_bincur) (void) hipFree(s.d_bincur);
     if (s.d_pub) (void) hipFree(s.d_pub);
     if (s.d_hdr) (void) hipFree(s.d_hdr);
     if (s.d_summ) (void) hipFree(s.d_summ);

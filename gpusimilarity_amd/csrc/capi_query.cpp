@@ -96,6 +96,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, redo_why), s.stream)); // (the per-query part)
         if (s.d_lk) GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));   // (a large-k enqueue may have failed between its radix passes)
         GSIM_HIP(hipMemsetAsync(s.d_summ, 0, kSummBytes, s.stream));
+        if (s.d_bincur) GSIM_HIP(hipMemsetAsync(s.d_bincur, 0, static_cast<size_t>(gsim::kScanBins) * 4, s.stream));
         s.state_dirty = false;
     }
     // (k between the knob fused_select_max_k and kFusedMaxK: the single launch could rank it, the publishing route is preferred)
@@ -155,6 +156,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
     if (caller_syncs) {
         s.slot_fused[pipe_slot] = false;
         s.slot_publish[pipe_slot] = false;
+        s.slot_binrank[pipe_slot] = false;
     }
     if (fused) {
         gsim::FusedArgs f{};
@@ -221,12 +223,37 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.tickets = s.d_summ + 4096;
         f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
         f.xflags = (static_cast<uint32_t>(db->knobs.fused_flags) & ~4u) | gsim::kFusedPublishOnly;
+        if (!s.d_lk) {
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_lk), sizeof(gsim::LargeKState)));
+            GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
+        }
+        if (!s.d_bincur) {
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_bincur), static_cast<size_t>(gsim::kScanBins) * 4));
+            GSIM_HIP(hipMemsetAsync(s.d_bincur, 0, static_cast<size_t>(gsim::kScanBins) * 4, s.stream));
+        }
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
+        db->large_k_published++;
+        if (caller_syncs) {
+            s.slot_publish[pipe_slot] = true;
+            // The caller reads the block: a hand-back costs a second run, not a wrong answer -- so the finalists are placed by coarse
+            // bin and ranked inside their bins (two launches; the radix select + gather + sort are four and a gap).  Tables whose
+            // top bins hold more than kBinRankCap rows (ties) hand that back: the next large-k queries take the radix tail.
+            if (db->knobs.largek_binrank && s.binrank_skip == 0) {
+                GSIM_HIP(gsim::launch_fused_binsort(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.d_bincur, s.stream));
+                if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
+                GSIM_HIP(gsim::launch_binrank_emit(a, s.d_final, s.final_cap, s.d_bincur, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
+                s.slot_binrank[pipe_slot] = true;
+                if (ev) {
+                    GSIM_HIP(hipEventRecord(ev[2], s.stream));
+                    s.ev_used++;
+                }
+                return GSIM_OK;
+            }
+            if (s.binrank_skip) s.binrank_skip--;
+        }
         GSIM_HIP(gsim::launch_fused_handoff(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.stream));
         a.gate = &s.d_state->redo;
-        db->large_k_published++;
-        if (caller_syncs) s.slot_publish[pipe_slot] = true;
     }
     // (a synchronous caller of the publishing launch learns of a hand-back from the block's header and runs the query again --
     // finish_query_sync -- instead of paying for three gated launches, ~4.5 us each, behind every query)
@@ -309,7 +336,8 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
     if (!s.slot_fused[pipe_slot]) {
         int rc = wait_stream(s.stream);
         if (rc == GSIM_OK && s.slot_publish[pipe_slot] && (static_cast<const gsim_result_header*>(out)->flags & 2u)) {
-            // k above 8192, scanned by the single launch, handed back (heavy ties): the emission cleared the per-query state
+            // large k, scanned by the single launch, handed back (heavy ties): the emission cleared the per-query state
+            if (s.slot_binrank[pipe_slot]) s.binrank_skip = 16; // (ties in the top bins, most likely: the next ones by the radix tail)
             rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
             if (rc == GSIM_OK) rc = wait_stream(s.stream);
         }

@@ -61,6 +61,7 @@ constexpr uint32_t kRedoArrivalWait = 4;  // the grid-wide arrival did not compl
 constexpr uint32_t kRedoFinalists = 8;    // more rows at or above the final threshold than a selector's LDS holds
 constexpr uint32_t kRedoOwned = 16;       // ... or more of them owned by one selector than its list holds
 constexpr uint32_t kRedoSeen = 32;        // a selector found the query already failed
+constexpr uint32_t kRedoBinTies = 64;     // large k, ranked by coarse bin: one of the top bins holds more rows than kBinRankCap (ties)
 
 struct ScanGeometry {
     uint32_t lanes_per_row; // 16-byte lanes per fingerprint (fp words / 4), 0 = generic path
@@ -130,6 +131,12 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
 // Behind a kFusedPublishOnly launch: the published rows of the coarse bins at or above the k-th best's become the finalists of
 // the large-k kernels (their keys into `finalists`, QueryState::nfinal set; ::ghist was filled by the launch) -- unless the
 // launch handed the query back (QueryState::redo != 0).
+// ... or, for callers that look at the result block (a hand-back can be run again by the host): the same rows placed BY COARSE BIN,
+// highest bin first (the histogram gives every bin's first position; `cursors`: kScanBins counters, zero between queries), so
+// that launch_binrank_emit only has to order each bin's rows among themselves.  A top bin of more than kBinRankCap rows: handed
+// back (kRedoBinTies), nothing is placed.
+constexpr uint32_t kBinRankCap = 16384; // (a hand-back costs a second scan; a bin of 16 Ki rows ~40 us of compares)
+hipError_t launch_fused_binsort(const ScanArgs& a, const FusedArgs& f, uint32_t nwg, unsigned long long* finalists, uint32_t cap, uint32_t* cursors, hipStream_t s);
 hipError_t launch_fused_handoff(const ScanArgs& a, const FusedArgs& f, uint32_t nwg, unsigned long long* finalists, uint32_t cap, hipStream_t s);
 bool fused_supported(const ScanGeometry& g);
 uint32_t fused_summary_keys(uint32_t nwaves, uint32_t k, uint32_t max_m = 16);
@@ -151,6 +158,7 @@ struct Knobs {
     int fused_publish = 1;           // GSIM_FUSED_PUBLISH       0: k above 8192 scans with the four-kernel pipeline's scan
     int fused_select_max_k = 4096;   // GSIM_FUSED_SELECT_MAX_K  largest k the single launch ranks itself (4096 ... 8192) where it can also publish for the large-k kernels
     int largek_one_block_max = 32768; // GSIM_LARGEK_ONE_BLOCK_MAX
+    int largek_binrank = 1;          // GSIM_LARGEK_BINRANK      0: the published rows of a large-k query always go through the radix select + sort
     int each_pipeline = 1;           // GSIM_EACH_PIPELINE       0: gsim_db_search_each waits for every query before the next
     int batch = 1;                   // GSIM_BATCH               0: no shared table passes
     int batch_waves_per_cu = 12;     // GSIM_BATCH_WAVES_PER_CU
@@ -203,6 +211,12 @@ hipError_t launch_sort_desc(unsigned long long* keys, unsigned long long* tmp, u
 // per-query state re-zeroed (until round 4: a fill, the sort, an emission kernel and a reset kernel)
 hipError_t launch_largek_sort_emit(const ScanArgs& a, unsigned long long* keys, uint32_t n_pow2, LargeKState* lk, uint32_t row_base,
                                    uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result, hipStream_t s);
+
+// Behind launch_fused_binsort: every finalist's position = its bin's first position + the number of larger keys in its bin; the
+// hits of the first k, the header (flag 2 and no hits if QueryState::redo is set: the host runs the query again), the per-query
+// state and the cursors re-zeroed by the last workgroup.  Two launches instead of the radix select + gather + two-launch sort.
+hipError_t launch_binrank_emit(const ScanArgs& a, const unsigned long long* finalists, uint32_t cap, uint32_t* cursors, LargeKState* lk,
+                               uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result, hipStream_t s);
 
 // Folded tables: re-score the candidates of a folded search (result block `folded_block`, device memory) with the full
 // fingerprints, stable sort by the new score, first min(k, .) at or above the cutoff -> out_block (fingerprintdb_cuda.cu:

@@ -198,6 +198,46 @@ __device__ __forceinline__ void find_threshold(const uint32_t* hist, uint32_t k,
     threshold_from_counts<PER>(h, s, k, lane, bin_out, cnt_out);
 }
 
+// The coarse histogram as a layout: base[b] = rows in the bins above b (bin b's first position in a list ordered by bin, highest
+// first), B* = the bin of the k-th best (find_threshold), and the largest population among the bins >= B*.  One wavefront
+// (threads 0..63 of the workgroup); base: kScanBins words of LDS.
+__device__ __forceinline__ void bin_layout(const uint32_t* hist, uint32_t k, int lane, uint32_t* base, uint32_t& bstar_out, uint32_t& cnt_out,
+                                           uint32_t& maxpop_out)
+{
+    constexpr int PER = kScanBins / 64;
+    uint32_t h[PER];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        h[i] = hist[lane * PER + i];
+        s += h[i];
+    }
+    uint32_t incl = s; // suffix sum over lanes >= lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = static_cast<uint32_t>(__shfl_down(static_cast<int>(incl), d, 64));
+        if (lane + d < 64) incl += t;
+    }
+    uint32_t acc = incl - s;
+#pragma unroll
+    for (int i = PER - 1; i >= 0; i--) {
+        base[lane * PER + i] = acc;
+        acc += h[i];
+    }
+    uint32_t bstar, cnt;
+    threshold_from_counts<PER>(h, s, k, lane, bstar, cnt);
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) mx = (static_cast<uint32_t>(lane * PER + i) >= bstar && h[i] > mx) ? h[i] : mx;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t t = static_cast<uint32_t>(__shfl_xor(static_cast<int>(mx), d, 64));
+        mx = t > mx ? t : mx;
+    }
+    bstar_out = bstar;
+    cnt_out = cnt;
+    maxpop_out = mx;
+}
 
 } // namespace
 } // namespace gsim

@@ -1437,7 +1437,80 @@ __global__ __launch_bounds__(256) void fused_handoff_kernel(ScanArgs a, FusedArg
     }
 }
 
+// The same hand-off BY COARSE BIN (gsim_device.h launch_fused_binsort): every workgroup derives the layout from the histogram
+// for itself, then places the rows of its regions.  A device-scope counter per bin hands out the positions inside a bin -- to
+// workgroups, not rows: a workgroup counts its rows per bin in LDS first and reserves each bin's share with one atomic (one
+// atomic per row queued 11 k of them on ~60 addresses: 40 us at k = 8192), and few workgroups take many regions each so that
+// the shares are worth an atomic.  A top bin beyond kBinRankCap rows, or a launch that handed the query back: nothing is placed.
+constexpr uint32_t kBinsortGrid = 128;
+
+__global__ __launch_bounds__(256) void fused_binsort_kernel(ScanArgs a, FusedArgs fa, uint32_t nwg, u64* finalists, uint32_t cap, uint32_t* cursors)
+{
+    __shared__ uint32_t s_base[kScanBins], s_mine[kScanBins], s_off[kScanBins];
+    __shared__ uint32_t s_bstar, s_cnt, s_ok;
+    QueryState* st = a.state;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && a.query_dev != a.query) // the device copy of the query the emission reads (the classic scan's job otherwise)
+        for (uint32_t i = tid; i < a.W; i += 256) a.query_dev[i] = a.query[i];
+    if (agent_load(&st->redo) != 0) return; // (set before the launch ended: every workgroup reads the same)
+    if (tid < 64) {
+        uint32_t bstar, cnt, mx;
+        bin_layout(st->ghist, a.k, tid, s_base, bstar, cnt, mx);
+        if (tid == 0) {
+            s_bstar = bstar;
+            s_cnt = cnt;
+            s_ok = mx <= kBinRankCap ? 1u : 0u;
+        }
+    }
+    for (int i = tid; i < kScanBins; i += 256) s_mine[i] = 0;
+    __syncthreads();
+    if (!s_ok) { // (every workgroup finds the same: nobody places anything; the emission reports the hand-back and tidies up)
+        if (blockIdx.x == 0 && tid == 0) {
+            st->redo_sum += 1u;
+            st->redo_why |= kRedoBinTies;
+            __hip_atomic_store(&st->redo, kRedoBinTies, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const uint32_t bstar = s_bstar;
+    const uint32_t* hdr = static_cast<const uint32_t*>(fa.hdr);
+    for (uint32_t r = blockIdx.x; r < nwg; r += gridDim.x) { // this workgroup's rows per bin
+        const uint32_t n = hdr[r * (kFusedHeaderBytes / 4)] & 0x7FFFFFFFu;
+        const u32x4* reg = static_cast<const u32x4*>(fa.pub) + static_cast<size_t>(r) * kFusedRegion;
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t bin = coarse_bin(key_score(reg[i].y));
+            if (bin >= bstar) atomicAdd(&s_mine[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < kScanBins; b += 256) { // its share of every bin it holds rows of
+        const uint32_t c = s_mine[b];
+        if (c) s_off[b] = s_base[b] + atomicAdd(&cursors[b], c);
+        s_mine[b] = 0; // (from here on: the rows placed so far)
+    }
+    __syncthreads();
+    for (uint32_t r = blockIdx.x; r < nwg; r += gridDim.x) {
+        const uint32_t n = hdr[r * (kFusedHeaderBytes / 4)] & 0x7FFFFFFFu;
+        const u32x4* reg = static_cast<const u32x4*>(fa.pub) + static_cast<size_t>(r) * kFusedRegion;
+        for (uint32_t i = tid; i < n; i += 256) {
+            const u32x4 e = reg[i];
+            const uint32_t bin = coarse_bin(key_score(e.y));
+            if (bin >= bstar) {
+                const uint32_t pos = s_off[bin] + atomicAdd(&s_mine[bin], 1u);
+                if (pos < cap) finalists[pos] = (static_cast<u64>(e.y) << 32) | e.x; // (cap >= the table's rows: never short)
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) st->nfinal = s_cnt; // rows in the bins >= B* (all published rows if they are fewer than k)
+}
+
 } // namespace
+
+hipError_t launch_fused_binsort(const ScanArgs& a, const FusedArgs& f, uint32_t nwg, unsigned long long* finalists, uint32_t cap, uint32_t* cursors, hipStream_t s)
+{
+    hipLaunchKernelGGL(fused_binsort_kernel, dim3(nwg < kBinsortGrid ? nwg : kBinsortGrid), dim3(256), 0, s, a, f, nwg, finalists, cap, cursors);
+    return hipGetLastError();
+}
 
 hipError_t launch_fused_handoff(const ScanArgs& a, const FusedArgs& f, uint32_t nwg, unsigned long long* finalists, uint32_t cap, hipStream_t s)
 {

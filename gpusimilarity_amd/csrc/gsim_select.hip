@@ -632,6 +632,89 @@ __global__ __launch_bounds__(256) void rank_merge_kernel(const u64* __restrict__
     if (s_last) reset_query_state(em.a.state, em.lk, static_cast<int>(threadIdx.x), 256);
 }
 
+// Large k behind the publishing single launch, for callers that read the block (launch_fused_binsort placed the finalists by
+// coarse bin, highest bin first): the list is in order ACROSS bins -- the coarse bin is monotone in the score key -- so a key's
+// final position is its bin's first position plus the number of larger keys IN ITS BIN: a few hundred compares against keys
+// the whole wave reads together (neighbours in the list share a bin), instead of the radix select over all finalists, the
+// gather and the two-launch sort (k = 8192 at 1 M rows: 18 + 16 + 9 us and a 6 us gap -> one launch).  A workgroup takes
+// kBinRankKeys list positions; the grid covers k + kBinRankCap of them (fewer than k rows lie above B*, at most kBinRankCap in it).
+constexpr uint32_t kBinRankChunk = 2048; // keys staged in LDS at a time
+constexpr uint32_t kBinRankKeys = 64;    // list positions per workgroup: its waves share the compares of each
+constexpr int kBinRankThreads = 512;
+
+__global__ __launch_bounds__(kBinRankThreads) void binrank_emit_kernel(ScanArgs a, const u64* __restrict__ finalists, uint32_t cap, uint32_t* cursors,
+                                                           LargeKState* lk, uint32_t row_base, uint32_t flags, u64 approx_if_no_cutoff, void* d_result)
+{
+    __shared__ uint32_t s_base[kScanBins];
+    __shared__ __attribute__((aligned(16))) u64 s_keys[kBinRankChunk];
+    __shared__ uint32_t s_rank[kBinRankKeys];
+    __shared__ uint32_t s_last, s_rlo, s_rhi;
+    QueryState* st = a.state;
+    const int tid = threadIdx.x, ki = tid & 63, part = tid >> 6;
+    gsim_result_header* hdr = reinterpret_cast<gsim_result_header*>(d_result);
+    const bool back = st->redo != 0; // (the launch, or the placement, handed the query back: read before this workgroup's ticket)
+    uint32_t nfinal = st->nfinal;
+    if (nfinal > cap) nfinal = cap;
+    const uint32_t p0 = blockIdx.x * kBinRankKeys;
+    if (!back && p0 < nfinal) {
+        if (tid < 64) {
+            uint32_t bstar, cnt, mx;
+            bin_layout(st->ghist, a.k, tid, s_base, bstar, cnt, mx);
+            s_rank[tid] = 0;
+        }
+        __syncthreads();
+        // Lane ki of every wave holds list position p0 + ki; wave `part` compares it with every eighth group of eight keys of
+        // its bin (alone on its SIMD a wave issues one instruction per ~5 cycles: a bin of 2600 keys, k = 20 000 at 100 M rows, is
+        // 13 k instructions per key -- shared by eight waves, on four times as many workgroups, it is a few microseconds).
+        const uint32_t p = p0 + ki;
+        const bool valid = p < nfinal;
+        const u64 key = valid ? finalists[p] : ~0ull;
+        const uint32_t bin = valid ? coarse_bin(key_score(static_cast<uint32_t>(key >> 32))) : 0u;
+        const uint32_t lo = valid ? s_base[bin] : 0u, hi = valid ? lo + st->ghist[bin] : 0u; // the list positions of this key's bin
+        // the workgroup's keys are neighbours in the list: their bins together are ONE stretch of it, from the first key's bin to
+        // the last valid one's -- staged in LDS a chunk at a time (coalesced) and compared from there: the lanes of a wave read
+        // the same words (straight from memory every thread's loop waited ~0.3 us per four keys: 55 us at k = 8192)
+        if (tid == 0) s_rlo = lo;
+        if (part == 0 && valid && (p + 1 == nfinal || ki == 63)) s_rhi = hi;
+        __syncthreads();
+        const uint32_t rlo = s_rlo & ~7u, rhi = s_rhi; // (chunks start at a multiple of eight list positions: 16-byte LDS reads)
+        uint32_t rank = 0;
+        for (uint32_t c = rlo; c < rhi; c += kBinRankChunk) {
+            const uint32_t cn = rhi - c < kBinRankChunk ? rhi - c : kBinRankChunk;
+            for (uint32_t i = tid; i < kBinRankChunk; i += kBinRankThreads) s_keys[i] = i < cn ? finalists[c + i] : 0ull; // (past the stretch: below every key)
+            __syncthreads();
+            const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(s_keys);
+            for (uint32_t g = static_cast<uint32_t>(part) * 8u; g < cn; g += 8u * (kBinRankThreads / 64)) { // (wave-uniform)
+                const ulonglong2 q0 = k2[g / 2], q1 = k2[g / 2 + 1], q2 = k2[g / 2 + 2], q3 = k2[g / 2 + 3];
+                const u64 kk[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t j = c + g + static_cast<uint32_t>(e);
+                    rank += (j - lo < hi - lo && kk[e] > key) ? 1u : 0u; // (a key of this key's bin, and larger)
+                }
+            }
+            __syncthreads();
+        }
+        if (rank) atomicAdd(&s_rank[ki], rank);
+        __syncthreads();
+        const uint32_t pos = lo + s_rank[ki];
+        if (part == 0 && valid && pos < a.k) emit_hit(a, key, row_base, reinterpret_cast<gsim_hit*>(hdr + 1) + pos);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        hdr->count = back ? 0u : (nfinal < a.k ? nfinal : a.k);
+        hdr->flags = flags | (back ? 2u : 0u);
+        hdr->approx = a.cutoff > 0.0f ? st->kept : approx_if_no_cutoff;
+    }
+    // the last workgroup re-zeroes the per-query state and the bins' cursors (every workgroup is done with both before its ticket)
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(&lk->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        reset_query_state(st, lk, tid, kBinRankThreads);
+        for (int i = tid; i < kScanBins; i += kBinRankThreads) cursors[i] = 0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // merge of per-shard result blocks (fingerprintdb_cuda.cu:363-380)
 // ---------------------------------------------------------------------------
@@ -801,6 +884,14 @@ hipError_t launch_largek_sort_emit(const ScanArgs& a, unsigned long long* keys, 
     hipLaunchKernelGGL(tile_sort_kernel, dim3(n_pow2 / kSortTile), dim3(kSortThreads), 0, s, keys, n_pow2, &lk->count);
     LargeKEmit em{a, lk, row_base, flags, approx_if_no_cutoff, d_result};
     hipLaunchKernelGGL(rank_merge_kernel<true>, dim3(n_pow2 / 256), dim3(256), 0, s, keys, static_cast<u64*>(nullptr), n_pow2, em);
+    return hipGetLastError();
+}
+
+hipError_t launch_binrank_emit(const ScanArgs& a, const unsigned long long* finalists, uint32_t cap, uint32_t* cursors, LargeKState* lk,
+                               uint32_t row_base, uint64_t approx_if_no_cutoff, uint32_t flags, void* d_result, hipStream_t s)
+{
+    const uint32_t nb = (a.k + kBinRankCap + kBinRankKeys - 1u) / kBinRankKeys;
+    hipLaunchKernelGGL(binrank_emit_kernel, dim3(nb), dim3(kBinRankThreads), 0, s, a, finalists, cap, cursors, lk, row_base, flags, approx_if_no_cutoff, d_result);
     return hipGetLastError();
 }
 

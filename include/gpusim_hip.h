@@ -86,7 +86,8 @@ typedef struct {
     uint64_t handed_back_why;   /* union of the reasons, since the handle was created: 1 a wave's candidate store or a
                                    workgroup's list overflowed (heavy ties, ascending scores), 2 / 4 a wait ran out
                                    (GPU shared with another process), 8 more rows at the final threshold than a
-                                   selector holds, 16 more of them owned by one selector than its list holds           */
+                                   selector holds, 16 more of them owned by one selector than its list holds, 64 (k above 4096)
+                                   more rows in one of the top score bins than the bin-ranked emission takes (ties)     */
     uint64_t batches_dense_cutoff; /* multi-query passes, since the handle was created, whose cutoff kept so many rows that the
                                       matrix-core pass counted them from its accumulators (gsim_prefilter.h cutoff_band)      */
     uint64_t collectives;          /* searches (single queries or <= 256-query batches) merged through gsim_db_set_comm's route */
