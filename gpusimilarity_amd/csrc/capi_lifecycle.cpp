@@ -44,7 +44,7 @@ gsim::Knobs read_knobs()
     k.fused_seed_narrow = env_value("GSIM_FUSED_SEED_NARROW", k.fused_seed_narrow);
     k.fused_publish = env_value("GSIM_FUSED_PUBLISH", k.fused_publish);
     k.largek_binrank = env_value("GSIM_LARGEK_BINRANK", k.largek_binrank);
-    k.fused_select_max_k = std::min(std::max(env_value("GSIM_FUSED_SELECT_MAX_K", k.fused_select_max_k), 4096), static_cast<int>(gsim::kFusedMaxK));
+    k.fused_select_max_k = std::min(std::max(env_value("GSIM_FUSED_SELECT_MAX_K", k.fused_select_max_k), 2048), static_cast<int>(gsim::kFusedMaxK)); // (the large-k sort takes k > 2048)
     k.largek_one_block_max = env_value("GSIM_LARGEK_ONE_BLOCK_MAX", k.largek_one_block_max);
     k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
     k.batch = env_value("GSIM_BATCH", k.batch);

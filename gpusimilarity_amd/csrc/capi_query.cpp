@@ -59,9 +59,10 @@ bool fused_applies(const gsim_db* db, const Shard& s, uint32_t k)
 
 // k in (fused_select_max_k, kFusedPublishMaxK]: the single launch scans and publishes (kFusedPublishOnly), the large-k kernels
 // rank what it published.  Rows of 512 bits and more only: the narrow widths want the sampled seed (enqueue_query_impl), and
-// their scan is bound by the per-row arithmetic either way.  From k = 4097, not 8193: the selectors' own ranking of that many
-// rows is issue-bound (one wave per SIMD; profiles/EXPERIMENTS.md) -- k = 8192 at 1 M rows 103 us a query inside the launch, 96
-// through the large-k kernels (Morgan-shaped rows 139 -> 96, and nothing is handed back for "too many finalists").
+// their scan is bound by the per-row arithmetic either way.  From k = 2049, not 8193: the selectors' own ranking of thousands of
+// rows is issue-bound (one wave per SIMD; profiles/EXPERIMENTS.md) -- k = 4096 at 1 M rows 89 us a query inside the launch, 63
+// published and ranked by score bin; k = 8192 103 -> 74 (Morgan-shaped rows 139 -> 76, and nothing is handed back for "too many
+// finalists"); at 100 M rows k = 4096 0.856 -> 0.872 of the roofline.
 bool fused_publish_applies(const gsim_db* db, const Shard& s, uint32_t k)
 {
     if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(db->knobs.fused_select_max_k) || k > gsim::kFusedPublishMaxK || s.nrows == 0 ||

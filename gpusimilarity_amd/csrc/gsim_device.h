@@ -156,7 +156,7 @@ struct Knobs {
     int fused_flags = 0;             // GSIM_FUSED_FLAGS
     int fused_seed_narrow = 1;       // GSIM_FUSED_SEED_NARROW
     int fused_publish = 1;           // GSIM_FUSED_PUBLISH       0: k above 8192 scans with the four-kernel pipeline's scan
-    int fused_select_max_k = 4096;   // GSIM_FUSED_SELECT_MAX_K  largest k the single launch ranks itself (4096 ... 8192) where it can also publish for the large-k kernels
+    int fused_select_max_k = 2048;   // GSIM_FUSED_SELECT_MAX_K  largest k the single launch ranks itself (2048 ... 8192) where it can also publish for the large-k kernels
     int largek_one_block_max = 32768; // GSIM_LARGEK_ONE_BLOCK_MAX
     int largek_binrank = 1;          // GSIM_LARGEK_BINRANK      0: the published rows of a large-k query always go through the radix select + sort
     int each_pipeline = 1;           // GSIM_EACH_PIPELINE       0: gsim_db_search_each waits for every query before the next

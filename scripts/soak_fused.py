@@ -14,8 +14,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000
 W, NQ = int(os.environ.get("SOAK_BITS", "1024")) // 32, 48
 cases = [(1000, 0.0), (10, 0.0), (100, 0.07), (2048, 0.0), (8192, 0.0)]
-if os.environ.get("SOAK_LARGE_K") == "1":  # the single launch publishing for the large-k kernels (k in (8192, 32768]), mixed with ordinary queries
-    cases = [(9000, 0.0), (1000, 0.0), (20000, 0.0), (12000, 0.05), (32768, 0.0), (100, 0.0)]
+if os.environ.get("SOAK_LARGE_K") == "1":  # the single launch publishing for the large-k kernels (k in (2048, 32768]), mixed with ordinary queries
+    cases = [(9000, 0.0), (1000, 0.0), (20000, 0.0), (12000, 0.05), (32768, 0.0), (100, 0.0), (3000, 0.0), (4096, 0.02)]
 KIND = {"sparse": capi.SYNTH_SPARSE, "morgan": capi.SYNTH_MORGAN}[os.environ.get("SOAK_KIND", "sparse")]
 
 

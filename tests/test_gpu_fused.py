@@ -83,12 +83,12 @@ def test_queries_the_path_cannot_hold_are_handed_back_and_stay_exact():
     tied = np.ascontiguousarray(base[np.random.default_rng(11).integers(0, 4, size=700_000)])
     t = make_table(tied)
     t.enable_timing(True)
-    for k in (10, 1000, 4096):
+    for k in (10, 1000, 2048):
         check(t, tied, base[1], k, 0.0, "ties k=%d" % k)
     assert t.timing()["handed_back"] == 0
-    # k above 4096 is published for the large-k kernels, whose bin-ranked emission does not take a score bin of 175 k rows: the
+    # k above 2048 is published for the large-k kernels, whose bin-ranked emission does not take a score bin of 175 k rows: the
     # first such query is handed back for that (reason 64) and run again, the next ones take the radix tail.  Exact either way.
-    for k in (5000, 8192, 6000):
+    for k in (5000, 8192, 3000):
         check(t, tied, base[1], k, 0.0, "ties k=%d" % k)
     tm = t.timing()
     assert tm["handed_back"] <= 1 and not (tm["handed_back_why"] & ~64), tm

@@ -351,12 +351,12 @@ def test_large_k_with_ties_in_the_boundary_bin():
 
 
 def test_large_k_single_launch_scan():
-    """k in (4096, 32768] on a table of at least 64 k rows: the single launch scans and publishes, the hand-off kernel makes its
+    """k in (2048, 32768] on a table of at least 64 k rows: the single launch scans and publishes, the hand-off kernel makes its
     lists the finalists of the large-k kernels (gsim_timing.large_k_single_scan counts the route).  Whole-table oracle at
     several widths and k, with a cutoff, with Tversky; a table of eight fingerprints (the k-th score is shared by 125 k rows); a table of ONE fingerprint, which the single
     launch hands back (a wave's store overflows: the four-kernel pipeline's scan answers, handed_back counts it); ordinary queries
     in between on the same handles."""
-    for W, n, ks in ((32, 2_200_000, (4097, 8192, 8193, 20_000, 32_768)), (16, 1_400_000, (6_000, 12_000, 20_000)), (64, 700_000, (10_000,))):
+    for W, n, ks in ((32, 2_200_000, (2049, 4097, 8192, 8193, 20_000, 32_768)), (16, 1_400_000, (3_000, 6_000, 12_000, 20_000)), (64, 700_000, (10_000,))):
         db = O.synth_rows(0x5CA7 + W, 0, 0, n, W)
         t = make_table(db)
         before = t.timing()["large_k_single_scan"]
