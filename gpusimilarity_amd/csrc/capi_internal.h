@@ -102,7 +102,7 @@ struct Shard {
     unsigned long long* d_large = nullptr; // k > kSelectCap: the gathered top-k keys and the sort's second buffer, 2 x next_pow2(k) entries
     uint32_t large_cap = 0;
     gsim::LargeKState* d_lk = nullptr;
-    uint32_t* d_bincur = nullptr;    // kScanBins cursors of launch_fused_binsort (zero between queries)
+    uint32_t* d_bincur = nullptr;    // kScanBins cursors of launch_fused_binsort (zero between queries) + kScanBins words: the bins' first positions
     uint32_t binrank_skip = 0;       // large-k queries left that take the radix tail: the bin-ranked one handed a query back (ties)
     bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)
     void* d_pub = nullptr;      // single-launch path: the workgroups' published-candidate regions (128 KB each)

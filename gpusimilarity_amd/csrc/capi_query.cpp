@@ -229,8 +229,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));
         }
         if (!s.d_bincur) {
-            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_bincur), static_cast<size_t>(gsim::kScanBins) * 4));
-            GSIM_HIP(hipMemsetAsync(s.d_bincur, 0, static_cast<size_t>(gsim::kScanBins) * 4, s.stream));
+            GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_bincur), static_cast<size_t>(gsim::kScanBins) * 8)); // (cursors + the layout)
+            GSIM_HIP(hipMemsetAsync(s.d_bincur, 0, static_cast<size_t>(gsim::kScanBins) * 8, s.stream));
         }
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));

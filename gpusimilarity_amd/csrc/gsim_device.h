@@ -132,7 +132,7 @@ hipError_t launch_fused(const ScanArgs& a, const ScanGeometry& g, const FusedArg
 // the large-k kernels (their keys into `finalists`, QueryState::nfinal set; ::ghist was filled by the launch) -- unless the
 // launch handed the query back (QueryState::redo != 0).
 // ... or, for callers that look at the result block (a hand-back can be run again by the host): the same rows placed BY COARSE BIN,
-// highest bin first (the histogram gives every bin's first position; `cursors`: kScanBins counters, zero between queries), so
+// highest bin first (the histogram gives every bin's first position; `cursors`: kScanBins counters, zero between queries, + kScanBins words that receive the layout), so
 // that launch_binrank_emit only has to order each bin's rows among themselves.  A top bin of more than kBinRankCap rows: handed
 // back (kRedoBinTies), nothing is placed.
 constexpr uint32_t kBinRankCap = 16384; // (a hand-back costs a second scan; a bin of 16 Ki rows ~40 us of compares)

@@ -1502,6 +1502,8 @@ __global__ __launch_bounds__(256) void fused_binsort_kernel(ScanArgs a, FusedArg
         }
     }
     if (blockIdx.x == 0 && tid == 0) st->nfinal = s_cnt; // rows in the bins >= B* (all published rows if they are fewer than k)
+    if (blockIdx.x == 0) // the layout, for the emission: every bin's first position (kScanBins words behind the cursors)
+        for (int b = tid; b < kScanBins; b += 256) cursors[kScanBins + b] = s_base[b];
 }
 
 } // namespace

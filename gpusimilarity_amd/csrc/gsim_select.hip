@@ -645,7 +645,6 @@ constexpr int kBinRankThreads = 512;
 __global__ __launch_bounds__(kBinRankThreads) void binrank_emit_kernel(ScanArgs a, const u64* __restrict__ finalists, uint32_t cap, uint32_t* cursors,
                                                            LargeKState* lk, uint32_t row_base, uint32_t flags, u64 approx_if_no_cutoff, void* d_result)
 {
-    __shared__ uint32_t s_base[kScanBins];
     __shared__ __attribute__((aligned(16))) u64 s_keys[kBinRankChunk];
     __shared__ uint32_t s_rank[kBinRankKeys];
     __shared__ uint32_t s_last, s_rlo, s_rhi;
@@ -657,12 +656,7 @@ __global__ __launch_bounds__(kBinRankThreads) void binrank_emit_kernel(ScanArgs 
     if (nfinal > cap) nfinal = cap;
     const uint32_t p0 = blockIdx.x * kBinRankKeys;
     if (!back && p0 < nfinal) {
-        if (tid < 64) {
-            uint32_t bstar, cnt, mx;
-            bin_layout(st->ghist, a.k, tid, s_base, bstar, cnt, mx);
-            s_rank[tid] = 0;
-        }
-        __syncthreads();
+        if (tid < 64) s_rank[tid] = 0;
         // Lane ki of every wave holds list position p0 + ki; wave `part` compares it with every eighth group of eight keys of
         // its bin (alone on its SIMD a wave issues one instruction per ~5 cycles: a bin of 2600 keys, k = 20 000 at 100 M rows, is
         // 13 k instructions per key -- shared by eight waves, on four times as many workgroups, it is a few microseconds).
@@ -670,7 +664,7 @@ __global__ __launch_bounds__(kBinRankThreads) void binrank_emit_kernel(ScanArgs 
         const bool valid = p < nfinal;
         const u64 key = valid ? finalists[p] : ~0ull;
         const uint32_t bin = valid ? coarse_bin(key_score(static_cast<uint32_t>(key >> 32))) : 0u;
-        const uint32_t lo = valid ? s_base[bin] : 0u, hi = valid ? lo + st->ghist[bin] : 0u; // the list positions of this key's bin
+        const uint32_t lo = valid ? cursors[kScanBins + bin] : 0u, hi = valid ? lo + st->ghist[bin] : 0u; // the list positions of this key's bin (the layout launch_fused_binsort left)
         // the workgroup's keys are neighbours in the list: their bins together are ONE stretch of it, from the first key's bin to
         // the last valid one's -- staged in LDS a chunk at a time (coalesced) and compared from there: the lanes of a wave read
         // the same words (straight from memory every thread's loop waited ~0.3 us per four keys: 55 us at k = 8192)
@@ -687,17 +681,16 @@ __global__ __launch_bounds__(kBinRankThreads) void binrank_emit_kernel(ScanArgs 
             for (uint32_t g = static_cast<uint32_t>(part) * 8u; g < cn; g += 8u * (kBinRankThreads / 64)) { // (wave-uniform)
                 const ulonglong2 q0 = k2[g / 2], q1 = k2[g / 2 + 1], q2 = k2[g / 2 + 2], q3 = k2[g / 2 + 3];
                 const u64 kk[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+                // (no test of the position: the stretch is in order across bins, so the keys of higher bins in front of this key's
+                // bin all count and those of lower bins behind it never do -- the count over the whole stretch is the key's place in it)
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const uint32_t j = c + g + static_cast<uint32_t>(e);
-                    rank += (j - lo < hi - lo && kk[e] > key) ? 1u : 0u; // (a key of this key's bin, and larger)
-                }
+                for (int e = 0; e < 8; e++) rank += kk[e] > key ? 1u : 0u;
             }
             __syncthreads();
         }
         if (rank) atomicAdd(&s_rank[ki], rank);
         __syncthreads();
-        const uint32_t pos = lo + s_rank[ki];
+        const uint32_t pos = rlo + s_rank[ki];
         if (part == 0 && valid && pos < a.k) emit_hit(a, key, row_base, reinterpret_cast<gsim_hit*>(hdr + 1) + pos);
     }
     if (blockIdx.x == 0 && tid == 0) {
