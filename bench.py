@@ -334,7 +334,8 @@ def time_queries(ctx, table, total_rows, R, fp_bits, kind, k, steps, warmup, qps
         "fingerprints_per_s": total_rows * steps * qps / elapsed,
         "whole_path_hbm_frac": (total_rows * (fp_bits // 8) / (elapsed / (steps * qps))) / (HBM_PEAK_GBS * 1e9 * ctx["world"]),
         "roofline": {
-            "kernel": kernel_label(W, table_uses_fused(k, tm)),
+            "kernel": kernel_label(W, table_uses_fused(k, tm)) + (" [publishes only; fused_binsort_kernel + binrank_emit_kernel rank]"
+                                                                 if tm.get("large_k_single_scan", 0) > 0 else ""),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
             "traffic_note": "not collected for this entry (the headline entry runs the rocprofv3 --pmc passes)",
@@ -365,7 +366,8 @@ def kernel_label(W, fused):
 
 
 def table_uses_fused(k, tm):
-    return k <= 8192 and os.environ.get("GSIM_FUSED", "1") != "0" and tm["handed_back"] < max(1, tm["queries"])
+    """the single launch scanned (and ranked, or -- gsim_timing.large_k_single_scan -- published for the kernels that rank)"""
+    return (k <= 8192 or tm.get("large_k_single_scan", 0) > 0) and os.environ.get("GSIM_FUSED", "1") != "0" and tm["handed_back"] < max(1, tm["queries"])
 
 
 # The matrix-core batch kernel against its OTHER roofline (SURVEY 8d: "report it against both"): instruction issue.  Two waves per
@@ -767,11 +769,11 @@ def main():
         # the other single-GPU BASELINE configs, measured in this run, each with its own dominant-kernel roofline
         cfgs = []
 
-        def single_cfg(name, rows, kind_, qps_, note=None):
+        def single_cfg(name, rows, kind_, qps_, note=None, k_=1000):
             t = make_table(rows, 1024, 0, kind_)
-            r, _ = time_queries(ctx, t, rows, rows, 1024, kind_, 1000, max(args.steps, 20), args.warmup, qps_, False)
+            r, _ = time_queries(ctx, t, rows, rows, 1024, kind_, k_, max(args.steps, 20), args.warmup, qps_, False)
             t.close()
-            c = {"name": name, "rows_per_gpu": rows, "fp_bits": 1024, "k": 1000, "ms_per_query": r["ms_per_query"],
+            c = {"name": name, "rows_per_gpu": rows, "fp_bits": 1024, "k": k_, "ms_per_query": r["ms_per_query"],
                  "ms_per_step": r["ms_per_query"] * qps_, "queries_per_step": qps_, "value": r["fingerprints_per_s"],
                  "unit": "fingerprints/s", "timed_region_s": r["seconds"], "whole_path_hbm_frac": r["whole_path_hbm_frac"],
                  "roofline": r["roofline"]}
@@ -794,6 +796,14 @@ def main():
                                    capi.SYNTH_MORGAN, 32))
         except Exception as e:  # never lose the headline over it
             cfgs.append({"name": "Morgan-like tables", "error": repr(e)})
+        # large k (not a BASELINE config; the reference sorts every row, any k: fingerprintdb_cuda.cu:280-290): the single launch
+        # publishes, two small kernels rank by score bin
+        try:
+            cfgs.append(single_cfg("large k: 100M x 1024-bit, Tanimoto top-20000 (single launch publishes, bin-ranked emission)", 100_000_000,
+                                   kind, 32, k_=20000))
+            cfgs.append(single_cfg("large k: 1M x 1024-bit, Tanimoto top-8192", 1_000_000, kind, 128, k_=8192))
+        except Exception as e:
+            cfgs.append({"name": "large k", "error": repr(e)})
         try:
             t4 = make_table(125_000_000, 2048, 0)
             r4 = time_batches(ctx, t4, 125_000_000, 125_000_000, 2048, kind, 1000, 256, 8, 2, False)
