@@ -120,6 +120,7 @@ struct Shard {
     // Tables whose scores tie heavily (narrow or very sparse fingerprints) make the single-launch path hand every
     // query back, i.e. scan twice: after consecutive hand-backs the synchronous path skips it for 2, 4, ... 64 queries.
     uint32_t redo_streak = 0, fused_skip = 0;
+    uint32_t publish_streak = 0, publish_skip = 0; // the same back-off for the publishing launch of k above fused_select_max_k (synchronous callers)
     unsigned long long* d_dbg = nullptr; // GSIM_FUSED_DEBUG: per-workgroup phase timestamps
     void* d_result = nullptr;
     size_t result_bytes = 0;

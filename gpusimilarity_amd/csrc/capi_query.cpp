@@ -101,7 +101,11 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         s.state_dirty = false;
     }
     // (k between the knob fused_select_max_k and kFusedMaxK: the single launch could rank it, the publishing route is preferred)
-    const bool publish = mode == kAuto && fused_publish_applies(db, s, k);
+    bool publish = mode == kAuto && fused_publish_applies(db, s, k);
+    if (publish && caller_syncs && s.publish_skip) { // (tables that make the publishing launch hand every query back: scanned twice)
+        s.publish_skip--;
+        publish = false;
+    }
     bool fused = mode == kAuto && !publish && fused_applies(db, s, k);
     if (fused && caller_syncs && s.fused_skip) {
         s.fused_skip--;
@@ -336,9 +340,16 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
 {
     if (!s.slot_fused[pipe_slot]) {
         int rc = wait_stream(s.stream);
-        if (rc == GSIM_OK && s.slot_publish[pipe_slot] && (static_cast<const gsim_result_header*>(out)->flags & 2u)) {
+        const bool back = rc == GSIM_OK && s.slot_publish[pipe_slot] && (static_cast<const gsim_result_header*>(out)->flags & 2u);
+        if (rc == GSIM_OK && s.slot_publish[pipe_slot] && !back) s.publish_streak = 0;
+        if (back) {
             // large k, scanned by the single launch, handed back (heavy ties): the emission cleared the per-query state
-            if (s.slot_binrank[pipe_slot]) s.binrank_skip = 16; // (ties in the top bins, most likely: the next ones by the radix tail)
+            if (s.slot_binrank[pipe_slot]) {
+                s.binrank_skip = 16; // (ties in the top bins, most likely: the next ones by the radix tail)
+            } else { // not the bin-ranked emission's doing: the launch itself cannot hold this table's queries -- back off as the single launch does
+                s.publish_streak = s.publish_streak < 6 ? s.publish_streak + 1 : 6;
+                s.publish_skip = 1u << s.publish_streak;
+            }
             rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
             if (rc == GSIM_OK) rc = wait_stream(s.stream);
         }

@@ -393,7 +393,8 @@ def test_large_k_single_launch_scan():
         check_against_oracle(t, same, base[1], 500, 0.0, ctx="small k on the all-tie table")
     check_against_oracle(t, same, base[2], 12_000, 0.01, ctx="single-scan, all rows tie, cutoff")
     tm = t.timing()
-    assert tm["large_k_single_scan"] == 3 and tm["handed_back"] >= 3 and tm["handed_back_why"] & 1, tm
+    # (after a hand-back that was not the bin-ranked emission's the shard's next 2, 4, ... 64 large-k queries skip the publishing launch)
+    assert 1 <= tm["large_k_single_scan"] <= 3 and tm["handed_back"] >= 3 and tm["handed_back_why"] & 1, tm
     # the pipelined per-query entry point: handed-back large-k queries with later ones already enqueued behind them
     qs = np.ascontiguousarray(np.stack([base[0], base[1], base[0], base[3], base[0]]))
     bufs = t.make_search_buffers(len(qs), 8500)
