@@ -21,10 +21,26 @@ int ensure_classic_scratch(Shard& s)
     GSIM_HIP(hipMalloc(&s.d_cand, static_cast<size_t>(slots) * 8));
     GSIM_HIP(hipMalloc(&s.d_cand_cb, static_cast<size_t>(slots) * 4));
     GSIM_HIP(hipMalloc(&s.d_seg_count, static_cast<size_t>(s.geo.nwaves) * 4));
+    if (s.d_final) { // (the publishing route's smaller list: nothing is in flight on it when a classic query is about to be enqueued
+        GSIM_HIP(hipStreamSynchronize(s.stream)); //  behind it on the same stream -- but the free must not overtake the kernels)
+        GSIM_HIP(hipFree(s.d_final));
+        s.d_final = nullptr;
+    }
     s.final_cap = next_pow2_u32(slots);
     GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
     GSIM_HIP(hipMalloc(&s.d_final_cb, static_cast<size_t>(s.final_cap) * 4));
     s.classic_ready = true;
+    return GSIM_OK;
+}
+
+// The finalist list alone, sized by what the single launch can publish (its workgroups' regions): all a synchronous caller's
+// large-k query needs behind the publishing launch -- 16 MB, not the four-kernel pipeline's 24 bytes per row.
+int ensure_publish_scratch(Shard& s)
+{
+    if (s.d_final) return GSIM_OK;
+    GSIM_HIP(set_device(s.device));
+    s.final_cap = next_pow2_u32(static_cast<uint64_t>(s.fgeo.nwaves / 4) * gsim::kFusedRegion);
+    GSIM_HIP(hipMalloc(&s.d_final, static_cast<size_t>(s.final_cap) * 8));
     return GSIM_OK;
 }
 
@@ -111,9 +127,12 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         s.fused_skip--;
         fused = false;
     }
-    const bool classic = !fused || !caller_syncs;
+    const bool classic = (!fused && !(publish && caller_syncs)) || !caller_syncs;
     if (classic) {
         const int rc = ensure_classic_scratch(s);
+        if (rc != GSIM_OK) return rc;
+    } else if (publish) {
+        const int rc = ensure_publish_scratch(s);
         if (rc != GSIM_OK) return rc;
     }
     const uint32_t slot = s.q_next++ % kQueryRing;
