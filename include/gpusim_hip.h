@@ -98,8 +98,9 @@ typedef struct {
     uint64_t blocks_torn;          /* ... and those that never matched: the query was re-run on the four-kernel pipeline      */
     uint64_t batches_regrown;      /* since the handle was created: multi-query passes run again because a wave's candidate segment
                                       overflowed (the segments start at 4 Ki slots and grow to what was asked for, up to 64 Ki)   */
-    uint64_t large_k_single_scan;  /* since the handle was created: shard queries with k above 8192 whose scan was the single launch's
-                                      (it publishes, the large-k kernels rank); the rest of them took the four-kernel pipeline's scan */
+    uint64_t large_k_single_scan;  /* since the handle was created: shard queries with k above 2048 whose scan was the single launch's
+                                      (it publishes, other kernels rank: DESIGN.md section 3); the rest of them were ranked inside it (k up to 8192)
+                                      or took the four-kernel pipeline's scan */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */
