@@ -84,3 +84,56 @@ def test_random_odd_width_tables_match_the_oracle(seed):
         assert int(approx[0]) == wap, ctx
         assert_hits_equal(hits[0], want, ctx)
     t.close()
+
+
+def large_k_walk(seed, stats=None):
+    """One random table of 150 k ... 3 M rows of 512 ... 4096 bits (i.i.d., dense, Morgan-shaped; every fifth with heavy
+    duplication), eight queries with k from 2049 to 40000 (cutoffs, Tversky) through gsim_db_search and the same queries through
+    the pipelined gsim_db_search_each, each against the oracle: the single launch publishes and the rows are placed by score
+    bin and ranked inside their bins -- or (ties, k above 32768, hand-backs) the radix tail / the four-kernel pipeline answers."""
+    rng = np.random.default_rng(0x1A26E + seed)
+    W = int(rng.choice([16, 32, 32, 32, 64, 128]))
+    n = int(np.exp(rng.uniform(np.log(150_000), np.log(3_000_000 if W <= 32 else 700_000))))
+    kind = int(rng.choice([0, 0, 1, O.KIND_MORGAN])) if W == 32 else int(rng.choice([0, 1]))
+    db = O.synth_rows(0x1A260000 + seed, kind, 0, n, W)
+    if seed % 5 == 4:  # heavy duplication: a few distinct rows
+        db = np.ascontiguousarray(db[rng.integers(0, int(rng.choice([8, 300, 5000])), size=n)])
+    t = make_table(db)
+    tv = dict(metric=capi.METRIC_TVERSKY, alpha=np.float32(rng.choice([0.3, 0.5, 1.0])), beta=np.float32(rng.choice([0.7, 0.5, 1.0])))
+    cases = []
+    for case in range(8):
+        q = db[int(rng.integers(n))] if rng.random() < 0.8 else O.synth_rows(0x1A269999 + seed, 0 if kind != 1 else 1, 50 + case, 1, W)[0]
+        k = int(rng.choice([2049, 2500, 3000, 4096, 4097, 6000, 8192, 8193, 12000, 20000, 32768, 32769, 40000]))
+        cutoff = float(rng.choice([0.0, 0.0, 0.0, 0.03, 0.1, 0.4]))
+        cases.append((q, k, cutoff, tv if rng.random() < 0.25 else {}))
+    nq = 0
+    try:
+        for q, k, cutoff, kw in cases:
+            hits, approx = t.search(q, k, np.float32(cutoff), **kw)
+            want, wap = O.search(q, db, k, np.float32(cutoff), nthreads=16, **kw)
+            ctx = "seed %d: n=%d W=%d kind=%d k=%d cutoff=%g %s" % (seed, n, W, kind, k, cutoff, "tversky" if kw else "tanimoto")
+            assert int(approx[0]) == wap, ctx
+            assert_hits_equal(hits[0], want, ctx)
+            nq += 1
+        k = cases[0][1]  # the pipelined entry point: one k, eight queries in flight
+        qs = np.ascontiguousarray(np.stack([c[0] for c in cases]))
+        bufs = t.make_search_buffers(len(qs), k)
+        t.search_each_into(qs, k, bufs)
+        for i in range(len(qs)):
+            want, wap = O.search(qs[i], db, k, np.float32(0.0), nthreads=16)
+            assert int(bufs[2][i]) == wap, "seed %d pipelined %d" % (seed, i)
+            assert_hits_equal(bufs[0][i][:int(bufs[1][i])], want, "seed %d pipelined %d k=%d" % (seed, i, k))
+            nq += 1
+    finally:
+        if stats is not None:
+            tm = t.timing()
+            stats["queries"] = stats.get("queries", 0) + nq
+            stats["published"] = stats.get("published", 0) + tm["large_k_single_scan"]
+            stats["handed_back"] = stats.get("handed_back", 0) + tm["handed_back"]
+            stats["why"] = stats.get("why", 0) | tm["handed_back_why"]
+        t.close()
+
+
+@pytest.mark.parametrize("seed", [0, 4, 9, 14, 23, 31])
+def test_large_k_random_tables_match_the_oracle(seed):
+    large_k_walk(seed)

