@@ -112,6 +112,8 @@ struct Shard {
     uint32_t epoch = 0;
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
     uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
+    hipEvent_t slot_ev[kPipe] = {}; // recorded behind the last kernel of a synchronous enqueue that is not the single launch's own: its
+    bool slot_ev_set[kPipe] = {};   // caller waits for THIS query, not for the queries enqueued behind it on the stream
     bool slot_publish[kPipe] = {};  // the synchronous enqueue of the slot was a large-k query scanned by the single launch (header flag 2: run it again)
     bool slot_binrank[kPipe] = {};  // ... and ranked by coarse bin (a hand-back sends the next ones to the radix tail)
     bool slot_rerun[kPipe] = {};    // ... but behind a launch that left the per-query state dirty: not to be trusted, run again
@@ -240,6 +242,7 @@ int ensure_result_capacity(Shard& s, uint32_t k);
 int enqueue_query(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha, float beta,
                   uint32_t row_base, void* out, bool caller_syncs, QueryMode mode = kAuto, uint32_t pipe_slot = 0);
 int wait_stream(hipStream_t st);
+int wait_event(hipEvent_t ev);
 int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha, float beta,
                       uint32_t row_base, void* out, uint32_t pipe_slot = 0);
 int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha, float beta, gsim_hit* hits,
