@@ -67,6 +67,11 @@ class QdsReader
         m_p += n;
         return s;
     }
+    void skip(size_t n)
+    {
+        need(n);
+        m_p += n;
+    }
     std::vector<unsigned char> bytearray()
     {
         const uint32_t n = u32();

@@ -146,3 +146,31 @@ def test_corrupt_and_truncated_files_are_refused(multi, tmp_path):
     refused(bytes(bad), "gpusimserver:")
     off = 4 + 4 + len(b"sesame") + 1 + 4                                 # version, cstr dbkey, fp_bitcount
     refused(raw[:off] + struct.pack(">i", sum(BLOCKS) + 1) + raw[off + 4:], "Mismatch between FP count and data")
+    # a wild block count (the i32 behind fp_count): refused because the rest of the file cannot hold that many blocks,
+    # before anything is sized by it; and a negative one
+    refused(raw[:off + 4] + struct.pack(">i", 0x7FFFFFF0) + raw[off + 8:], "gpusimserver:")
+    refused(raw[:off + 4] + struct.pack(">i", -3) + raw[off + 8:], "gpusimserver:")
+    refused(b"", "gpusimserver:")                                        # an empty file
+
+
+def test_more_blocks_than_workers(tmp_path):
+    """100 FP blocks (more than kMaxExtractThreads = 32 workers; the reader used to start one thread per block): every
+    block is read, in file order, and the CPU route answers from all of them."""
+    nb, per = 100, 37
+    n = nb * per
+    rows = O.synth_rows(0xB10C, 0, 0, n, W)
+    parts = [rows[i * per:(i + 1) * per] for i in range(nb)]
+    smiles = [b"N%d" % i for i in range(n)]
+    ids = [b"I%d" % i for i in range(n)]
+    path = str(tmp_path / "many.fsim")
+    write_fsim(path, "k", W * 32, parts, smiles, ids, smiles_blocks=40, id_blocks=50)
+    f = read_fsim(path)
+    assert len(f.fp_blocks) == nb
+    srv = Server(["--cpu_only", path])
+    try:
+        for q in (0, n // 2, n - 1):  # rows of the first, a middle and the last block: each finds itself first
+            fp = rows[q].tobytes()
+            smi, idv, scores, _ = ask(srv, b"many", b"k", q, 3, 0.0, fp)
+            assert smi[0] == smiles[q] and idv[0] == ids[q] and scores[0] == np.float32(1.0)
+    finally:
+        srv.close()
