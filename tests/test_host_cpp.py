@@ -11,7 +11,7 @@ import time
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "gpusimilarity_amd", "bin")
+BIN = os.environ.get("GSIM_TEST_BIN", os.path.join(ROOT, "gpusimilarity_amd", "bin"))
 GOLD = os.path.join(ROOT, "tests", "golden")
 SOCK = "/tmp/gpusimilarity"
 
