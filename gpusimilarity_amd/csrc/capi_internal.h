@@ -110,6 +110,7 @@ struct Shard {
     uint32_t* d_summ = nullptr; // single-launch path: per-wave checkpoint summaries (16 KB, zero between queries)
     uint32_t* h_done = nullptr; // single-launch path: pinned words, one per pipeline slot (since round 3 only their address is used: "the caller polls the header")
     uint32_t epoch = 0;
+    uint32_t pub_tag = 0;           // the last single launch's FusedArgs::pub_tag
     bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
     uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
     hipEvent_t slot_ev[kPipe] = {}; // recorded behind the last kernel of a synchronous enqueue that is not the single launch's own: its

@@ -182,6 +182,9 @@ int setup_shard(gsim_db* db, Shard& s)
     if (gsim::fused_supported(s.fgeo)) {
         GSIM_HIP(hipMalloc(&s.d_pub, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
         GSIM_HIP(hipMalloc(&s.d_hdr, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
+        // (no launch carries tag 0: a selector never takes what the regions held before their first query for a published list)
+        GSIM_HIP(hipMemset(s.d_pub, 0, gsim::fused_pub_bytes(s.fgeo.nwaves / 4)));
+        GSIM_HIP(hipMemset(s.d_hdr, 0, gsim::fused_hdr_bytes(s.fgeo.nwaves / 4)));
     } else {
         static std::atomic<bool> said{false};
         if (s.geo.lanes_per_row != 0 && !said.exchange(true))

@@ -96,6 +96,15 @@ namespace
 // A synchronous query that does not end in the single launch's self-announcing block is waited for through an event of its
 // own: the stream holds up to kPipe - 1 later queries of a pipelined call, and waiting for IT to drain idled the device between
 // batches of eight (k = 8192 at 1 M rows: 74 us a query for 59 us of kernels).
+// The tag of a launch's published lists (FusedArgs::pub_tag): never 0 (what the regions hold when they are allocated), and its
+// low 26 bits -- the part a header carries -- never 0 either.
+uint32_t next_pub_tag(Shard& s)
+{
+    do s.pub_tag++;
+    while ((s.pub_tag & 0x3FFFFFFu) == 0);
+    return s.pub_tag;
+}
+
 int record_slot_event(Shard& s, uint32_t pipe_slot)
 {
     if (!s.slot_ev[pipe_slot]) GSIM_HIP(hipEventCreateWithFlags(&s.slot_ev[pipe_slot], hipEventDisableTiming));
@@ -211,6 +220,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.done_flag = caller_syncs ? s.h_done + pipe_slot : nullptr; // (non-null = "the caller polls the header")
         f.epoch = ++s.epoch & 0xFFFFFFu;
         if (f.epoch == 0) f.epoch = ++s.epoch & 0xFFFFFFu; // 0: what a clean header holds
+        f.pub_tag = next_pub_tag(s);
         if (caller_syncs) static_cast<gsim_result_header*>(out)->flags = 0;
         const int dbg_on = db->knobs.fused_debug;
         if (dbg_on && !s.d_dbg) GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_dbg), (static_cast<size_t>(s.fgeo.nwaves / 4) * 24 + 8) * 8));
@@ -259,6 +269,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.tickets = s.d_summ + 4096;
         f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
         f.xflags = (static_cast<uint32_t>(db->knobs.fused_flags) & ~4u) | gsim::kFusedPublishOnly;
+        f.pub_tag = next_pub_tag(s);
         if (!s.d_lk) {
             GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_lk), sizeof(gsim::LargeKState)));
             GSIM_HIP(hipMemsetAsync(s.d_lk, 0, sizeof(gsim::LargeKState), s.stream));

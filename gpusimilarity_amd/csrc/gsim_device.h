@@ -103,11 +103,11 @@ constexpr uint32_t kFusedPublishOnly = 2048u; // FusedArgs::xflags: scan + publi
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
 constexpr int kFusedSelectors = 256;        // workgroups of the grid: every one of them ranks its share of the finalists
 constexpr uint32_t kFusedRegion = 4 * kFusedWaveCap; // published entries (16 B each) of one workgroup: its fixed region of the list
-constexpr uint32_t kFusedHeaderBytes = 16;  // per workgroup: {entries | sorted << 31, 0, its end-of-scan report (64-bit key)}
-constexpr uint32_t kFusedArriveWords = 25;  // arrival: 8 group counters (b % 8), 1 top counter, 8 generation words; closing: 8 group tickets -- 128 B apart
+constexpr uint32_t kFusedHeaderBytes = 16;  // per workgroup: {entries | sorted << 31, bucket shift | launch tag << 5 | failed << 31, its end-of-scan report (64-bit key)}
+constexpr uint32_t kFusedArriveWords = 25;  // arrival (publishing launches of large-k queries only: the last workgroup tidies up): 8 group counters (b % 8), 1 top counter, [8 unused]; closing: 8 group tickets -- 128 B apart
 
 struct FusedArgs {
-    void* pub;            // device, nwg regions of kFusedRegion x 16 B {key, cb, 0}: what each workgroup publishes
+    void* pub;            // device, nwg regions of kFusedRegion x 16 B {key, cb, launch tag}: what each workgroup publishes
     void* hdr;            // device, nwg headers of kFusedHeaderBytes
     uint32_t* arrive;     // device, kFusedArriveWords words 128 B apart (zero between queries)
     uint32_t* summ;       // device, nwaves score keys: the waves' in-loop checkpoint summaries (zero between queries)
@@ -118,8 +118,10 @@ struct FusedArgs {
     uint32_t row_base;
     uint32_t* done_flag;  // non-NULL: a synchronous caller polls the result header (in pinned host memory): its flags word carries `epoch` << 8
     uint32_t epoch;
+    uint32_t pub_tag;     // non-zero, new for every launch on this handle: the fourth word of every entry this launch publishes, its low 26
+                          // bits in every header -- readers tell this query's lists from what a region held before (no arrival counter)
     uint32_t wait_ticks;     // bound of the grid-wide wait (100 MHz ticks): a few scan times, see fused_kernel
-    uint32_t xflags;         // 4 = QueryState::gtau was seeded by the sample kernel (a coarse bin); experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints, 1024 = release fence before the closing ticket
+    uint32_t xflags;         // 4 = QueryState::gtau was seeded by the sample kernel (a coarse bin); experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints, 1024 = release fence before the closing ticket, 4096 = the published entries get their tags a few microseconds after the header (drives the selectors' read-again path)
     unsigned long long* dbg; // NULL, or 24 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };
 

@@ -44,14 +44,15 @@ namespace
 //   3. a workgroup that has finished streaming drops what lies below the freshest in-loop threshold and publishes
 //      the rest into ITS OWN fixed region of the list -- no reservation, no exchange before it -- in an order a reader
 //      can stop in: canonical order up to kFusedSortCap rows (a local rank count), bucket order above (a counting
-//      sort by score key >> shift, highest bucket first); its 16-byte header holds the count, the order, the shift
-//      and the workgroup's REPORT, its Mw-th best 64-bit key.  Write-through stores, one wait, a two-level arrival
-//      (a counter per group of workgroups, a top counter, one generation word per group);
-//   4. every workgroup then becomes a selector.  It waits until all have arrived -- the ONE grid-wide wait of the
-//      kernel; bounded by a few scan times of wall clock: on a GPU shared with another queue part of the grid may
-//      not have started while the waiters hold their CUs, the query then goes to the four-kernel pipeline, which
-//      never waits -- and requests, in one round trip, every workgroup's header and the first 16 entries of every
-//      region.  From the reports every selector derives the SAME final threshold (the r-th largest report as a
+//      sort by score key >> shift, highest bucket first); its 16-byte header holds the count, the order, the shift,
+//      the workgroup's REPORT, its Mw-th best 64-bit key -- and the launch's TAG, which every entry carries too.  Write-
+//      through stores and nothing else: no wait for their acknowledgements, no counter -- the header IS the arrival;
+//   4. every workgroup then becomes a selector.  It polls the headers until all 256 carry the launch's tag -- the ONE
+//      grid-wide wait of the kernel; bounded by a few scan times of wall clock: on a GPU shared with another queue part
+//      of the grid may not have started while the waiters hold their CUs, the query then goes to the four-kernel
+//      pipeline, which never waits -- and requests the first 16 entries of a region as soon as its header has shown up
+//      (four regions per load): the lists of the workgroups that finished early are in LDS before the last one has
+//      published.  An entry without the tag was overtaken by its header and is read again.  From the reports every selector derives the SAME final threshold (the r-th largest report as a
 //      64-bit key -- it carries the row index, so it also cuts through groups of equal scores), keeps the published
 //      rows at or above it in LDS (a list is read on, 64 entries at a time, until an entry proves the rest lies below
 //      the threshold) and ranks the rows it owns (hash of the row) -- by counting larger keys, or through a histogram
@@ -583,6 +584,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         sh.fwd_done = 0;
         sh.elected = 0;
         sh.abort = 0;
+        sh.ok = 1u;        // (cleared by a selector wave that gives up waiting or meets a workgroup that failed)
+        sh.repmin = 0ull;  // (the workgroup's report: 0 = it holds fewer than Mw rows)
     }
     if (tid < kFusedCheckpoints) sh.ck_cnt[tid] = 0;
     if (tid == 0 && (fa.xflags & 4u)) {
@@ -695,6 +698,11 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const bool sorted = ntot <= kFusedSortCap;
     const uint32_t Mw = fa.final_keys; // rows a workgroup's report stands for (fused_final_keys)
     const __amdgpu_buffer_rsrc_t hrsrc_w = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
+    const uint32_t tag = fa.pub_tag; // every entry's fourth word: a reader tells this launch's entries from what the region held before
+    // (GSIM_FUSED_FLAGS=4096, the parity suite's way into the selectors' read-again path: the entries leave with the PREVIOUS
+    // launch's tag and get their own a few microseconds after the header -- every selector meets entries "still on their way")
+    const bool late_tags = (fa.xflags & 4096u) != 0 && !(fa.xflags & kFusedPublishOnly);
+    const uint32_t etag = late_tags ? tag - 1u : tag;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         static_cast<unsigned char*>(fa.pub) + static_cast<size_t>(blockIdx.x) * (kFusedRegion * 16u), 0, kFusedRegion * 16u, 0x00020000);
     const uint32_t mine_n = bad ? 0u : f.staged;
@@ -713,10 +721,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                     pos += (j + 1 < cnt && kk.y > key) ? 1u : 0u;
                 }
             }
-            if (Mw && pos == Mw - 1u) // the workgroup's report: straight into its header (bytes 8..15)
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32)}, hrsrc_w,
-                                                      blockIdx.x * kFusedHeaderBytes + 8u, 0, /*sc1*/ 16);
-            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
+            if (Mw && pos == Mw - 1u) sh.repmin = key; // the workgroup's report (one thread holds it)
+            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], etag};
             __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
         }
     } else {
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             const u64 key = f.skey[i];
             const uint32_t b = (static_cast<uint32_t>(key >> 32) >> shift) - binbase;
             const uint32_t pos = atomicAdd(&sh.hist[b], 1u);
-            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], 0u};
+            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], etag};
             __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
         }
         if (wv == 0 && rb != kFusedBins) {
@@ -812,21 +818,37 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             }
             if (lane == 0) sh.repmin = mth;
         }
-        __syncthreads();
     }
-    // the header: {entries | exact order << 31, bucket shift, report}.  In exact order the report was written above by the
-    // thread that held it -- and not at all when the workgroup holds fewer than Mw rows: the selectors take a report as
-    // present only if entries >= Mw, so a stale one from an earlier query is never read.
+    // The header, ONE 16-byte store: {entries | exact order << 31, bucket shift | the launch's tag << 5 | "this workgroup failed" << 31,
+    // report (0: fewer than Mw rows)}.  It is the workgroup's ARRIVAL: no counter, no wait for the entries' acknowledgements -- a
+    // selector takes a region's header for this query's by the tag and every entry for this query's by ITS tag (an entry that is
+    // still on its way when the header has landed is read again).  Issued behind a barrier: every wave's entry stores are
+    // ahead of it in the memory pipeline (they rarely lose the race), and the LDS store is free for the selectors.
+    __syncthreads();
+    const bool publish_only = (fa.xflags & kFusedPublishOnly) != 0;
     if (tid == 0) {
-        if (sorted) {
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{ntot | 0x80000000u, 0u}, hrsrc_w, blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
-        } else {
-            const u64 rep = sh.repmin;
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ntot, shift, static_cast<uint32_t>(rep), static_cast<uint32_t>(rep >> 32)}, hrsrc_w,
-                                                   blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
+        const u64 rep = sh.repmin;
+        const bool failed = bad || __hip_atomic_load(&sh.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        const uint32_t w1 = shift | ((tag & 0x3FFFFFFu) << 5) | (failed && !publish_only ? 0x80000000u : 0u);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{ntot | (sorted ? 0x80000000u : 0u), w1, static_cast<uint32_t>(rep), static_cast<uint32_t>(rep >> 32)},
+                                               hrsrc_w, blockIdx.x * kFusedHeaderBytes, 0, /*sc1*/ 16);
+        if (!publish_only) { // the selectors' state (first touched behind their next barrier)
+            sh.nfin = 0;
+            sh.nmine = 0;
+            sh.nitems[0] = 0;
+            sh.nitems[1] = 0;
+            sh.repmin = 0ull; // (from here on: the finalists' summed distance from the threshold)
+            sh.tauf = 0ull;
+            sh.cks = 0u;
+            if (bad) atomicOr(&st->redo, kRedoStore);               // (statistics: the closer adds the reasons up; every selector
+            atomicAdd(&st->ncand, static_cast<u64>(sh.nemit));      //  learns of a failure from the headers)
         }
     }
-    if (fa.xflags & kFusedPublishOnly) {
+    if (late_tags) {
+        for (int i = 0; i < 3 + static_cast<int>(blockIdx.x % 3u); i++) __builtin_amdgcn_s_sleep(127);
+        for (uint32_t i = static_cast<uint32_t>(tid); i < ntot; i += kScanBlock) __builtin_amdgcn_raw_buffer_store_b32(tag, rsrc, i * 16u + 12u, 0, /*sc1*/ 16);
+    }
+    if (publish_only) {
         // ... and, when the large-k kernels rank the lists, what the four-kernel pipeline's scan leaves for them: the published
         // rows counted per coarse bin in QueryState::ghist (fused_handoff_kernel and largek_one_block_kernel start from it)
         static_assert(kFusedBins >= static_cast<uint32_t>(kScanBins), "the publish phase's bucket counters double as the coarse histogram");
@@ -837,25 +859,18 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         __syncthreads();
         for (int i = tid; i < kScanBins; i += kScanBlock)
             if (sh.hist[i]) atomicAdd(&st->ghist[i], sh.hist[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries are out
+        __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: its entries (and header parts) are out
-    __syncthreads();
-    if (tid == 0) {
+    if (publish_only && tid == 0) {
         if (bad) atomicOr(&st->redo, kRedoStore);
-        // The arrival, two levels (MI355X_MICROARCH.md "barrier-xcd"): a counter per group of workgroups b % 8 (the XCD a
-        // block lands on, as observed -- only speed depends on it), the group's last arriver adds to the top counter,
-        // the last of those raises one generation word per group.  Every workgroup then polls ITS group's word: 32
-        // pollers per line instead of 256 on every line (a flat count polled by all cost 7-10 us after the last arrival).
+        // A publishing launch counts its workgroups in (nobody waits: the LAST one tidies up), two levels (MI355X_MICROARCH.md
+        // "barrier-xcd"): a counter per group of workgroups b % 8 (the XCD a block lands on, as observed -- only speed depends on
+        // it), the group's last arriver adds to the top counter.
         const uint32_t x = blockIdx.x % 8u;
         const uint32_t group_size = (nwg - x + 7u) / 8u, ngroups = nwg < 8u ? nwg : 8u;
-        const bool publish_only = (fa.xflags & kFusedPublishOnly) != 0;
-        if (publish_only) atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (before the arrival: the next launch sums it up)
+        atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (before the arrival: the next launch sums it up)
         const bool last = atomicAdd(&fa.arrive[x * 32u], 1u) == group_size - 1u && atomicAdd(&fa.arrive[8u * 32u], 1u) == ngroups - 1u;
-        if (last && !publish_only) {
-            for (uint32_t gq = 0; gq < 8u; gq++)
-                __hip_atomic_store(&fa.arrive[(9u + gq) * 32u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!publish_only) atomicAdd(&st->ncand, static_cast<u64>(sh.nemit)); // (statistics: nobody waits for it)
         sh.ticket = last ? 1u : 0u;
     }
     GSIM_STAMP(3);
@@ -898,47 +913,23 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
 
     // ---- 4. select: every workgroup of the grid (fused_supported: at most kFusedSelectors) ------
+    // There is no arrival to wait for: a selector watches the HEADERS.  Thread t looks after (virtual) region t -- wave w after
+    // regions 64 w .. 64 w + 63 -- and polls its header until it carries this launch's tag; as soon as the four regions of a
+    // group (sixteen lanes fetch the first kFusedPrefix entries of one region: 64 lanes = four regions per load) have shown up,
+    // the wave requests their prefixes straight into LDS (global_load_lds, 16 B per lane, no registers).  The prefixes of the
+    // workgroups that finish early arrive while the stragglers are still publishing; behind the last header there is one group's
+    // round trip left (before: every selector waited for a counted arrival and then fetched all 64 KB of prefixes, 4.9 us).
+    // On a GPU this kernel has to itself the wait is the spread of the streaming end times.  When another queue holds part of
+    // the CUs, workgroups of this grid may not have started yet and will not while the waiters keep theirs: after
+    // fa.wait_ticks (a few scan times) without a header the query goes to the classic kernels, which never wait.
     const uint32_t nsel = nwg, r = blockIdx.x;
-    if (wv == 0) {
-        uint32_t ok = 1;
-        // On a GPU this kernel has to itself the wait is the spread of the streaming end times.  When another queue
-        // holds part of the CUs, workgroups of this grid may not have started yet and will not while the waiters keep
-        // theirs: after fa.wait_ticks (a few scan times) without the last arrival the query goes to the classic
-        // kernels, which never wait.
-        const unsigned long long t_wait = wall_clock64();
-        const uint32_t* gen = &fa.arrive[(9u + blockIdx.x % 8u) * 32u];
-        for (uint32_t spins = 0;; spins++) {
-            if (agent_load(gen) != 0) break;
-            __builtin_amdgcn_s_sleep(2);
-            if ((spins & 255u) == 255u && wall_clock64() - t_wait > fa.wait_ticks) {
-                ok = 0;
-                if (lane == 0) atomicOr(&st->redo, kRedoArrivalWait);
-                break;
-            }
-        }
-        if (lane == 0) {
-            sh.ok = (ok && agent_load(&st->redo) == 0) ? 1u : 0u; // (one reader: the value is the same for the whole workgroup)
-            sh.nfin = 0;
-            sh.nmine = 0;
-            sh.nitems[0] = 0;
-            sh.nitems[1] = 0;
-            sh.repmin = 0ull; // (from here on: the finalists' summed distance from the threshold)
-            sh.tauf = 0ull;
-            sh.cks = 0u;
-        }
-    }
-    // (no acquire fence: everything read below was stored write-through and is read with sc1 loads, past the L1)
-    __syncthreads();
-    GSIM_STAMP(4);
-    // ONE round trip: the header of region `tid` and the first kFusedPrefix entries of every region are requested
-    // together, before anything is known about them (regions hold last query's rows beyond their count).  The entries
-    // go straight into LDS (global_load_lds, 16 B per lane, no registers), so that the code that filters them stays
-    // small: it is fetched cold in every launch.  Slot s = 16 g + p of the staging area receives entry (p - g) mod 16
-    // of region g: thread g later walks ITS region's entries, and the rotation spreads the 64 lanes over all banks.
-    // The staging area is the upper half of the finalist array: at most 4096 staged entries become finalists.
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, nwg * (kFusedRegion * 16u), 0x00020000);
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
     constexpr int PL = static_cast<int>(kFusedPrefix);
+    static_assert(kFusedPrefix == 16, "a group = 64 lanes = four regions' prefixes; slot rotation mod 16");
+    // Slot s = 16 g + p of the staging area receives entry (p - g) mod 16 of region g: thread g later walks ITS region's
+    // entries, and the rotation spreads the 64 lanes over all banks.  The staging area is the upper half of the finalist
+    // array: at most 4096 staged entries become finalists.
     u32x4* staging = reinterpret_cast<u32x4*>(&sh.sel.fkey[kFusedFinalLds / 2]);
     // A grid of fewer than 129 workgroups (small tables) leaves threads to spare: S = 2, 4, ... threads share a region,
     // each taking sixteen consecutive entries of it ("virtual region" v = S g + part), so that the requested prefix is
@@ -946,21 +937,48 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     uint32_t lgS = 0;
     while ((nwg << (lgS + 1u)) <= static_cast<uint32_t>(kFusedSelectors)) lgS++;
     const uint32_t my_region = static_cast<uint32_t>(tid) >> lgS, my_part = static_cast<uint32_t>(tid) & ((1u << lgS) - 1u);
-    const u32x4 hd = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, my_region * kFusedHeaderBytes, 0, /*sc1*/ 16); // (zeros past the grid)
+    const uint32_t htag = tag & 0x3FFFFFFu;
+    u32x4 hd{0u, 0u, 0u, 0u}; // (zeros past the grid, and for a header that never came)
     {
         const unsigned char* pubc = static_cast<const unsigned char*>(fa.pub);
-#pragma unroll
-        for (int u = 0; u < PL; u++) {
-            const uint32_t slot = static_cast<uint32_t>(u * kScanBlock + tid);
-            const uint32_t v = slot / kFusedPrefix, j = (slot - v) % kFusedPrefix; // virtual region, entry inside it
-            const uint32_t gi = v >> lgS, ent = ((v & ((1u << lgS) - 1u)) * kFusedPrefix) + j;
-            if (gi < nwg)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*) (pubc + static_cast<size_t>(gi) * (kFusedRegion * 16u) + ent * 16u),
-                    (__attribute__((address_space(3))) void*) (staging + u * kScanBlock + wv * 64), 16, 0, /*sc1*/ 16);
+        bool pend = my_region < nwg;
+        u64 issued = 0; // bit 4 u: the prefixes of this wave's group u have been requested
+        const unsigned long long t_wait = wall_clock64();
+        for (uint32_t spins = 0;; spins++) {
+            if (pend) {
+                const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, my_region * kFusedHeaderBytes, 0, /*sc1*/ 16);
+                if (((h.y >> 5) & 0x3FFFFFFu) == htag) {
+                    hd = h;
+                    pend = false;
+                }
+            }
+            const u64 pm = __ballot(pend);
+            u64 any4 = pm | (pm >> 1);
+            any4 |= any4 >> 2; // bit 4 u: one of lanes 4 u .. 4 u + 3 still waits for its header
+            u64 todo = ~any4 & 0x1111111111111111ull & ~issued;
+            issued |= todo;
+            while (todo) {
+                const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_ctzll(todo) >> 2)));
+                todo &= todo - 1ull;
+                const uint32_t v = static_cast<uint32_t>(wv) * 64u + 4u * u + (static_cast<uint32_t>(lane) >> 4); // virtual region of this lane's entry
+                const uint32_t gi = v >> lgS, ent = ((v & ((1u << lgS) - 1u)) * kFusedPrefix) + ((static_cast<uint32_t>(lane) - v) & (kFusedPrefix - 1u));
+                if (gi < nwg)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*) (pubc + static_cast<size_t>(gi) * (kFusedRegion * 16u) + ent * 16u),
+                        (__attribute__((address_space(3))) void*) (staging + (static_cast<uint32_t>(wv) * 64u + 4u * u) * kFusedPrefix), 16, 0, /*sc1*/ 16);
+            }
+            if (pm == 0) break;
+            if ((spins & 63u) == 63u && wall_clock64() - t_wait > fa.wait_ticks) {
+                if (lane == 0) atomicOr(&st->redo, kRedoArrivalWait);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
         }
+        // a header that never came, or one whose workgroup failed (a store that overflowed, an election it gave up waiting for)
+        if (__ballot(pend || (hd.y >> 31) != 0) != 0 && lane == 0) sh.ok = 0u;
     }
-    // (the header was requested first and loads return in order: the election below runs while the prefixes land)
+    GSIM_STAMP(4);
+    // (the election below runs while the last groups' prefixes land)
     const uint32_t n_mine = (hd.x & 0x7FFFFFFFu) < kFusedRegion ? (hd.x & 0x7FFFFFFFu) : kFusedRegion; // entries of region my_region
     const bool sorted_mine = (hd.x >> 31) != 0;
     const u64 rep_mine = (Mw && n_mine >= Mw && my_part == 0) ? ((static_cast<u64>(hd.w) << 32) | hd.z) : 0ull; // (one thread per region holds its report)
@@ -1030,6 +1048,31 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         u32x4 ev[PL];
 #pragma unroll
         for (int j = 0; j < PL; j++) ev[j] = staging[g16 + ((static_cast<uint32_t>(j) + static_cast<uint32_t>(tid)) % kFusedPrefix)];
+        {
+            // An entry that does not carry this launch's tag was overtaken by its header: read again, from memory, until it has
+            // landed (its store was issued before the header's: a matter of a fraction of a microsecond, and rare).
+            auto stale = [&]() -> uint32_t {
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < PL; j++) m |= (static_cast<uint32_t>(j) < npre && ev[j].w != tag) ? (1u << j) : 0u;
+                return m;
+            };
+            uint32_t stm = stale();
+            if (__ballot(stm != 0u) != 0) {
+                const unsigned long long t_wait = wall_clock64();
+                const uint32_t base = my_region * (kFusedRegion * 16u) + first * 16u;
+                do {
+#pragma unroll
+                    for (int j = 0; j < PL; j++)
+                        if ((stm >> j) & 1u) ev[j] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, base + static_cast<uint32_t>(j) * 16u, 0, /*sc1*/ 16);
+                    stm = stale();
+                    if (wall_clock64() - t_wait > fa.wait_ticks) { // (never seen: the publisher is gone)
+                        if (stm) sh.ok = 0u;
+                        break;
+                    }
+                } while (__ballot(stm != 0u) != 0);
+            }
+        }
         uint32_t passm = 0, stopm = 0; // bit j: entry j is a finalist / ends the list's part at or above the threshold
 #pragma unroll
         for (int j = 0; j < PL; j++) {
@@ -1113,7 +1156,19 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
 #pragma unroll
                 for (int u = 0; u < IF; u++) {
                     const bool in = ((lim >> u) & 1u) != 0;
-                    take(in, x[u]);
+                    if (__ballot(in && x[u].w != tag) != 0) { // entries overtaken by their header (see the prefixes): read again
+                        const unsigned long long t_wait = wall_clock64();
+                        const uint32_t start = ((itm[u] >> 8) & 0x1FFu) * 16u;
+                        do {
+                            if (in && x[u].w != tag)
+                                x[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, (itm[u] & 0xFFu) * (kFusedRegion * 16u) + (start + static_cast<uint32_t>(lane)) * 16u, 0, /*sc1*/ 16);
+                            if (wall_clock64() - t_wait > fa.wait_ticks) {
+                                if (in && x[u].w != tag) sh.ok = 0u;
+                                break;
+                            }
+                        } while (__ballot(in && x[u].w != tag) != 0);
+                    }
+                    take(in && x[u].w == tag, x[u]);
                     if (i0 + 4u * static_cast<uint32_t>(u) < nit && (itm[u] >> 23) != 0) { // (wave-uniform) the region's last item of this round
                         const uint32_t reg = itm[u] & 0xFFu, rnv = sh.rn[reg];
                         const uint32_t n_g = rnv & 0xFFFFu, end = ((itm[u] >> 8) & 0x1FFu) * 16u + ((itm[u] >> 17) & 63u) + 1u;
@@ -1141,6 +1196,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     __syncthreads();
     const uint32_t nfin = sh.nfin;
     uint32_t cks = 0; // sum of the words of the hits this thread writes (the block's checksum, see kBlockCheckMul)
+    good = good && sh.ok != 0; // (an entry that never arrived)
     uint32_t why = good ? 0u : kRedoSeen;
     if (good && nfin > static_cast<uint32_t>(kFusedFinalLds)) why = kRedoFinalists;
     good = good && nfin <= static_cast<uint32_t>(kFusedFinalLds);

@@ -264,3 +264,45 @@ t.close()
         env = hooks_env(GSIM_TEST_TORN_EVERY=hook, WANT_TORN=str(want_torn))
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
         assert out.returncode == 0, out.stdout.decode()[-1500:] + out.stderr.decode()[-3000:]
+
+
+def test_entries_that_arrive_after_their_header_are_read_again():
+    """The single launch has no arrival counter: a region's header carries the launch's tag and is the workgroup's arrival,
+    every entry carries the tag too, and a selector that meets an entry without it -- the header overtook it -- reads it
+    again.  On an idle GPU the entries win the race; GSIM_FUSED_FLAGS=4096 (read once per handle, hence the child process)
+    makes every workgroup publish its entries with the PREVIOUS launch's tag and hand the real one in 10-17 us after
+    the header, so that every selector goes through the read-again path for the prefixes (k = 10 ... 1000) and for the
+    lists read beyond them (k = 8192, Morgan-shaped rows); grids with several threads per region (small tables) included.
+    Every result equals the oracle's and nothing is handed back."""
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_lib as O
+from gpusimilarity_amd import capi
+for n, W, kind in ((700_001, 32, 0), (40_000, 32, 0), (300_000, 32, 2), (900_000, 8, 0)):
+    db = O.synth_rows_mt(0x7A65 + n, kind, 0, n, W)
+    t = capi.Table(32 * W).add_rows(db).finalize(0, 1)
+    t.enable_timing(True)
+    qs = np.ascontiguousarray(np.stack([db[O.query_row(i, n)] for i in range(12)]))
+    for k in (10, 1000, 8192):
+        bufs = t.make_search_buffers(len(qs), k)
+        t.search_each_into(qs, k, bufs)            # pipelined: eight in flight, consecutive tags
+        for i in range(len(qs)):
+            want, wap = O.search(qs[i], db, k, 0.0, nthreads=8)
+            got = bufs[0][i, :bufs[1][i]]
+            assert int(bufs[2][i]) == wap and (got["row"] == want["row"]).all(), (n, W, k, i)
+            assert (got["score"].view(np.uint32) == want["score"].view(np.uint32)).all()
+            assert (got["common"] == want["common"]).all() and (got["popc_db"] == want["popc_db"]).all()
+        h, ap = t.search(qs[3], k, 0.0)             # one at a time
+        want, wap = O.search(qs[3], db, k, 0.0, nthreads=8)
+        assert (h[0]["row"] == want["row"]).all()
+    tm = t.timing()
+    if W >= 32 and kind == 0:
+        assert tm["handed_back"] == 0, tm
+    t.close()
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, GSIM_FUSED_FLAGS="4096", GSIM_FUSED_SELECT_MAX_K="8192")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0 and b"ok" in out.stdout, out.stdout.decode()[-1500:] + out.stderr.decode()[-3000:]
