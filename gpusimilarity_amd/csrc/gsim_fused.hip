@@ -68,8 +68,11 @@ namespace
 // four-kernel pipeline then runs the query.
 constexpr int kFusedFinalLds = 16384;   // finalists a selector ranks (LDS)
 constexpr int kFusedMineCap = 2048;     // ... of which it owns at most this many
-constexpr int kFusedBlock = kScanBlock + 128; // four streaming waves + two service waves (forwarder, poller/elector)
-constexpr uint32_t kFusedPrefix = 16;   // entries of every region a selector requests before it knows the region's count
+constexpr int kFusedBlock = 2 * kScanBlock; // four streaming waves, two service waves (forwarder, poller/elector) and two that only wait: all
+                                            // EIGHT are selectors -- the phases behind the scan are bound by instruction issue and LDS
+                                            // round trips, and a SIMD with two waves issues while one of them waits
+constexpr uint32_t kFusedPrefix = 8;    // entries of a region ONE thread takes before the region's count is known (two threads per region on
+                                        // a full grid: sixteen entries of every region are requested)
 constexpr uint32_t kFusedSortCap = 128; // a workgroup with up to this many rows publishes them in canonical order (the count is
                                         // quadratic: 256 rows that all sit in one wave's store cost 10 us); more: in bucket order
 constexpr uint32_t kFusedItems = 1024;  // 64-entry reads beyond the prefixes a selector lists per round (at most 4 per region)
@@ -121,7 +124,7 @@ struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
         struct {                        // selectors, ranking many finalists by bucket:
             uint32_t hist[kFusedBins];  //   finalists per bucket of the 64-bit key, then the finalists in higher buckets
             uint32_t head[kFusedBins];  //   the first of this selector's rows in the bucket (+ 1); they are chained
-            uint32_t queue[kScanBlock / 64][128]; // per wave: (finalist, row of this selector in its bucket) pairs to compare
+            uint32_t queue[kFusedBlock / 64][128]; // per wave: (finalist, row of this selector in its bucket) pairs to compare
         } rk;
     };
 };
@@ -607,18 +610,18 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t CHR = LPR > 0 ? static_cast<uint32_t>(U * (64 / (LPR > 0 ? LPR : 1))) : g.chunk_rows; // rows per chunk (trip)
     const u64 nfull = a.nrows / CHR;    // full chunks
     sched.init(static_cast<uint32_t>(nfull / g.nwaves));
-    if (wv == kScanBlock / 64) {
-        fused_forwarder(sh, fa, sched, lane);
-        return;
-    }
-    if (wv == kScanBlock / 64 + 1) {
-        fused_poller(sh, st, fa, sched, g.nwaves, a.k, lane, dbg);
-        return;
-    }
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + wv);
+    // Waves 4 .. 7 do not stream: the forwarder, the poller, and two that have nothing to do until the scan is over (they wait at
+    // the barrier behind it and cost the streaming waves no issue slot).  A publishing launch (large k) has no selection: they
+    // leave when their service is done, as they always did.
+    const bool helper = wv >= kScanBlock / 64;
+    if (wv == kScanBlock / 64) fused_forwarder(sh, fa, sched, lane);
+    if (wv == kScanBlock / 64 + 1) fused_poller(sh, st, fa, sched, g.nwaves, a.k, lane, dbg);
+    if (helper && (fa.xflags & kFusedPublishOnly)) return;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * (kScanBlock / 64) + (helper ? 0 : wv));
     const uint32_t nwg = gridDim.x;
 
-    FusedFilter f;
+    FusedFilter f{};
+    if (!helper) {
     f.sh = &sh;
     f.st = st;
     f.skey = sh.store.key[wv];
@@ -679,7 +682,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         sh.wcount[wv] = f.store_off ? 0u : f.staged;
         if (f.emitted) atomicAdd(&sh.nemit, f.emitted);
     }
-    __syncthreads(); // (released once the service waves have exited too)
+    } // (!helper)
+    __syncthreads(); // (released once the service waves are here too)
     GSIM_STAMP(2);
     const bool bad = __hip_atomic_load(&sh.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
     uint32_t ntot = 0;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t etag = late_tags ? tag - 1u : tag;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         static_cast<unsigned char*>(fa.pub) + static_cast<size_t>(blockIdx.x) * (kFusedRegion * 16u), 0, kFusedRegion * 16u, 0x00020000);
-    const uint32_t mine_n = bad ? 0u : f.staged;
+    const uint32_t mine_n = (bad || helper) ? 0u : f.staged; // (the waves that did not stream take part in the barriers only)
     uint32_t shift = 0;
     if (sorted) {
         for (uint32_t i = lane; i < mine_n; i += 64) {
@@ -715,10 +719,15 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
                 const uint32_t cnt = sh.wcount[w2];
                 const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.store.key[w2]);
-                for (uint32_t j = 0; j < cnt; j += 2) {
-                    const ulonglong2 kk = k2[j >> 1];
-                    pos += kk.x > key ? 1u : 0u;
-                    pos += (j + 1 < cnt && kk.y > key) ? 1u : 0u;
+                for (uint32_t j = 0; j < cnt; j += 8) { // (four reads in flight: one at a time, a round trip each, cost 1.5 us)
+                    ulonglong2 kk[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) kk[u] = k2[(j + 2u * u < cnt ? j + 2u * u : j) >> 1];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        pos += (j + 2u * u < cnt && kk[u].x > key) ? 1u : 0u;
+                        pos += (j + 2u * u + 1u < cnt && kk[u].y > key) ? 1u : 0u;
+                    }
                 }
             }
             if (Mw && pos == Mw - 1u) sh.repmin = key; // the workgroup's report (one thread holds it)
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     if (late_tags) {
         for (int i = 0; i < 3 + static_cast<int>(blockIdx.x % 3u); i++) __builtin_amdgcn_s_sleep(127);
-        for (uint32_t i = static_cast<uint32_t>(tid); i < ntot; i += kScanBlock) __builtin_amdgcn_raw_buffer_store_b32(tag, rsrc, i * 16u + 12u, 0, /*sc1*/ 16);
+        for (uint32_t i = static_cast<uint32_t>(tid); i < ntot; i += kFusedBlock) __builtin_amdgcn_raw_buffer_store_b32(tag, rsrc, i * 16u + 12u, 0, /*sc1*/ 16);
     }
     if (publish_only) {
         // ... and, when the large-k kernels rank the lists, what the four-kernel pipeline's scan leaves for them: the published
@@ -884,7 +893,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         }
         uint4* sm = reinterpret_cast<uint4*>(fa.summ); // (16-byte stores)
         const uint32_t n16 = (g.nwaves + 3) / 4;
-        for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0};
+        for (uint32_t i = tid; i < n16; i += kScanBlock) sm[i] = uint4{0, 0, 0, 0}; // (the selectors' waves 4 .. 7 repeat some: zeros)
     };
     if (fa.xflags & kFusedPublishOnly) {
         // k above kFusedMaxK: the scan and its thresholds are this launch's, the ranking is the large-k kernels' (they are sized by
@@ -913,10 +922,11 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
 
     // ---- 4. select: every workgroup of the grid (fused_supported: at most kFusedSelectors) ------
-    // There is no arrival to wait for: a selector watches the HEADERS.  Thread t looks after (virtual) region t -- wave w after
-    // regions 64 w .. 64 w + 63 -- and polls its header until it carries this launch's tag; as soon as the four regions of a
-    // group (sixteen lanes fetch the first kFusedPrefix entries of one region: 64 lanes = four regions per load) have shown up,
-    // the wave requests their prefixes straight into LDS (global_load_lds, 16 B per lane, no registers).  The prefixes of the
+    // There is no arrival to wait for: a selector watches the HEADERS.  Thread t looks after virtual region t (on a full grid:
+    // entries 0 .. 7 or 8 .. 15 of region t / 2) -- wave w after virtual regions 64 w .. 64 w + 63 -- and polls its region's
+    // header until it carries this launch's tag; as soon as the eight virtual regions of a group (eight lanes fetch the
+    // kFusedPrefix entries of one: 64 lanes = eight per load) have shown up, the wave requests their entries straight into LDS
+    // (global_load_lds, 16 B per lane, no registers).  The prefixes of the
     // workgroups that finish early arrive while the stragglers are still publishing; behind the last header there is one group's
     // round trip left (before: every selector waited for a counted arrival and then fetched all 64 KB of prefixes, 4.9 us).
     // On a GPU this kernel has to itself the wait is the spread of the streaming end times.  When another queue holds part of
@@ -926,23 +936,23 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(fa.pub, 0, nwg * (kFusedRegion * 16u), 0x00020000);
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(fa.hdr, 0, nwg * kFusedHeaderBytes, 0x00020000);
     constexpr int PL = static_cast<int>(kFusedPrefix);
-    static_assert(kFusedPrefix == 16, "a group = 64 lanes = four regions' prefixes; slot rotation mod 16");
-    // Slot s = 16 g + p of the staging area receives entry (p - g) mod 16 of region g: thread g later walks ITS region's
+    static_assert(kFusedPrefix == 8, "a group = 64 lanes = eight virtual regions' entries; slot rotation mod 8");
+    // Slot s = 8 g + p of the staging area receives entry (p - g) mod 8 of virtual region g: thread g later walks ITS
     // entries, and the rotation spreads the 64 lanes over all banks.  The staging area is the upper half of the finalist
     // array: at most 4096 staged entries become finalists.
     u32x4* staging = reinterpret_cast<u32x4*>(&sh.sel.fkey[kFusedFinalLds / 2]);
-    // A grid of fewer than 129 workgroups (small tables) leaves threads to spare: S = 2, 4, ... threads share a region,
-    // each taking sixteen consecutive entries of it ("virtual region" v = S g + part), so that the requested prefix is
-    // 16 S entries -- the finalists per region grow as the grid shrinks.
-    uint32_t lgS = 0;
-    while ((nwg << (lgS + 1u)) <= static_cast<uint32_t>(kFusedSelectors)) lgS++;
+    // S = 2 threads share a region on a full grid, S = 4, 8, ... on a grid of fewer than 129 workgroups (small tables), each
+    // taking eight consecutive entries of it ("virtual region" v = S g + part), so that the requested prefix is 8 S entries --
+    // the finalists per region grow as the grid shrinks.
+    uint32_t lgS = 1;
+    while ((nwg << (lgS + 1u)) <= static_cast<uint32_t>(kFusedBlock)) lgS++;
     const uint32_t my_region = static_cast<uint32_t>(tid) >> lgS, my_part = static_cast<uint32_t>(tid) & ((1u << lgS) - 1u);
     const uint32_t htag = tag & 0x3FFFFFFu;
     u32x4 hd{0u, 0u, 0u, 0u}; // (zeros past the grid, and for a header that never came)
     {
         const unsigned char* pubc = static_cast<const unsigned char*>(fa.pub);
         bool pend = my_region < nwg;
-        u64 issued = 0; // bit 4 u: the prefixes of this wave's group u have been requested
+        u64 issued = 0; // bit 8 u: the entries of this wave's group u have been requested
         const unsigned long long t_wait = wall_clock64();
         for (uint32_t spins = 0;; spins++) {
             if (pend) {
@@ -953,19 +963,20 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 }
             }
             const u64 pm = __ballot(pend);
-            u64 any4 = pm | (pm >> 1);
-            any4 |= any4 >> 2; // bit 4 u: one of lanes 4 u .. 4 u + 3 still waits for its header
-            u64 todo = ~any4 & 0x1111111111111111ull & ~issued;
+            u64 any8 = pm | (pm >> 1);
+            any8 |= any8 >> 2;
+            any8 |= any8 >> 4; // bit 8 u: one of lanes 8 u .. 8 u + 7 still waits for its header
+            u64 todo = ~any8 & 0x0101010101010101ull & ~issued;
             issued |= todo;
             while (todo) {
-                const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_ctzll(todo) >> 2)));
+                const uint32_t u = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_ctzll(todo) >> 3)));
                 todo &= todo - 1ull;
-                const uint32_t v = static_cast<uint32_t>(wv) * 64u + 4u * u + (static_cast<uint32_t>(lane) >> 4); // virtual region of this lane's entry
+                const uint32_t v = static_cast<uint32_t>(wv) * 64u + 8u * u + (static_cast<uint32_t>(lane) >> 3); // virtual region of this lane's entry
                 const uint32_t gi = v >> lgS, ent = ((v & ((1u << lgS) - 1u)) * kFusedPrefix) + ((static_cast<uint32_t>(lane) - v) & (kFusedPrefix - 1u));
                 if (gi < nwg)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*) (pubc + static_cast<size_t>(gi) * (kFusedRegion * 16u) + ent * 16u),
-                        (__attribute__((address_space(3))) void*) (staging + (static_cast<uint32_t>(wv) * 64u + 4u * u) * kFusedPrefix), 16, 0, /*sc1*/ 16);
+                        (__attribute__((address_space(3))) void*) (staging + (static_cast<uint32_t>(wv) * 64u + 8u * u) * kFusedPrefix), 16, 0, /*sc1*/ 16);
             }
             if (pm == 0) break;
             if ((spins & 63u) == 63u && wall_clock64() - t_wait > fa.wait_ticks) {
@@ -982,25 +993,34 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t n_mine = (hd.x & 0x7FFFFFFFu) < kFusedRegion ? (hd.x & 0x7FFFFFFFu) : kFusedRegion; // entries of region my_region
     const bool sorted_mine = (hd.x >> 31) != 0;
     const u64 rep_mine = (Mw && n_mine >= Mw && my_part == 0) ? ((static_cast<u64>(hd.w) << 32) | hd.z) : 0ull; // (one thread per region holds its report)
-    sh.sel.u.rep[tid] = rep_mine;
+    if (my_part == 0) sh.sel.u.rep[my_region] = rep_mine;
+    if (static_cast<uint32_t>(tid) >= (static_cast<uint32_t>(kFusedBlock) >> lgS) && tid < kFusedSelectors) sh.sel.u.rep[tid] = 0ull; // (past the grid)
     __syncthreads(); // the reports of all regions
     const bool good0 = sh.ok != 0; // (not good: headers and regions may be stale -- nothing below is used, the query is handed back)
     // The final threshold: the r-th largest of the workgroups' reports, r = ceil(k / Mw).  Each of the r largest
     // reports stands for Mw distinct rows at or above it in the canonical order, so at least k rows are at or above
     // the r-th largest: no row of the top k lies below it.  The keys carry the row index: the threshold also cuts
-    // through a group of equal scores.  Every thread ranks its region's report by counting larger ones (256 broadcast
-    // reads); the thread whose report has rank r - 1 publishes it.  Every selector finds the same value.
+    // through a group of equal scores.  A region's first two threads (neighbouring lanes) rank its report by counting larger
+    // ones, half of the reports each (broadcast reads); the thread whose report has rank r - 1 publishes it.  Every selector
+    // finds the same value.
     if (good0 && Mw) {
         const uint32_t rr = (a.k + Mw - 1u) / Mw;
-        const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(sh.sel.u.rep);
+        // (the region's second thread gets the report from the first: lanes 2 m and 2 m + 1, since S is even)
+        const uint32_t nlo = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(rep_mine)), lane & ~1, 64));
+        const uint32_t nhi = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(rep_mine >> 32)), lane & ~1, 64));
+        const u64 rep_reg = my_part == 1 ? ((static_cast<u64>(nhi) << 32) | nlo) : rep_mine;
+        const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(sh.sel.u.rep) + (my_part & 1u) * (kFusedSelectors / 4);
         uint32_t rank = 0;
+        if (my_part < 2) {
 #pragma unroll 8
-        for (int j = 0; j < kFusedSelectors / 2; j++) {
-            const ulonglong2 kk = r2[j];
-            rank += kk.x > rep_mine ? 1u : 0u;
-            rank += kk.y > rep_mine ? 1u : 0u;
+            for (int j = 0; j < kFusedSelectors / 4; j++) {
+                const ulonglong2 kk = r2[j];
+                rank += kk.x > rep_reg ? 1u : 0u;
+                rank += kk.y > rep_reg ? 1u : 0u;
+            }
         }
-        if (rep_mine != 0ull && rank == rr - 1u) sh.tauf = rep_mine;
+        rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), 1, 64));
+        if (my_part == 0 && rep_mine != 0ull && rank == rr - 1u) sh.tauf = rep_mine;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's part of the prefixes is in LDS
     __syncthreads();                                 // ... and everybody's; the threshold is known
@@ -1126,12 +1146,13 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     {
         // Lists read beyond their prefix (a large k, series of analogs in neighbouring rows, ties), in rounds.  An item is 64
-        // entries of one region (one per lane); every wave takes every fourth item of the round's list, eight at a time
-        // with the eight loads in flight together: 32 items per round trip, whichever regions they belong to.  A region's
+        // entries of one region (one per lane); every wave takes every eighth item of the round's list, eight at a time
+        // with the eight loads in flight together: 64 items per round trip, whichever regions they belong to.  A region's
         // last item of a round, if it holds no entry that ends the list, lists the region's items of the next round:
         // as many entries again as have been read beyond the prefix, at most 4 items (the list holds 4 per region).
         // item = region | first entry / 16 << 8 | (entries - 1) << 17 | last of its region << 23.
         constexpr int IF = 8;
+        constexpr uint32_t NW = kFusedBlock / 64; // waves
 #pragma unroll 1
         for (uint32_t round = 0;; round++) {
             if (tid == 0) sh.nitems[(round + 2u) % 4u] = 0; // (last read two rounds ago -- every wave is past that --, appended to in the next round)
@@ -1141,13 +1162,13 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             const uint32_t* cur = sh.items[round & 1u];
             uint32_t* nxt = sh.items[(round + 1u) & 1u];
 #pragma unroll 1
-            for (uint32_t i0 = static_cast<uint32_t>(wv); i0 < nit; i0 += 4u * IF) {
+            for (uint32_t i0 = static_cast<uint32_t>(wv); i0 < nit; i0 += NW * IF) {
                 u32x4 x[IF];
                 uint32_t itm[IF];
                 uint32_t lim = 0;
 #pragma unroll
                 for (int u = 0; u < IF; u++) {
-                    const uint32_t idx = i0 + 4u * static_cast<uint32_t>(u);
+                    const uint32_t idx = i0 + NW * static_cast<uint32_t>(u);
                     itm[u] = cur[idx < nit ? idx : i0]; // (past the list: this wave's first item again, not taken)
                     const uint32_t start = ((itm[u] >> 8) & 0x1FFu) * 16u, cnt = ((itm[u] >> 17) & 63u) + 1u;
                     lim |= (idx < nit && static_cast<uint32_t>(lane) < cnt) ? (1u << u) : 0u;
@@ -1169,7 +1190,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                         } while (__ballot(in && x[u].w != tag) != 0);
                     }
                     take(in && x[u].w == tag, x[u]);
-                    if (i0 + 4u * static_cast<uint32_t>(u) < nit && (itm[u] >> 23) != 0) { // (wave-uniform) the region's last item of this round
+                    if (i0 + NW * static_cast<uint32_t>(u) < nit && (itm[u] >> 23) != 0) { // (wave-uniform) the region's last item of this round
                         const uint32_t reg = itm[u] & 0xFFu, rnv = sh.rn[reg];
                         const uint32_t n_g = rnv & 0xFFFFu, end = ((itm[u] >> 8) & 0x1FFu) * 16u + ((itm[u] >> 17) & 63u) + 1u;
                         const u64 key = (static_cast<u64>(x[u].y) << 32) | x[u].x;
@@ -1238,7 +1259,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                                     (static_cast<u64>(wave_sum(static_cast<uint32_t>(dacc >> 32) & 0xFFFFu)) << 32);
                     if (lane == 0) atomicAdd(&sh.repmin, tot); // (zero since the selectors' start)
                 }
-                for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kScanBlock) { // (the items are done with)
+                for (uint32_t i = static_cast<uint32_t>(tid); i < kFusedBins; i += kFusedBlock) { // (the items are done with)
                     sh.rk.hist[i] = 0;
                     sh.rk.head[i] = 0;
                 }
@@ -1253,7 +1274,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 };
                 // node t, 16 bytes from the array's end downwards: {the row's key, the bucket's next row + 1, larger keys in the bucket}
                 u32x4* nodes = reinterpret_cast<u32x4*>(&sh.sel.fkey[kFusedFinalLds]);
-                for (uint32_t t = static_cast<uint32_t>(tid); t < nmine; t += kScanBlock) {
+                for (uint32_t t = static_cast<uint32_t>(tid); t < nmine; t += kFusedBlock) {
                     const u64 key = sh.sel.fkey[sh.sel.u.mine.idx[t]];
                     const uint32_t before = atomicExch(&sh.rk.head[bucket(key)], t + 1u);
                     *(nodes - 1 - static_cast<int>(t)) = u32x4{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), before, 0u};
@@ -1285,7 +1306,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                             __builtin_amdgcn_wave_barrier();
                         }
                     };
-                    for (uint32_t j0 = static_cast<uint32_t>(wv) * 64u; j0 < nfin; j0 += kScanBlock) {
+                    for (uint32_t j0 = static_cast<uint32_t>(wv) * 64u; j0 < nfin; j0 += kFusedBlock) {
                         const uint32_t j = j0 + static_cast<uint32_t>(lane);
                         uint32_t at = 0;
                         if (j < nfin) {
@@ -1325,7 +1346,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                     }
                 }
                 __syncthreads();
-                for (uint32_t t = static_cast<uint32_t>(tid); t < nmine; t += kScanBlock) {
+                for (uint32_t t = static_cast<uint32_t>(tid); t < nmine; t += kFusedBlock) {
                     const u32x4 node = *(nodes - 1 - static_cast<int>(t));
                     const u64 mine = (static_cast<u64>(node.y) << 32) | node.x;
                     const uint32_t rank = sh.rk.hist[bucket(mine)] + node.w;
@@ -1338,7 +1359,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             // (ds_read_b128, two keys per read, several reads in flight), then a shuffle sum
             constexpr int RG = 16;
             const uint32_t sub = static_cast<uint32_t>(tid % RG);
-            for (uint32_t t0 = 0; t0 < nmine && !by_bucket; t0 += kScanBlock / RG) {
+            for (uint32_t t0 = 0; t0 < nmine && !by_bucket; t0 += kFusedBlock / RG) {
                 const uint32_t t = t0 + static_cast<uint32_t>(tid / RG);
                 const bool have = t < nmine;
                 const u64 mine = have ? sh.sel.fkey[sh.sel.u.mine.idx[t]] : ~0ull;
