@@ -712,27 +712,58 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     const uint32_t mine_n = (bad || helper) ? 0u : f.staged; // (the waves that did not stream take part in the barriers only)
     uint32_t shift = 0;
     if (sorted) {
-        for (uint32_t i = lane; i < mine_n; i += 64) {
-            const u64 key = f.skey[i];
-            uint32_t pos = 0; // the number of larger keys (keys are unique)
-#pragma unroll 1
-            for (int w2 = 0; w2 < kScanBlock / 64; w2++) {
-                const uint32_t cnt = sh.wcount[w2];
-                const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.store.key[w2]);
-                for (uint32_t j = 0; j < cnt; j += 8) { // (four reads in flight: one at a time, a round trip each, cost 1.5 us)
-                    ulonglong2 kk[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) kk[u] = k2[(j + 2u * u < cnt ? j + 2u * u : j) >> 1];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        pos += (j + 2u * u < cnt && kk[u].x > key) ? 1u : 0u;
-                        pos += (j + 2u * u + 1u < cnt && kk[u].y > key) ? 1u : 0u;
+        // Every live thread takes part, the waves that did not stream too (eight of them, four in a publishing launch): SG lanes
+        // share a row and each counts the larger keys among every SG-th PAIR of every wave's store -- the reads of a store's first
+        // 8 SG entries requested together, the four stores' back to back: one LDS round trip (a lane per row and a read at a time: 2.5 us)
+        // -- then a shuffle sum.  Up to kFusedSortCap rows: one pass of the eight waves.
+        constexpr uint32_t SG = 4;
+        const uint32_t nthr = (fa.xflags & kFusedPublishOnly) ? static_cast<uint32_t>(kScanBlock) : static_cast<uint32_t>(kFusedBlock);
+        const uint32_t c0 = sh.wcount[0], c1 = sh.wcount[1], c2 = sh.wcount[2];
+        const uint32_t sub = static_cast<uint32_t>(tid) % SG;
+        for (uint32_t r0 = 0; r0 < ntot; r0 += nthr / SG) { // (ntot = 0 when a store overflowed)
+            const uint32_t rho = r0 + static_cast<uint32_t>(tid) / SG;
+            const bool have = rho < ntot;
+            uint32_t w2 = 0, i = have ? rho : 0u; // row rho of the workgroup = row i of wave w2's store
+            if (have && i >= c0) {
+                i -= c0;
+                w2 = 1;
+                if (i >= c1) {
+                    i -= c1;
+                    w2 = 2;
+                    if (i >= c2) {
+                        i -= c2;
+                        w2 = 3;
                     }
                 }
             }
-            if (Mw && pos == Mw - 1u) sh.repmin = key; // the workgroup's report (one thread holds it)
-            const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), f.scb[i], etag};
-            __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
+            const u64 key = have ? sh.store.key[w2][i] : ~0ull;
+            uint32_t pos = 0; // the number of larger keys (keys are unique)
+#pragma unroll
+            for (int v = 0; v < kScanBlock / 64; v++) {
+                const uint32_t cnt = sh.wcount[v], npair = (cnt + 1u) >> 1;
+                const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.store.key[v]);
+                ulonglong2 kk[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) kk[u] = k2[sub + SG * u < npair ? sub + SG * u : 0u];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t j = sub + SG * u;
+                    pos += (2u * j < cnt && kk[u].x > key) ? 1u : 0u;
+                    pos += (2u * j + 1u < cnt && kk[u].y > key) ? 1u : 0u;
+                }
+                for (uint32_t j = sub + SG * 4u; j < npair; j += SG) { // (a store of more than 32 rows: the rest, a read at a time)
+                    const ulonglong2 k1 = k2[j];
+                    pos += k1.x > key ? 1u : 0u;
+                    pos += (2u * j + 1u < cnt && k1.y > key) ? 1u : 0u;
+                }
+            }
+            pos += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pos), 1, 64));
+            pos += static_cast<uint32_t>(__shfl_xor(static_cast<int>(pos), 2, 64));
+            if (have && sub == 0) {
+                if (Mw && pos == Mw - 1u) sh.repmin = key; // the workgroup's report (one thread holds it)
+                const u32x4 e{static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), sh.store.cb[w2][i], etag};
+                __builtin_amdgcn_raw_buffer_store_b128(e, rsrc, pos * 16u, 0, /*sc1: write-through*/ 16);
+            }
         }
     } else {
         { // the range of the workgroup's score keys; the buckets' counters
@@ -1357,10 +1388,11 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(sh.sel.fkey);
             // RG lanes share one row: each counts the larger keys among every RG-th pair
             // (ds_read_b128, two keys per read, several reads in flight), then a shuffle sum
-            constexpr int RG = 16;
-            const uint32_t sub = static_cast<uint32_t>(tid % RG);
+            // (a selector owns ~k / 256 of the finalists: with few of them a whole wave shares a row, so that all eight waves work)
+            const uint32_t RG = nmine <= static_cast<uint32_t>(kFusedBlock) / 64u ? 64u : (nmine <= static_cast<uint32_t>(kFusedBlock) / 32u ? 32u : 16u);
+            const uint32_t sub = static_cast<uint32_t>(tid) % RG;
             for (uint32_t t0 = 0; t0 < nmine && !by_bucket; t0 += kFusedBlock / RG) {
-                const uint32_t t = t0 + static_cast<uint32_t>(tid / RG);
+                const uint32_t t = t0 + static_cast<uint32_t>(tid) / RG;
                 const bool have = t < nmine;
                 const u64 mine = have ? sh.sel.fkey[sh.sel.u.mine.idx[t]] : ~0ull;
                 uint32_t rank = 0;
@@ -1378,8 +1410,10 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                         rank += (in && kk[u].y > mine) ? 1u : 0u;
                     }
                 }
+                if (RG > 32u) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), 32, 64));
+                if (RG > 16u) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), 16, 64));
 #pragma unroll
-                for (int d = RG / 2; d > 0; d >>= 1) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), d, 64));
+                for (int d = 8; d > 0; d >>= 1) rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), d, 64));
                 if (have && sub == 0 && rank < a.k) write_hit(mine, rank, sh.sel.u.mine.cb[t]);
             }
         }
