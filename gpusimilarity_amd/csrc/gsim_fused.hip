@@ -110,6 +110,7 @@ struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
     uint32_t wsum[kScanBlock / 64];                 // ... the summaries (each wave's M-th best score key)
     uint32_t wcount[kScanBlock / 64];
     uint32_t nfin, nmine, ok, ticket;
+    uint32_t exact;                 // selectors: no sampled report qualified as the final threshold -- every report is ranked
     uint32_t cks, cks_total;        // selectors: sum of the words of the hits this workgroup wrote / of all hits (the closer)
     uint32_t nitems[4];             // selectors: items listed for round r at [r % 4]
     uint32_t hmin, hmax;            // publish: range of the workgroup's score keys
@@ -880,6 +881,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             sh.repmin = 0ull; // (from here on: the finalists' summed distance from the threshold)
             sh.tauf = 0ull;
             sh.cks = 0u;
+            sh.exact = 0u;
             if (bad) atomicOr(&st->redo, kRedoStore);               // (statistics: the closer adds the reasons up; every selector
             atomicAdd(&st->ncand, static_cast<u64>(sh.nemit));      //  learns of a failure from the headers)
         }
@@ -979,6 +981,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     while ((nwg << (lgS + 1u)) <= static_cast<uint32_t>(kFusedBlock)) lgS++;
     const uint32_t my_region = static_cast<uint32_t>(tid) >> lgS, my_part = static_cast<uint32_t>(tid) & ((1u << lgS) - 1u);
     const uint32_t htag = tag & 0x3FFFFFFu;
+    if (tid < 128) sh.hist[tid] = 0u; // (the publish phase is done with its bucket counters: the election's, see below)
     u32x4 hd{0u, 0u, 0u, 0u}; // (zeros past the grid, and for a header that never came)
     {
         const unsigned char* pubc = static_cast<const unsigned char*>(fa.pub);
@@ -1028,18 +1031,62 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     if (static_cast<uint32_t>(tid) >= (static_cast<uint32_t>(kFusedBlock) >> lgS) && tid < kFusedSelectors) sh.sel.u.rep[tid] = 0ull; // (past the grid)
     __syncthreads(); // the reports of all regions
     const bool good0 = sh.ok != 0; // (not good: headers and regions may be stale -- nothing below is used, the query is handed back)
-    // The final threshold: the r-th largest of the workgroups' reports, r = ceil(k / Mw).  Each of the r largest
-    // reports stands for Mw distinct rows at or above it in the canonical order, so at least k rows are at or above
-    // the r-th largest: no row of the top k lies below it.  The keys carry the row index: the threshold also cuts
-    // through a group of equal scores.  A region's first two threads (neighbouring lanes) rank its report by counting larger
-    // ones, half of the reports each (broadcast reads); the thread whose report has rank r - 1 publishes it.  Every selector
-    // finds the same value.
+    // The final threshold: a report with at least r - 1 larger ones, r = ceil(k / Mw) -- each of the r largest reports stands for
+    // Mw distinct rows at or above it in the canonical order, so at least k rows are at or above such a report: no row of the top
+    // k lies below it.  The keys carry the row index: the threshold also cuts through a group of equal scores.  The r-th largest
+    // itself is the tightest, and ranking every report against every other (65 k 64-bit compares per selector) took 2.6 us of
+    // instruction issue.  Instead: the reports of regions 0 .. 31 are SAMPLES.  Every report counts the samples above it -- its
+    // bucket b; a report in a lower bucket is larger than every report in a higher one, and inside a sample's own bucket every
+    // other report is larger than the sample -- so the bucket populations give every sample's exact rank:
+    // rank(s) = population of buckets 0 .. b(s), minus one.  The threshold is the sample with the smallest rank >= r - 1 (about
+    // 256 / 33 reports -- 40 rows -- beyond the r-th largest).  No such sample (all 32 among the r - 1 largest: 3 in 10 000 queries
+    // at k = 1000), or a grid without them: every report is ranked, as before.  Every selector finds the same value.
+    constexpr uint32_t kSamples = 32;
+    const uint32_t rr = Mw ? (a.k + Mw - 1u) / Mw : 0u;
+    // (the region's second thread gets the report from the first: lanes 2 m and 2 m + 1, since S is even)
+    const uint32_t nlo = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(rep_mine)), lane & ~1, 64));
+    const uint32_t nhi = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(rep_mine >> 32)), lane & ~1, 64));
+    const u64 rep_reg = my_part == 1 ? ((static_cast<u64>(nhi) << 32) | nlo) : rep_mine;
     if (good0 && Mw) {
-        const uint32_t rr = (a.k + Mw - 1u) / Mw;
-        // (the region's second thread gets the report from the first: lanes 2 m and 2 m + 1, since S is even)
-        const uint32_t nlo = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(rep_mine)), lane & ~1, 64));
-        const uint32_t nhi = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(rep_mine >> 32)), lane & ~1, 64));
-        const u64 rep_reg = my_part == 1 ? ((static_cast<u64>(nhi) << 32) | nlo) : rep_mine;
+        uint32_t bkt = 0;
+        if (my_part < 2) { // the region's two threads: sixteen samples each
+            const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(sh.sel.u.rep) + (my_part & 1u) * (kSamples / 4);
+#pragma unroll
+            for (uint32_t j = 0; j < kSamples / 4; j++) {
+                const ulonglong2 kk = s2[j];
+                bkt += kk.x > rep_reg ? 1u : 0u;
+                bkt += kk.y > rep_reg ? 1u : 0u;
+            }
+        }
+        bkt += static_cast<uint32_t>(__shfl_xor(static_cast<int>(bkt), 1, 64));
+        if (my_part == 0 && rep_mine != 0ull) {
+            atomicAdd(&sh.hist[bkt], 1u); // (zero since the selectors' start; absent reports are not counted)
+            if (my_region < kSamples) sh.hist[64u + my_region] = bkt;
+        }
+    }
+    __syncthreads(); // the buckets' populations
+    if (good0 && Mw && wv == 0) {
+        uint32_t incl = static_cast<uint32_t>(lane) <= kSamples ? sh.hist[lane] : 0u; // lane b: the reports in bucket b ...
+        { // ... in buckets 0 .. b (DPP inside the 16-lane rows, readlanes across them: a shuffle chain costs ~700 cycles)
+            uint32_t o;
+            o = dpp_shr<1>(incl); incl += o;
+            o = dpp_shr<2>(incl); incl += o;
+            o = dpp_shr<4>(incl); incl += o;
+            o = dpp_shr<8>(incl); incl += o;
+            const uint32_t row0 = __builtin_amdgcn_readlane(incl, 15), row1 = __builtin_amdgcn_readlane(incl, 31);
+            incl += (lane >= 16 ? row0 : 0u) + (lane >= 32 ? row1 : 0u); // (buckets 0 .. 32: rows 0 .. 2)
+        }
+        const u64 smp = static_cast<uint32_t>(lane) < kSamples ? sh.sel.u.rep[lane] : 0ull; // lane i: sample i, its bucket, its rank
+        const uint32_t sb = static_cast<uint32_t>(lane) < kSamples ? sh.hist[64u + static_cast<uint32_t>(lane)] : 0u;
+        const uint32_t srank = static_cast<uint32_t>(__shfl(static_cast<int>(incl), static_cast<int>(sb <= kSamples ? sb : 0u), 64)) - 1u;
+        const bool cand = smp != 0ull && srank >= rr - 1u;
+        const uint32_t best = ~wave_max_u32(cand ? ~((srank << 6) | static_cast<uint32_t>(lane)) : 0u); // the smallest (rank, lane) among them
+        if (cand && ((srank << 6) | static_cast<uint32_t>(lane)) == best) sh.tauf = smp;
+        if (lane == 0) sh.exact = (best == ~0u) ? 1u : 0u; // no sample qualifies: every report is ranked
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's part of the prefixes is in LDS
+    __syncthreads();                                 // ... and everybody's; the threshold is known
+    if (good0 && Mw && sh.exact != 0u) { // (rare) no sample had r - 1 reports above it: the r-th largest report, by ranking all
         const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(sh.sel.u.rep) + (my_part & 1u) * (kFusedSelectors / 4);
         uint32_t rank = 0;
         if (my_part < 2) {
@@ -1052,9 +1099,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         }
         rank += static_cast<uint32_t>(__shfl_xor(static_cast<int>(rank), 1, 64));
         if (my_part == 0 && rep_mine != 0ull && rank == rr - 1u) sh.tauf = rep_mine;
+        __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's part of the prefixes is in LDS
-    __syncthreads();                                 // ... and everybody's; the threshold is known
     const u64 tauf = good0 ? sh.tauf : ~0ull;
     if (dbg && tid == 0) dbg[23] = wall_clock64();
     // finalists = the published rows at or above the final threshold -> LDS.  Thread g takes region g's staged entries
