@@ -988,14 +988,13 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
         bool pend = my_region < nwg;
         u64 issued = 0; // bit 8 u: the entries of this wave's group u have been requested
         const unsigned long long t_wait = wall_clock64();
-        // (two polls in flight: the next one is on its way while this one is looked at -- a header is seen half a round trip sooner)
-        u32x4 hnext = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (pend ? my_region : 0u) * kFusedHeaderBytes, 0, /*sc1*/ 16);
         for (uint32_t spins = 0;; spins++) {
-            const u32x4 h = hnext;
-            hnext = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (pend ? my_region : 0u) * kFusedHeaderBytes, 0, /*sc1*/ 16);
-            if (pend && ((h.y >> 5) & 0x3FFFFFFu) == htag) {
-                hd = h;
-                pend = false;
+            if (pend) {
+                const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, my_region * kFusedHeaderBytes, 0, /*sc1*/ 16);
+                if (((h.y >> 5) & 0x3FFFFFFu) == htag) {
+                    hd = h;
+                    pend = false;
+                }
             }
             const u64 pm = __ballot(pend);
             u64 any8 = pm | (pm >> 1);
@@ -1018,6 +1017,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 if (lane == 0) atomicOr(&st->redo, kRedoArrivalWait);
                 break;
             }
+            __builtin_amdgcn_s_sleep(1);
         }
         // a header that never came, or one whose workgroup failed (a store that overflowed, an election it gave up waiting for)
         if (__ballot(pend || (hd.y >> 31) != 0) != 0 && lane == 0) sh.ok = 0u;
