@@ -76,7 +76,7 @@ constexpr uint32_t kFusedPrefix = 8;    // entries of a region ONE thread takes 
 constexpr uint32_t kFusedSortCap = 128; // a workgroup with up to this many rows publishes them in canonical order (the count is
                                         // quadratic: 256 rows that all sit in one wave's store cost 10 us); more: in bucket order
 constexpr uint32_t kFusedItems = 1024;  // 64-entry reads beyond the prefixes a selector lists per round (at most 4 per region)
-constexpr uint32_t kFusedRankDirect = 2048; // up to this many finalists a selector ranks its rows by comparing each with every finalist
+constexpr uint32_t kFusedRankDirect = 3072; // up to this many finalists a selector ranks its rows by comparing each with every finalist
 constexpr uint32_t kFusedBins = 1024;   // buckets of the order in which a workgroup with more than kFusedSortCap rows publishes them
 
 struct FusedShared { // (static_assert below: it fits the CU's 160 KB)
@@ -1191,19 +1191,24 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
             return incl;
         };
         // more rows of this region may qualify: its list is longer than the requested prefix and the prefix's last part
-        // holds no entry that ends it.  The next 64 entries become an item of round 0 (below).
+        // holds no entry that ends it.  The next 256 entries (what the list holds of them) become up to four items of round 0
+        // (below): a long list is a series of analogs or a tie -- most of it qualifies -- and a round is a round trip (one
+        // item first and "as many again" per round took three rounds, 7 us, for the 222 rows a Morgan-shaped table's
+        // workgroup published).
         const bool more = good0 && my_part == (1u << lgS) - 1u && n_mine > pre_all && stopm == 0;
+        const uint32_t left0 = more ? n_mine - pre_all : 0u;
+        const uint32_t ni0 = (left0 + 63u) / 64u < 4u ? (left0 + 63u) / 64u : 4u;
         uint32_t wtot, wtot2;
-        const uint32_t incl = wave_scan(cnt, wtot), incl2 = wave_scan(more ? 1u : 0u, wtot2);
+        const uint32_t incl = wave_scan(cnt, wtot), incl2 = wave_scan(ni0, wtot2);
         uint32_t base = 0, base2 = 0;
         if (lane == 0 && wtot) base = atomicAdd(&sh.nfin, wtot); // (one LDS atomic per wave and list, not one per lane)
         if (lane == 0 && wtot2) base2 = atomicAdd(&sh.nitems[0], wtot2);
         base = __builtin_amdgcn_readfirstlane(base);
         base2 = __builtin_amdgcn_readfirstlane(base2);
         if (my_part == 0) sh.rn[my_region] = n_mine | (shift_mine << 16) | (sorted_mine ? 0x80000000u : 0u);
-        if (more) {
-            const uint32_t left = n_mine - pre_all;
-            sh.items[0][base2 + incl2 - 1u] = my_region | ((pre_all / 16u) << 8) | (((left < 64u ? left : 64u) - 1u) << 17) | (1u << 23);
+        for (uint32_t q = 0; q < ni0; q++) {
+            const uint32_t st0 = pre_all + 64u * q, c = n_mine - st0 < 64u ? n_mine - st0 : 64u;
+            sh.items[0][base2 + incl2 - ni0 + q] = my_region | ((st0 / 16u) << 8) | ((c - 1u) << 17) | (q == ni0 - 1u ? (1u << 23) : 0u);
         }
         const uint32_t slot0 = base + incl - cnt;
 #pragma unroll
