@@ -47,16 +47,19 @@ namespace
 //      sort by score key >> shift, highest bucket first); its 16-byte header holds the count, the order, the shift,
 //      the workgroup's REPORT, its Mw-th best 64-bit key -- and the launch's TAG, which every entry carries too.  Write-
 //      through stores and nothing else: no wait for their acknowledgements, no counter -- the header IS the arrival;
-//   4. every workgroup then becomes a selector.  It polls the headers until all 256 carry the launch's tag -- the ONE
-//      grid-wide wait of the kernel; bounded by a few scan times of wall clock: on a GPU shared with another queue part
-//      of the grid may not have started while the waiters hold their CUs, the query then goes to the four-kernel
-//      pipeline, which never waits -- and requests the first 16 entries of a region as soon as its header has shown up
-//      (four regions per load): the lists of the workgroups that finished early are in LDS before the last one has
-//      published.  An entry without the tag was overtaken by its header and is read again.  From the reports every selector derives the SAME final threshold (the r-th largest report as a
-//      64-bit key -- it carries the row index, so it also cuts through groups of equal scores), keeps the published
-//      rows at or above it in LDS (a list is read on, 64 entries at a time, until an entry proves the rest lies below
-//      the threshold) and ranks the rows it owns (hash of the row) -- by counting larger keys, or through a histogram
-//      of the finalists when there are many -- the output slot of a hit is its rank, keys are unique; the hits of
+//   4. every workgroup then becomes a selector -- all EIGHT of its waves: the two service waves and two that waited out the
+//      scan at a barrier join the four streaming waves (the phases below are bound by instruction issue and LDS round
+//      trips).  Two threads look after a region; they poll its header until it carries the launch's tag -- the ONE grid-wide
+//      wait of the kernel; bounded by a few scan times of wall clock: on a GPU shared with another queue part of the grid
+//      may not have started while the waiters hold their CUs, the query then goes to the four-kernel pipeline, which never
+//      waits -- and the first 16 entries of a region are requested as soon as its header has shown up (four regions per
+//      load): the lists of the workgroups that finished early are in LDS before the last one has published.  An entry
+//      without the tag was overtaken by its header and is read again.  From the reports every selector derives the SAME
+//      final threshold (a report with at least r - 1 larger ones, found through 32 sampled reports; a 64-bit key -- it
+//      carries the row index, so it also cuts through groups of equal scores), keeps the published rows at or above it in
+//      LDS (a list is read on, up to 256 entries in the first round, until an entry proves the rest lies below the
+//      threshold) and ranks the rows it owns (hash of the row) -- by counting larger keys, or through a histogram of the
+//      finalists when there are many -- the output slot of a hit is its rank, keys are unique; the hits of
 //      rank < k go straight into the result block, written through at system scope;
 //   5. every selector waits for its stores' acknowledgements and takes a (two-level) ticket; the last one writes the
 //      header -- for the synchronous API with the query's epoch in the flags word: the caller polls the header of its
