@@ -1020,7 +1020,11 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
                 if (lane == 0) atomicOr(&st->redo, kRedoArrivalWait);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            // (the wait is a few polls on a GPU this kernel has to itself; a long one means the rest of the grid cannot start
+            // -- another process holds CUs -- and 512 threads per workgroup polling flat out would take ~2 TB/s from ITS scan)
+            if (spins < 16u) __builtin_amdgcn_s_sleep(1);
+            else if (spins < 256u) __builtin_amdgcn_s_sleep(32); // ~1 us
+            else __builtin_amdgcn_s_sleep(127);                  // ~3.4 us
         }
         // a header that never came, or one whose workgroup failed (a store that overflowed, an election it gave up waiting for)
         if (__ballot(pend || (hd.y >> 31) != 0) != 0 && lane == 0) sh.ok = 0u;
