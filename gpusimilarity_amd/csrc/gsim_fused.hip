@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     // bucket b; a report in a lower bucket is larger than every report in a higher one, and inside a sample's own bucket every
     // other report is larger than the sample -- so the bucket populations give every sample's exact rank:
     // rank(s) = population of buckets 0 .. b(s), minus one.  The threshold is the sample with the smallest rank >= r - 1 (about
-    // 256 / 33 reports -- 40 rows -- beyond the r-th largest).  No such sample (all 32 among the r - 1 largest: 3 in 10 000 queries
+    // 256 / 33 reports -- 40 rows -- beyond the r-th largest).  No such sample (all 32 among the r - 1 largest: by (199/256)^32 about 3 in 10 000 queries
     // at k = 1000), or a grid without them: every report is ranked, as before.  Every selector finds the same value.
     constexpr uint32_t kSamples = 32;
     const uint32_t rr = Mw ? (a.k + Mw - 1u) / Mw : 0u;
