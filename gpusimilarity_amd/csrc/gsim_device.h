@@ -121,7 +121,7 @@ struct FusedArgs {
     uint32_t pub_tag;     // non-zero, new for every launch on this handle: the fourth word of every entry this launch publishes, its low 26
                           // bits in every header -- readers tell this query's lists from what a region held before (no arrival counter)
     uint32_t wait_ticks;     // bound of the grid-wide wait (100 MHz ticks): a few scan times, see fused_kernel
-    uint32_t xflags;         // 4 = QueryState::gtau was seeded by the sample kernel (a coarse bin); experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints, 1024 = release fence before the closing ticket, 4096 = the published entries get their tags a few microseconds after the header (drives the selectors' read-again path)
+    uint32_t xflags;         // 4 = QueryState::gtau was seeded by the sample kernel (a coarse bin); experiments (GSIM_FUSED_FLAGS): 2 = no in-loop checkpoints, 1024 = release fence before the closing ticket, 4096 = the published entries get their tags a few microseconds after the header (drives the selectors' read-again path), 8192 = the final threshold always by ranking every report (the path behind a sampled election that found no sample)
     unsigned long long* dbg; // NULL, or 24 timestamps (100 MHz wall clock) per workgroup: phase profile (GSIM_FUSED_DEBUG)
 };
 

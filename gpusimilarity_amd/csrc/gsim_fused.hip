@@ -1093,7 +1093,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_kernel(ScanArgs a, ScanGeom
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's part of the prefixes is in LDS
     __syncthreads();                                 // ... and everybody's; the threshold is known
-    if (good0 && Mw && sh.exact != 0u) { // (rare) no sample had r - 1 reports above it: the r-th largest report, by ranking all
+    // (GSIM_FUSED_FLAGS=8192: always -- the only way to reach this path on purpose; it then overrides the sample's threshold)
+    if (good0 && Mw && (sh.exact != 0u || (fa.xflags & 8192u) != 0u)) { // (rare) no sample had r - 1 reports above it: the r-th largest report, by ranking all
         const ulonglong2* r2 = reinterpret_cast<const ulonglong2*>(sh.sel.u.rep) + (my_part & 1u) * (kFusedSelectors / 4);
         uint32_t rank = 0;
         if (my_part < 2) {
