@@ -221,6 +221,91 @@ def pmc_traffic(rows, fp_bits, kind_name, k, kernel_substr):
     return fetch, write, note
 
 
+
+# ---------------------------------------------------------------------------------------------
+# output: ONE short JSON line (the contract) + bench_detail.json beside this script (everything else)
+# ---------------------------------------------------------------------------------------------
+
+LINE_CAP = 12000  # bytes; the driver parses the line from a bounded tail of stdout (round 5's 20.5 KB line was not parsed)
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline", "timed_region_s", "queries_per_step", "ms_per_query",
+                 "whole_path_hbm_frac", "sync_ms_median", "sync_ms_p95", "calls", "queries_per_s")
+
+
+def _sig(x, digits=6):
+    """floats to `digits` significant digits, recursively (a line of 17-digit doubles is twice as long as it needs to be)"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k_: _sig(v, digits) for k_, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(out, detail_path):
+    """The contract line: the contract's keys first and short; `configs`, `widths`, `server_latency`, `cpu_baseline.parts`,
+    the full `collective.per_rank`, the full `routes` and the notes live in the detail file only."""
+    line = {k_: out[k_] for k_ in CONTRACT_KEYS if k_ in out}
+    if "config" in line:
+        line["config"] = {k_: v for k_, v in out["config"].items() if k_ != "query_execution"}
+    if out.get("roofline"):
+        keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel_ms_avg",
+                "algorithmic_bytes_per_launch", "queries_handed_back", "issue")
+        line["roofline"] = {k_: out["roofline"].get(k_) for k_ in keep if k_ in out["roofline"] or k_ == "traffic"}
+        if isinstance(line["roofline"].get("issue"), dict):
+            line["roofline"]["issue"] = {k_: v for k_, v in line["roofline"]["issue"].items() if k_ != "source"}
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = {k_: out["cpu_baseline"].get(k_) for k_ in ("value", "unit", "cores", "kind", "sample")}
+    if out.get("collective"):
+        c = out["collective"]
+        cc = {k_: c.get(k_) for k_ in ("backend", "world", "launcher", "data_path_collective", "queries_in_flight", "shared_gpu_test_mode", "rccl")
+              if c.get(k_) is not None or k_ in ("backend", "world")}
+        cc["ranks"] = [{"rank": m.get("rank"), "device": m.get("device"), "pci_bus_id": m.get("pci_bus_id")} for m in c.get("ranks", [])]
+        if c.get("per_rank"):
+            pr = []
+            for m in c["per_rank"]:
+                e = {"rank": m.get("rank")}
+                e.update(m.get("phases_per_query") or {})
+                tw = m.get("single_gpu_twin") or {}
+                e["twin_ms_per_query"], e["twin_kernel_ms"] = tw.get("ms_per_query"), tw.get("kernel_ms_avg")
+                pr.append(e)
+            cc["per_rank"] = pr
+        line["collective"] = cc
+    if out.get("routes"):
+        keep = ("ms_per_query", "fingerprints_per_s", "kernel_ms_avg_first_shard", "gather_us_avg", "merge_us_avg", "collectives", "transport",
+                "identical_to_host_merge", "backend", "queries_handed_back", "error")
+        line["routes"] = {name: {k_: r.get(k_) for k_ in keep if r.get(k_) is not None} for name, r in out["routes"].items()}
+    if out.get("summary"):
+        line["summary"] = out["summary"]
+    line["detail"] = detail_path
+    line = _sig(line)
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text) >= LINE_CAP and line.get("summary", {}).get("configs"):
+        line["summary"]["configs"].pop()  # never reached with today's entries (the line is ~4 KB); a cap is a cap
+        line["summary"]["truncated"] = True
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_CAP, len(text)
+    return text
+
+
+def emit(out, json_fd, detail_name="bench_detail.json"):
+    """Write the full record to bench_detail.json (beside bench.py; and under gpurun_out/ when that directory exists, so that a
+    gpurun call brings it home) and the contract line to stdout."""
+    paths = [os.path.join(ROOT, detail_name)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", detail_name))
+    written = None
+    for p_ in paths:
+        try:
+            with open(p_, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+            written = written or os.path.relpath(p_, ROOT)
+        except OSError:
+            pass
+    os.write(json_fd, (compact_line(out, written) + "\n").encode())
+
 # ---------------------------------------------------------------------------------------------
 # GPU runs
 # ---------------------------------------------------------------------------------------------
@@ -569,7 +654,7 @@ def in_process(args):
                      "traffic": None, "kernel_ms_avg": hm["kernel_ms_avg_first_shard"]},
         "routes": routes,
     }
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(out, json_fd, "bench_detail_inprocess.json")
 
 
 def main():
@@ -690,7 +775,7 @@ def main():
         }
         table.close()
         if rank == 0:
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            emit(out, json_fd, "bench_detail_batch.json")
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
@@ -895,7 +980,7 @@ def main():
                 short.append(e)
             out["summary"] = {"configs": short, "traffic_over_algorithmic": out["roofline"].get("traffic_over_algorithmic"),
                               "cpu_baseline_fp_per_s": (out.get("cpu_baseline") or {}).get("value")}
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

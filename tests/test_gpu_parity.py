@@ -1191,9 +1191,10 @@ def test_bench_contract_lines():
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, r.stdout[-500:]
+        assert len(lines[0]) < 12000, len(lines[0])
         d = json.loads(lines[0])
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                    "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+                    "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "detail"):
             assert key in d, key
         assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and "workload" in d["config"]
         assert d["roofline"]["bound"] in ("hbm", "mfma") and d["roofline"]["peak"] > 0
@@ -1203,8 +1204,11 @@ def test_bench_contract_lines():
         if "--force-sharded-path" in extra:
             # the N > 1 line decomposes: this rank's phase times by HIP events, its shard's single-GPU twin
             pr = d["collective"]["per_rank"][0]
-            assert set(pr["phases_per_query"]) >= {"search_ms", "gather_us", "merge_us", "d2h_us"} and pr["phases_per_query"]["search_ms"] > 0
-            assert pr["single_gpu_twin"]["ms_per_query"] > 0 and d["collective"]["queries_in_flight"] == 8
+            assert set(pr) >= {"search_ms", "gather_us", "merge_us", "d2h_us"} and pr["search_ms"] > 0
+            assert pr["twin_ms_per_query"] > 0 and d["collective"]["queries_in_flight"] == 8
+            # ... and the full per-rank record is in the detail file the line names
+            full = json.load(open(os.path.join(ROOT, d["detail"])))
+            assert full["collective"]["per_rank"][0]["single_gpu_twin"]["ms_per_query"] > 0
         else:
             # SURVEY 8(d)'s latency next to the pipelined mean, and the PMC traffic of the dominant kernel in the line itself
             assert d["sync_ms_median"] > 0 and d["sync_ms_p95"] >= d["sync_ms_median"] and d["calls"] >= 50
@@ -1214,3 +1218,34 @@ def test_bench_contract_lines():
                 assert rf["traffic"] is not None, rf["traffic_note"]
                 # (400 k rows = 51 MB: the table fits the 256 MB Infinity Cache, whose hits the counter includes; the bound is loose)
                 assert 0.5 * rf["algorithmic_bytes_per_launch"] <= rf["traffic"] <= 1.5 * rf["algorithmic_bytes_per_launch"], rf
+
+
+def test_bench_default_command_line_parses():
+    """The line of the command the DRIVER runs (`bench.py --gpus 1 --steps 20 --warmup 5`: every config, the widths, the
+    server record, the CPU baseline) is one JSON line under 12 KB that carries `roofline` and `cpu_baseline`; everything
+    else is in the detail file it names (round 5's 20.5 KB line could not be parsed by the driver)."""
+    import subprocess
+    import sys
+    from gpusimilarity_amd import capi
+    if capi.device_free_bytes(0) < 140 * 2**30:
+        pytest.skip("the default run holds the 1 B-row table (128 GB): not enough free HBM on this device")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-500:]
+    assert len(lines[0]) < 12000, len(lines[0])
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "summary", "detail"):
+        assert key in d, key
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and "workload" in d["config"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("reference", "port") and cb["sample"]
+    # kernel <= step: the dominant kernel's average duration cannot exceed the mean time per query of the timed region
+    assert rf["kernel_ms_avg"] <= d["ms_per_query"] * 1.001
+    assert d["timed_region_s"] > 0 and abs(d["ms_per_step"] * d["steps"] / 1e3 - d["timed_region_s"]) < 0.01 * d["timed_region_s"]
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert len(full["configs"]) >= 8 and full["widths"] and full["cpu_baseline"]["parts"]
+    assert len(d["summary"]["configs"]) == len(full["configs"])
