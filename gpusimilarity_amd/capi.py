@@ -34,7 +34,8 @@ class GsimTiming(C.Structure):
                 ("batches", C.c_uint64), ("batch_kernel_ms_sum", C.c_double), ("handed_back_why", C.c_uint64), ("batches_dense_cutoff", C.c_uint64),
                 ("collectives", C.c_uint64), ("gather_ms_sum", C.c_double), ("merge_ms_sum", C.c_double),
                 ("blocks_rechecked", C.c_uint64), ("blocks_torn", C.c_uint64), ("batches_regrown", C.c_uint64),
-                ("large_k_single_scan", C.c_uint64)]
+                ("large_k_single_scan", C.c_uint64), ("rerun_own", C.c_uint64), ("rerun_publish", C.c_uint64),
+                ("rerun_behind", C.c_uint64), ("rerun_torn", C.c_uint64), ("backoff_skips", C.c_uint64)]
 
 
 class GsimError(RuntimeError):
@@ -55,7 +56,7 @@ EXPORTS = [
     "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm", "gsim_db_set_comm_root",
     "gsim_db_enable_timing",
-    "gsim_db_get_timing", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
+    "gsim_db_get_timing", "gsim_debug_query_flags", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
 ]
 
 
@@ -122,6 +123,7 @@ def load():
         "gsim_db_set_comm_root": (C.c_int, [vp, C.c_int]),
         "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
+        "gsim_debug_query_flags": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint32)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                              C.c_uint32, C.POINTER(C.c_float)]),
         "gsim_debug_sort_desc": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32]),
@@ -338,6 +340,15 @@ class Table:
         t = GsimTiming()
         check(self._L.gsim_db_get_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in GsimTiming._fields_}
+
+    def query_flags(self, n: int) -> np.ndarray:
+        """One byte per query of the last search call made with timing enabled (gsim_debug_query_flags): 1 handed back by its own
+        single launch, 2 re-run behind a launch that did not close, 4 torn block, 8 routed around the single launch by the
+        back-off, 16 / 32 the same two for the large-k publishing route."""
+        out = np.zeros(n, dtype=np.uint8)
+        w = C.c_uint32(0)
+        check(self._L.gsim_debug_query_flags(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n, C.byref(w)))
+        return out[:w.value]
 
 
 class Comm:

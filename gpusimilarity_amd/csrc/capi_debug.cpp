@@ -176,7 +176,22 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
     db->acc.blocks_torn = db->blocks_torn;
     db->acc.batches_regrown = db->batch_regrown;
     db->acc.large_k_single_scan = db->large_k_published.load();
+    db->acc.rerun_own = db->rerun_own;
+    db->acc.rerun_publish = db->rerun_publish;
+    db->acc.rerun_behind = db->rerun_behind;
+    db->acc.rerun_torn = db->rerun_torn;
+    db->acc.backoff_skips = db->backoff_skips;
     *out = db->acc;
+    return GSIM_OK;
+}
+
+int gsim_debug_query_flags(gsim_db* db, uint8_t* flags, uint32_t n, uint32_t* written)
+{
+    if (!db || (!flags && n)) return fail(GSIM_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> guard(db->search_mutex);
+    const uint32_t m = static_cast<uint32_t>(std::min<size_t>(n, db->query_flags.size()));
+    if (m) std::memcpy(flags, db->query_flags.data(), m);
+    if (written) *written = m;
     return GSIM_OK;
 }
 

@@ -104,6 +104,7 @@ struct Shard {
     gsim::LargeKState* d_lk = nullptr;
     uint32_t* d_bincur = nullptr;    // kScanBins cursors of launch_fused_binsort (zero between queries) + kScanBins words: the bins' first positions
     uint32_t binrank_skip = 0;       // large-k queries left that take the radix tail: the bin-ranked one handed a query back (ties)
+    uint32_t binrank_streak = 0;     // ... consecutive times: the skip doubles (16, 32, ... 1024)
     bool classic_ready = false; // candidate / finalist scratch of the four-kernel pipeline (allocated on first use)
     void* d_pub = nullptr;      // single-launch path: the workgroups' published-candidate regions (128 KB each)
     void* d_hdr = nullptr;      // ... and their headers (64 B each)
@@ -118,6 +119,8 @@ struct Shard {
     bool slot_publish[kPipe] = {};  // the synchronous enqueue of the slot was a large-k query scanned by the single launch (header flag 2: run it again)
     bool slot_binrank[kPipe] = {};  // ... and ranked by coarse bin (a hand-back sends the next ones to the radix tail)
     bool slot_rerun[kPipe] = {};    // ... but behind a launch that left the per-query state dirty: not to be trusted, run again
+    bool slot_inflight[kPipe] = {}; // a synchronous enqueue of the slot has not been finished yet (whatever route it took)
+    uint8_t slot_why[kPipe] = {};   // kQ* bits: how the slot's query was routed and why it was run again (gsim_debug_query_flags)
     char* h_pipe = nullptr;          // kPipe pinned result blocks (gsim_db_search_each)
     size_t h_pipe_block = 0;
     // Tables whose scores tie heavily (narrow or very sparse fingerprints) make the single-launch path hand every
@@ -205,6 +208,10 @@ struct gsim_db {
     unsigned long long dense_batches = 0; // multi-query passes whose dense cutoff the matrix-core pass counted itself
     unsigned long long batch_regrown = 0; // batches run again with larger candidate segments
     std::atomic<unsigned long long> large_k_published{0}; // shard queries with k > kSelectCap scanned by the single launch
+    // why synchronous queries were run a second time / routed around the single launch (host-side counts, gsim_timing.rerun_*)
+    unsigned long long rerun_own = 0, rerun_behind = 0, rerun_torn = 0, rerun_publish = 0, backoff_skips = 0;
+    size_t query_flags_at = 0;        // ... the query search_one is answering
+    std::vector<uint8_t> query_flags; // kQ* bits of every query of the last gsim_db_search / _each call (timing enabled)
     unsigned long long blocks_checked = 0, blocks_rechecked = 0, blocks_torn = 0; // single launch, synchronous callers: result blocks whose checksum
                                                                // did not match at first sight / never did (re-run)
     gsim_comm* comm = nullptr; // gsim_db_set_comm: shard results meet through an RCCL all-gather + merge_kernel instead of on the host
@@ -232,6 +239,13 @@ inline uint32_t popcount_words(const uint32_t* q, uint32_t W)
 }
 
 enum QueryMode { kAuto = 0, kClassic = 1 };
+// Per-query record of the synchronous routes (Shard::slot_why -> gsim_db::query_flags -> gsim_debug_query_flags)
+constexpr uint8_t kQHandedBack = 1;   // the single launch ran the query and handed it back itself (gsim_timing.handed_back counts these)
+constexpr uint8_t kQRerunBehind = 2;  // run again because a launch ahead of it on the stream ended without closing its query
+constexpr uint8_t kQTorn = 4;         // run again because its block's checksum never matched
+constexpr uint8_t kQSkipFused = 8;    // routed around the single launch by the back-off after earlier hand-backs
+constexpr uint8_t kQPublishBack = 16; // large k: the publishing launch or the bin-ranked emission handed it back
+constexpr uint8_t kQSkipPublish = 32; // large k: routed around the publishing launch / the bin-ranked emission by a back-off
 constexpr uint32_t kBatchMaxQ = 256; // queries per batch call on a shard (larger requests are split)
 
 // capi_lifecycle.cpp

@@ -46,6 +46,8 @@ gsim::Knobs read_knobs()
     k.largek_binrank = env_value("GSIM_LARGEK_BINRANK", k.largek_binrank);
     k.fused_select_max_k = std::min(std::max(env_value("GSIM_FUSED_SELECT_MAX_K", k.fused_select_max_k), 2048), static_cast<int>(gsim::kFusedMaxK)); // (the large-k sort takes k > 2048)
     k.largek_one_block_max = env_value("GSIM_LARGEK_ONE_BLOCK_MAX", k.largek_one_block_max);
+    k.fused_backoff = env_value("GSIM_FUSED_BACKOFF", k.fused_backoff);
+    k.publish_min_rows_per_k = std::max(env_value("GSIM_PUBLISH_MIN_ROWS_PER_K", k.publish_min_rows_per_k), 0);
     k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
     k.batch = env_value("GSIM_BATCH", k.batch);
     k.batch_waves_per_cu = env_value("GSIM_BATCH_WAVES_PER_CU", k.batch_waves_per_cu);

@@ -86,7 +86,7 @@ bool fused_publish_applies(const gsim_db* db, const Shard& s, uint32_t k)
         return false;
     if (s.fgeo.lanes_per_row < 4 || s.fgeo.ragged_words || s.fgeo.ragged_loads) return false;
     if (gsim::fused_summary_keys(s.fgeo.nwaves, k, 64) == 0) return false; // (no thresholds: every row would be published)
-    if (s.nrows < 64ull * k) return false; // (a short table: the thresholds come late and most of it is published)
+    if (s.nrows < static_cast<uint64_t>(db->knobs.publish_min_rows_per_k) * k) return false; // (a short table: the thresholds come late and most of it is published)
     const long long max_rows = db->knobs.fused_max_rows;
     return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
 }
@@ -138,15 +138,19 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
     }
     // (k between the knob fused_select_max_k and kFusedMaxK: the single launch could rank it, the publishing route is preferred)
     bool publish = mode == kAuto && fused_publish_applies(db, s, k);
+    uint8_t why = 0;
     if (publish && caller_syncs && s.publish_skip) { // (tables that make the publishing launch hand every query back: scanned twice)
         s.publish_skip--;
         publish = false;
+        why |= kQSkipPublish;
     }
     bool fused = mode == kAuto && !publish && fused_applies(db, s, k);
     if (fused && caller_syncs && s.fused_skip) {
         s.fused_skip--;
         fused = false;
+        why |= kQSkipFused;
     }
+    if (why) db->backoff_skips++;
     const bool classic = (!fused && !(publish && caller_syncs)) || !caller_syncs;
     if (classic) {
         const int rc = ensure_classic_scratch(s);
@@ -202,6 +206,9 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         s.slot_publish[pipe_slot] = false;
         s.slot_binrank[pipe_slot] = false;
         s.slot_ev_set[pipe_slot] = false;
+        s.slot_rerun[pipe_slot] = false; // (a slot is enqueued again only after it was finished: a flag still set here is stale -- ADVICE r05)
+        s.slot_inflight[pipe_slot] = true;
+        if (mode == kAuto) s.slot_why[pipe_slot] = why; // (a re-run, kClassic, keeps what the first run recorded)
     }
     if (fused) {
         gsim::FusedArgs f{};
@@ -297,7 +304,11 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
                 }
                 return record_slot_event(s, pipe_slot);
             }
-            if (s.binrank_skip) s.binrank_skip--;
+            if (s.binrank_skip) {
+                s.binrank_skip--;
+                s.slot_why[pipe_slot] |= kQSkipPublish;
+                db->backoff_skips++;
+            }
         }
         GSIM_HIP(gsim::launch_fused_handoff(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.stream));
         a.gate = &s.d_state->redo;
@@ -391,34 +402,54 @@ int wait_stream(hipStream_t st)
 int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
                       float beta, uint32_t row_base, void* out, uint32_t pipe_slot)
 {
+    s.slot_inflight[pipe_slot] = false;
+    const bool backoff = db->knobs.fused_backoff != 0;
+    auto run_again = [&]() -> int { // the four-kernel pipeline, waited for
+        int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
+        if (rc == GSIM_OK) rc = wait_stream(s.stream);
+        s.slot_inflight[pipe_slot] = false;
+        s.slot_ev_set[pipe_slot] = false;
+        return rc;
+    };
+    if (s.slot_rerun[pipe_slot]) {
+        // Enqueued behind a single launch that ended without closing its query (below): this one ran on per-query state
+        // nobody had re-zeroed -- WHATEVER route it took (a classic or publishing query behind the failed launch
+        // shared that state too) -- and a block's checksum only covers the block's own hits: run it again.  The stream had
+        // drained when the flag was set, so its own kernels are over.
+        s.slot_rerun[pipe_slot] = false;
+        s.slot_fused[pipe_slot] = s.slot_publish[pipe_slot] = s.slot_binrank[pipe_slot] = false;
+        s.slot_why[pipe_slot] |= kQRerunBehind;
+        db->rerun_behind++;
+        return run_again();
+    }
     if (!s.slot_fused[pipe_slot]) {
         int rc = s.slot_ev_set[pipe_slot] ? wait_event(s.slot_ev[pipe_slot]) : wait_stream(s.stream);
         s.slot_ev_set[pipe_slot] = false;
         const bool back = rc == GSIM_OK && s.slot_publish[pipe_slot] && (static_cast<const gsim_result_header*>(out)->flags & 2u);
-        if (rc == GSIM_OK && s.slot_publish[pipe_slot] && !back) s.publish_streak = 0;
+        if (rc == GSIM_OK && s.slot_publish[pipe_slot] && !back) {
+            s.publish_streak = 0;
+            if (s.slot_binrank[pipe_slot]) s.binrank_streak = 0;
+        }
         if (back) {
             // large k, scanned by the single launch, handed back (heavy ties): the emission cleared the per-query state
             if (s.slot_binrank[pipe_slot]) {
-                s.binrank_skip = 16; // (ties in the top bins, most likely: the next ones by the radix tail)
+                // ties in the top bins, most likely: the next ones by the radix tail -- 16, 32, ... 1024 of them while it keeps
+                // happening (a fixed 16 made a tie-heavy table pay a second scan every 17th large-k query for good)
+                if (backoff) s.binrank_skip = 16u << s.binrank_streak;
+                s.binrank_streak = s.binrank_streak < 6 ? s.binrank_streak + 1 : 6;
             } else { // not the bin-ranked emission's doing: the launch itself cannot hold this table's queries -- back off as the single launch does
                 s.publish_streak = s.publish_streak < 6 ? s.publish_streak + 1 : 6;
-                s.publish_skip = 1u << s.publish_streak;
+                if (backoff) s.publish_skip = 1u << s.publish_streak;
             }
-            rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
-            if (rc == GSIM_OK) rc = wait_stream(s.stream);
+            s.slot_why[pipe_slot] |= kQPublishBack;
+            db->rerun_publish++;
+            s.slot_publish[pipe_slot] = false;
+            return run_again();
         }
         s.slot_publish[pipe_slot] = false;
         return rc;
     }
     s.slot_fused[pipe_slot] = false;
-    if (s.slot_rerun[pipe_slot]) {
-        // enqueued behind a single launch that ended without closing its query (below): this one ran on per-query state
-        // nobody had re-zeroed, and its block's checksum only covers the block's own hits -- run it again
-        s.slot_rerun[pipe_slot] = false;
-        const int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
-        if (rc != GSIM_OK) return rc;
-        return wait_stream(s.stream);
-    }
     volatile uint32_t* flag = &static_cast<gsim_result_header*>(out)->flags; // (flags | epoch << 8: one 16-byte store with the rest of the header)
     const uint32_t want = s.slot_epoch[pipe_slot];
     bool done = false;
@@ -487,19 +518,25 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
     }
     if (done && !torn) {
         s.redo_streak = s.redo_streak < 6 ? s.redo_streak + 1 : 6;
-        if (s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
+        if (backoff && s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
+        s.slot_why[pipe_slot] |= kQHandedBack;
+        db->rerun_own++;
+    } else if (torn) {
+        s.slot_why[pipe_slot] |= kQTorn;
+        db->rerun_torn++;
     }
     if (!done) {
-        // the launch ended without closing the query: the state is re-zeroed, and the later queries of a pipelined call --
-        // the stream has drained, so they have all run already, on that state -- are run again
+        // The launch ended without closing the query: the state is re-zeroed, and the later queries of a pipelined call --
+        // the stream has drained, so they have all run already, on that state -- are run again, whichever
+        // route they took (every slot in flight, not only the single launch's)
         s.state_dirty = true;
+        s.slot_why[pipe_slot] |= kQRerunBehind;
+        db->rerun_behind++;
         for (uint32_t j = 0; j < static_cast<uint32_t>(kPipe); j++)
-            if (j != pipe_slot && s.slot_fused[j]) s.slot_rerun[j] = true;
+            if (j != pipe_slot && s.slot_inflight[j]) s.slot_rerun[j] = true;
     }
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
-    int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
-    if (rc != GSIM_OK) return rc;
-    return wait_stream(s.stream);
+    return run_again();
 }
 
 // One query through the single-query pipeline on every shard, host merge across shards
@@ -525,6 +562,7 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
         int rc = finish_query_sync(db, s, query, k, cutoff, metric, alpha, beta,
                                    db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
         if (rc != GSIM_OK) return rc;
+        if (db->query_flags_at < db->query_flags.size()) db->query_flags[db->query_flags_at] |= s.slot_why[0];
         const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
         const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
         ap += h->approx;
@@ -586,6 +624,7 @@ int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uin
             const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta,
                                              db->row_base + static_cast<uint32_t>(s.first_row), out, done % kPipe);
             if (rc != GSIM_OK) return rc;
+            if (done < db->query_flags.size()) db->query_flags[done] |= s.slot_why[done % kPipe];
             const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
             const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
             ap += h->approx;
@@ -630,6 +669,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
     const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(kout, db->nrows));
     const size_t nsh = db->shards.size();
     std::vector<gsim_hit> merged;
+    db->query_flags.assign(db->timing ? nq : 0, 0); // (gsim_debug_query_flags: how each query of this call was routed / re-run)
     if (db->fold > 1) {
         if (metric != GSIM_METRIC_TANIMOTO) return fail(GSIM_ERR_INVALID, "folded tables support Tanimoto only");
         return search_folded(db, queries, nq, kout, cutoff, hits, counts, approx);
@@ -645,6 +685,7 @@ int gsim_db_search(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k
         return search_each_pipelined(db, queries, nq, k, kout, cutoff, metric, alpha, beta, hits, counts, approx);
     for (uint32_t q = 0; q < nq; q++) {
         const uint32_t* query = queries + static_cast<size_t>(q) * db->W;
+        db->query_flags_at = q;
         rc = search_one(db, query, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout, &counts[q],
                         approx ? &approx[q] : nullptr, merged);
         if (rc != GSIM_OK) return rc;
@@ -662,7 +703,9 @@ int gsim_db_search_timed(gsim_db* db, const uint32_t* queries, uint32_t nq, uint
     std::lock_guard<std::mutex> guard(db->search_mutex);
     const uint32_t k = static_cast<uint32_t>(std::min<uint64_t>(kout, db->nrows));
     std::vector<gsim_hit> merged;
+    db->query_flags.assign(db->timing ? nq : 0, 0);
     for (uint32_t q = 0; q < nq; q++) {
+        db->query_flags_at = q;
         const auto t0 = std::chrono::steady_clock::now();
         rc = search_one(db, queries + static_cast<size_t>(q) * db->W, k, cutoff, metric, alpha, beta, hits + static_cast<size_t>(q) * kout,
                         &counts[q], approx ? &approx[q] : nullptr, merged);

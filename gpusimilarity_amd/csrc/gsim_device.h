@@ -157,9 +157,13 @@ struct Knobs {
     int fused_debug = 0;             // GSIM_FUSED_DEBUG         in-kernel phase stamps
     int fused_flags = 0;             // GSIM_FUSED_FLAGS
     int fused_seed_narrow = 1;       // GSIM_FUSED_SEED_NARROW
-    int fused_publish = 1;           // GSIM_FUSED_PUBLISH       0: k above 8192 scans with the four-kernel pipeline's scan
+    int fused_publish = 1;           // GSIM_FUSED_PUBLISH       0: k in (2048, 8192] is ranked inside the single launch, k above 8192 scans with the four-kernel pipeline
     int fused_select_max_k = 2048;   // GSIM_FUSED_SELECT_MAX_K  largest k the single launch ranks itself (2048 ... 8192) where it can also publish for the large-k kernels
     int largek_one_block_max = 32768; // GSIM_LARGEK_ONE_BLOCK_MAX
+    int fused_backoff = 1;           // GSIM_FUSED_BACKOFF       0: a query handed back never routes later ones around the single launch
+    int publish_min_rows_per_k = 0;  // GSIM_PUBLISH_MIN_ROWS_PER_K  tables shorter than this many rows per hit rank large k inside the launch (up
+                                     // to round 5: 64 -- short tables publish most of their rows; measured in round 6 the publishing route is
+                                     // still 1.5 ... 6 x faster there and hands nothing back: profiles/r06_short_tables_large_k.txt)
     int largek_binrank = 1;          // GSIM_LARGEK_BINRANK      0: the published rows of a large-k query always go through the radix select + sort
     int each_pipeline = 1;           // GSIM_EACH_PIPELINE       0: gsim_db_search_each waits for every query before the next
     int batch = 1;                   // GSIM_BATCH               0: no shared table passes

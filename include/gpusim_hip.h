@@ -86,7 +86,7 @@ typedef struct {
     uint64_t handed_back_why;   /* union of the reasons, since the handle was created: 1 a wave's candidate store or a
                                    workgroup's list overflowed (heavy ties, ascending scores), 2 / 4 a wait ran out
                                    (GPU shared with another process), 8 more rows at the final threshold than a
-                                   selector holds, 16 more of them owned by one selector than its list holds, 64 (k above 4096)
+                                   selector holds, 16 more of them owned by one selector than its list holds, 64 (k in (GSIM_FUSED_SELECT_MAX_K = 2048, 32768], rows of at least 512 bits: the publishing route)
                                    more rows in one of the top score bins than the bin-ranked emission takes (ties)     */
     uint64_t batches_dense_cutoff; /* multi-query passes, since the handle was created, whose cutoff kept so many rows that the
                                       matrix-core pass counted them from its accumulators (gsim_prefilter.h cutoff_band)      */
@@ -101,6 +101,16 @@ typedef struct {
     uint64_t large_k_single_scan;  /* since the handle was created: shard queries with k above 2048 whose scan was the single launch's
                                       (it publishes, other kernels rank: DESIGN.md section 3); the rest of them were ranked inside it (k up to 8192)
                                       or took the four-kernel pipeline's scan */
+    /* Why synchronous queries (gsim_db_search, _each, _timed) ran a second time on the four-kernel pipeline, counted on the host
+     * since the handle was created -- `handed_back` above is the DEVICE's count of single launches that ended with a hand-back and
+     * equals rerun_own + rerun_publish when nothing else went wrong: */
+    uint64_t rerun_own;     /* the query's own single launch handed it back (reasons: handed_back_why)                          */
+    uint64_t rerun_publish; /* large k: its publishing launch, or the bin-ranked emission behind it, handed it back             */
+    uint64_t rerun_behind;  /* it ran behind a launch that ended without closing its query (GPU shared: a wait ran out and the
+                               kernel was gone before its header): every query in flight on that state is run again            */
+    uint64_t rerun_torn;    /* = blocks_torn                                                                                    */
+    uint64_t backoff_skips; /* queries routed AROUND the single launch (or its publishing mode / the bin-ranked emission) because
+                               earlier ones were handed back: they scan once, on the four-kernel pipeline, and are not hand-backs */
 } gsim_timing;
 
 /* ---- device enumeration / placement ------------------------------------- */
@@ -299,6 +309,12 @@ int gsim_db_set_comm_root(gsim_db* db, int shard);
 /* ---- instrumentation ------------------------------------------------------ */
 int gsim_db_enable_timing(gsim_db* db, int enable); /* resets the accumulators */
 int gsim_db_get_timing(gsim_db* db, gsim_timing* out); /* synchronises the stream */
+/* With timing enabled: one byte per query of the handle's LAST gsim_db_search / _each / _timed call (first min(n, queries) bytes of
+ * `flags`; *written = how many) -- 1 its own single launch handed it back, 2 run again behind a launch that did not close its query,
+ * 4 its block's checksum never matched, 8 routed around the single launch by the back-off, 16 large k: publishing launch or
+ * bin-ranked emission handed it back, 32 large k: routed around those by a back-off.  For the tests that compare the pipelined
+ * entry point with one query at a time. */
+int gsim_debug_query_flags(gsim_db* db, uint8_t* flags, uint32_t n, uint32_t* written);
 /* score of every (common, popc_db) pair for a query of popcount a, computed ON
  * THE DEVICE with the scan kernel's arithmetic: out[c * (max_b+1) + b].  Used
  * by the parity tests to pin the f32 divide bit for bit. */

@@ -310,3 +310,37 @@ print("ok")
         env = dict(os.environ, GSIM_FUSED_FLAGS=flags, GSIM_FUSED_SELECT_MAX_K="8192")
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=600)
         assert out.returncode == 0 and b"ok" in out.stdout, flags + ": " + out.stdout.decode()[-1500:] + out.stderr.decode()[-3000:]
+
+
+def test_pipelined_hand_backs_equal_one_at_a_time_under_both_elections():
+    """VERDICT r05 item 2.  A 300 k-row Morgan-shaped table at k = 8192 ranked INSIDE the single launch (the round-5 route of
+    tables shorter than 64 rows per hit: GSIM_PUBLISH_MIN_ROWS_PER_K=64) hands many queries back for "more rows at the final
+    threshold than a selector holds".  With the back-off off (GSIM_FUSED_BACKOFF=0: every query tries the single launch) the
+    queries whose OWN launch hands them back are the same through gsim_db_search_each (eight in flight) and one at a time
+    (gsim_db_search_timed), pass after pass, under the sampled election and under the ranked one (GSIM_FUSED_FLAGS=8192); the
+    ranked election -- the tighter threshold -- never hands back a query the sampled one keeps; nothing is run again for any
+    other reason; every result equals the first pass's (the script asserts it).  Round 5's "2011 against 1704" was the back-off:
+    with it on, a hand-back routes the next queries AROUND the launch (gsim_timing.backoff_skips), and how many of the failing
+    queries land in those windows depends on how many fail -- fewer failures, shorter windows, more attempts, more hand-backs.
+    And on the round-6 default route (the launch publishes, short tables too) the same queries hand nothing back."""
+    import json
+    script = os.path.join(ROOT, "scripts", "trace_handbacks.py")
+    res = {}
+    for name, env in (("sampled", {"GSIM_FUSED_FLAGS": "0"}), ("ranked", {"GSIM_FUSED_FLAGS": "8192"})):
+        e = dict(os.environ, GSIM_FUSED_BACKOFF="0", GSIM_PUBLISH_MIN_ROWS_PER_K="64", SOAK_KIND="morgan", **env)
+        out = subprocess.run([sys.executable, script, "300000", "8192", "6"], env=e, capture_output=True, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-3000:]
+        res[name] = r = json.loads(out.stdout.decode().strip().splitlines()[-1])
+        one, pipe = r["one_at_a_time"], r["pipelined"]
+        assert one["handed_back_by_query"] == pipe["handed_back_by_query"], (name, one, pipe)
+        assert all(v == 6 for v in one["handed_back_by_query"].values()), one  # deterministic: every pass, the same queries
+        for m in (one, pipe):
+            assert m["device_handed_back"] == m["rerun_own"] == sum(m["handed_back_by_query"].values()), m
+            assert m["rerun_behind"] == 0 and m["rerun_torn"] == 0 and m["rerun_publish"] == 0 and m["backoff_skips"] == 0, m
+    assert set(res["ranked"]["one_at_a_time"]["handed_back_by_query"]) <= set(res["sampled"]["one_at_a_time"]["handed_back_by_query"])
+    assert len(res["sampled"]["one_at_a_time"]["handed_back_by_query"]) > 0  # (the table does what the test is about)
+    out = subprocess.run([sys.executable, script, "300000", "8192", "6"], env=dict(os.environ, SOAK_KIND="morgan"), capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    r = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    for m in (r["one_at_a_time"], r["pipelined"]):
+        assert m["device_handed_back"] == 0 and m["rerun_own"] + m["rerun_publish"] + m["rerun_behind"] + m["rerun_torn"] + m["backoff_skips"] == 0, m
