@@ -259,7 +259,7 @@ def compact_line(out, detail_path):
         line["cpu_baseline"] = {k_: out["cpu_baseline"].get(k_) for k_ in ("value", "unit", "cores", "kind", "sample")}
     if out.get("collective"):
         c = out["collective"]
-        cc = {k_: c.get(k_) for k_ in ("backend", "world", "launcher", "data_path_collective", "queries_in_flight", "shared_gpu_test_mode", "rccl")
+        cc = {k_: c.get(k_) for k_ in ("backend", "world", "launcher", "data_path_collective", "queries_in_flight", "shared_gpu_test_mode", "rccl", "identical_hits_across_routes")
               if c.get(k_) is not None or k_ in ("backend", "world")}
         cc["ranks"] = [{"rank": m.get("rank"), "device": m.get("device"), "pci_bus_id": m.get("pci_bus_id")} for m in c.get("ranks", [])]
         if c.get("per_rank"):
@@ -613,6 +613,7 @@ def in_process(args):
     except capi.GsimError as e:
         routes["gsim_comm"] = {"error": str(e)}
     shards = table.shard_count()
+    shard_devices = table.shard_devices()
     table.close()
     if comm is not None:
         comm.close()
@@ -653,6 +654,14 @@ def in_process(args):
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (R * (args.fp_bits // 8) / (hm["kernel_ms_avg_first_shard"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if hm["kernel_ms_avg_first_shard"] else None,
                      "traffic": None, "kernel_ms_avg": hm["kernel_ms_avg_first_shard"]},
         "routes": routes,
+        # who is in the job (the one-process route's "ranks" are the handle's shards, one per device) and what crosses xGMI
+        "collective": {"backend": routes.get("gsim_comm", {}).get("transport", "gsim_comm failed"), "world": shards,
+                       "ranks": [{"rank": i, "device": "hip:%d" % d, "pci_bus_id": None} for i, d in enumerate(shard_devices)],
+                       "launcher": "one process, %d devices" % N,
+                       "data_path_collective": "gsim_comm route: one grouped ncclAllGather of the shards' result blocks per query, %d B per shard, "
+                                               "then merge_kernel on the root's device; host_merge route: none (pinned blocks, k-way merge on the host)"
+                                               % capi.result_block_bytes(k),
+                       "rccl": capi.rccl_info(), "identical_hits_across_routes": bool(routes.get("gsim_comm", {}).get("identical_to_host_merge"))},
     }
     emit(out, json_fd, "bench_detail_inprocess.json")
 
@@ -756,6 +765,11 @@ def main():
                                            "%d B per rank" % capi.result_block_bytes(k)) if world > 1 else None}
     if share:
         collective["shared_gpu_test_mode"] = True
+    if dist.is_initialized():  # (the C-ABI library's own view; the torch route's collectives run on torch's librccl.so either way)
+        try:
+            collective["rccl"] = dict(capi.rccl_info(), torch_nccl_version=".".join(str(x) for x in torch.cuda.nccl.version()))
+        except Exception as e:
+            collective["rccl"] = {"error": repr(e)}
 
     table = make_table(R, args.fp_bits, rank * R)
     if args.batch_queries:

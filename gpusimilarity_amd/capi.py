@@ -35,7 +35,7 @@ class GsimTiming(C.Structure):
                 ("collectives", C.c_uint64), ("gather_ms_sum", C.c_double), ("merge_ms_sum", C.c_double),
                 ("blocks_rechecked", C.c_uint64), ("blocks_torn", C.c_uint64), ("batches_regrown", C.c_uint64),
                 ("large_k_single_scan", C.c_uint64), ("rerun_own", C.c_uint64), ("rerun_publish", C.c_uint64),
-                ("rerun_behind", C.c_uint64), ("rerun_torn", C.c_uint64), ("backoff_skips", C.c_uint64)]
+                ("rerun_behind", C.c_uint64), ("rerun_torn", C.c_uint64), ("lane_queries", C.c_uint64), ("backoff_skips", C.c_uint64)]
 
 
 class GsimError(RuntimeError):
@@ -54,7 +54,7 @@ EXPORTS = [
     "gsim_db_shard_count", "gsim_db_shard_device", "gsim_db_search", "gsim_db_search_each", "gsim_db_search_timed", "gsim_db_search_cpu", "gsim_db_set_stream", "gsim_db_set_row_base",
     "gsim_result_block_bytes", "gsim_db_search_device", "gsim_merge_device", "gsim_db_search_batch_device",
     "gsim_merge_device_batch", "gsim_merge_host",
-    "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_db_set_comm", "gsim_db_set_comm_root",
+    "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_rccl_info", "gsim_db_set_comm", "gsim_db_set_comm_root",
     "gsim_db_enable_timing",
     "gsim_db_get_timing", "gsim_debug_query_flags", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
 ]
@@ -118,6 +118,7 @@ def load():
         "gsim_merge_host": (C.c_int, [vp, C.c_uint32, C.c_size_t, C.c_uint32, vp]),
         "gsim_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
         "gsim_comm_destroy": (C.c_int, [vp]),
+        "gsim_rccl_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
         "gsim_comm_size": (C.c_int, [vp]),
         "gsim_db_set_comm": (C.c_int, [vp, vp]),
         "gsim_db_set_comm_root": (C.c_int, [vp, C.c_int]),
@@ -349,6 +350,15 @@ class Table:
         w = C.c_uint32(0)
         check(self._L.gsim_debug_query_flags(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n, C.byref(w)))
         return out[:w.value]
+
+
+def rccl_info() -> dict:
+    """gsim_rccl_info: the RCCL header version the library was built with, the version and file of the librccl.so bound to this process."""
+    L = load()
+    h, r = C.c_int(0), C.c_int(0)
+    buf = C.create_string_buffer(1024)
+    check(L.gsim_rccl_info(C.byref(h), C.byref(r), buf, len(buf)))
+    return {"header_version": h.value, "runtime_version": r.value, "path": buf.value.decode()}
 
 
 class Comm:

@@ -9,6 +9,8 @@
 
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 struct gsim_comm {
     std::vector<int> devices;       // logical device per rank, in the order of the handle's shards
     std::vector<ncclComm_t> comms;  // one communicator per device (ncclCommInitAll); empty: loop-back
@@ -253,9 +255,37 @@ using namespace gsim_host;
 
 extern "C" {
 
+// Which RCCL is this process bound to?  libgsim_hip.so names librccl.so as a dependency with /opt/rocm/lib on its run path,
+// but a process that loaded another librccl.so FIRST (PyTorch ships its own and loads it at import) keeps that one: the
+// loader resolves a dependency by soname to what is already mapped.  The five entry points used here (ncclCommInitAll,
+// ncclGroupStart/End, ncclAllGather, ncclCommDestroy + ncclGetErrorString) exist unchanged in every NCCL/RCCL 2.x, so a
+// different MINOR version is reported, not refused; a different MAJOR version is refused by gsim_comm_create.
+int gsim_rccl_info(int* header_version, int* runtime_version, char* path, size_t path_bytes)
+{
+    if (header_version) *header_version = NCCL_VERSION_CODE;
+    int v = 0;
+    const ncclResult_t r = ncclGetVersion(&v);
+    if (r != ncclSuccess) return fail_nccl(r, "ncclGetVersion");
+    if (runtime_version) *runtime_version = v;
+    if (path && path_bytes) {
+        Dl_info info{};
+        const char* p = (dladdr(reinterpret_cast<void*>(&ncclGetVersion), &info) && info.dli_fname) ? info.dli_fname : "";
+        std::snprintf(path, path_bytes, "%s", p);
+    }
+    return GSIM_OK;
+}
+
 int gsim_comm_create(const int* devices, int ndevices, gsim_comm** out)
 {
     if (!devices || !out || ndevices < 1) return fail(GSIM_ERR_INVALID, "NULL / empty argument");
+    {
+        int rt = 0;
+        const int rc = gsim_rccl_info(nullptr, &rt, nullptr, 0);
+        if (rc != GSIM_OK) return rc;
+        if (rt / 10000 != NCCL_VERSION_CODE / 10000)
+            return fail(GSIM_ERR_STATE, "the librccl.so bound to this process is version " + std::to_string(rt) + ", this library was built against " +
+                                            std::to_string(NCCL_VERSION_CODE) + ": a different major version (gsim_rccl_info names the file)");
+    }
     int ndev = 0;
     gsim_device_count(&ndev);
     if (ndev == 0) return fail(GSIM_ERR_NO_DEVICE, "no GPU available");

@@ -136,7 +136,7 @@ int gsim_db_enable_timing(gsim_db* db, int enable)
     std::lock_guard<std::mutex> guard(db->search_mutex);
     db->timing = enable != 0;
     db->acc = gsim_timing{};
-    for (auto& s : db->shards) {
+    auto rebase = [&](Shard& s) -> int {
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
         unsigned long long c = 0, f = 0;
@@ -146,6 +146,13 @@ int gsim_db_enable_timing(gsim_db* db, int enable)
         s.base_ncand = c;
         s.base_nfinal = f;
         s.base_nredo = r;
+        return GSIM_OK;
+    };
+    for (auto& s : db->shards) {
+        int rc = rebase(s);
+        for (auto& l : s.lanes)
+            if (rc == GSIM_OK) rc = rebase(l);
+        if (rc != GSIM_OK) return rc;
     }
     db->acc = gsim_timing{};
     return GSIM_OK;
@@ -159,7 +166,7 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
     db->acc.finalists_sum = 0;
     db->acc.handed_back = 0;
     db->acc.handed_back_why = 0;
-    for (auto& s : db->shards) {
+    auto fold = [&](Shard& s) -> int {
         int rc = drain_timing(db, s);
         if (rc != GSIM_OK) return rc;
         unsigned long long c = 0, f = 0;
@@ -170,7 +177,15 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out)
         db->acc.finalists_sum += f - s.base_nfinal;
         db->acc.handed_back += r - s.base_nredo;
         db->acc.handed_back_why |= s.h_state->redo_why & (31u | gsim::kRedoBinTies); // (bit 5 = "a selector saw it fail": not a reason of its own)
+        return GSIM_OK;
+    };
+    for (auto& s : db->shards) {
+        int rc = fold(s);
+        for (auto& l : s.lanes) // (the half-grid lanes of gsim_db_search_each on small tables: own state, own events)
+            if (rc == GSIM_OK) rc = fold(l);
+        if (rc != GSIM_OK) return rc;
     }
+    db->acc.lane_queries = db->lane_queries;
     db->acc.batches_dense_cutoff = db->dense_batches;
     db->acc.blocks_rechecked = db->blocks_rechecked;
     db->acc.blocks_torn = db->blocks_torn;

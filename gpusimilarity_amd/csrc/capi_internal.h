@@ -72,6 +72,12 @@ constexpr int kPipe = 8; // single queries of one gsim_db_search_each call enque
 struct Shard {
     int device = 0;
     int num_cus = 256;
+    int cu_share = 1;       // > 1: a LANE of another shard -- its grids are sized for num_cus / cu_share compute units (see `lanes`)
+    // Small tables, gsim_db_search_each: the query's launch streams for half its time and selects for the other half, and
+    // launches on one stream serialise.  Two lanes = two half-grid copies of this shard's search state (own stream, per-query
+    // state, regions, exchange buffer; the SAME rows): consecutive queries alternate between them, so one query's scan
+    // overlaps the other's selection (capi_query.cpp search_each_pipelined; made on first use).
+    std::vector<Shard> lanes;
     uint64_t first_row = 0; // offset inside the handle's table
     uint64_t nrows = 0;
     uint32_t W = 0;         // words per row ON THE DEVICE (table width / fold factor)
@@ -209,6 +215,7 @@ struct gsim_db {
     unsigned long long batch_regrown = 0; // batches run again with larger candidate segments
     std::atomic<unsigned long long> large_k_published{0}; // shard queries with k > kSelectCap scanned by the single launch
     // why synchronous queries were run a second time / routed around the single launch (host-side counts, gsim_timing.rerun_*)
+    unsigned long long lane_queries = 0; // shard queries of gsim_db_search_each answered by a half-grid lane
     unsigned long long rerun_own = 0, rerun_behind = 0, rerun_torn = 0, rerun_publish = 0, backoff_skips = 0;
     size_t query_flags_at = 0;        // ... the query search_one is answering
     std::vector<uint8_t> query_flags; // kQ* bits of every query of the last gsim_db_search / _each call (timing enabled)

@@ -49,6 +49,8 @@ gsim::Knobs read_knobs()
     k.fused_backoff = env_value("GSIM_FUSED_BACKOFF", k.fused_backoff);
     k.publish_min_rows_per_k = std::max(env_value("GSIM_PUBLISH_MIN_ROWS_PER_K", k.publish_min_rows_per_k), 0);
     k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
+    k.each_lanes = env_value("GSIM_EACH_LANES", k.each_lanes);
+    k.each_lanes_max_mb = env_value("GSIM_EACH_LANES_MAX_MB", k.each_lanes_max_mb);
     k.batch = env_value("GSIM_BATCH", k.batch);
     k.batch_waves_per_cu = env_value("GSIM_BATCH_WAVES_PER_CU", k.batch_waves_per_cu);
     k.batch_seg_cap = env_value("GSIM_BATCH_SEG_CAP", k.batch_seg_cap);
@@ -94,6 +96,8 @@ hipError_t set_device(int logical)
 
 int free_shard(Shard& s)
 {
+    for (auto& l : s.lanes) (void) free_shard(l); // (they share s.d_rows and do not own it)
+    s.lanes.clear();
     (void) set_device(s.device);
     if (s.stream) (void) hipStreamSynchronize(s.stream);
     if (s.owns_rows && s.d_rows) (void) hipFree(s.d_rows);
@@ -158,7 +162,8 @@ int setup_shard(gsim_db* db, Shard& s)
     GSIM_HIP(set_device(s.device));
     hipDeviceProp_t prop;
     GSIM_HIP(hipGetDeviceProperties(&prop, phys_device(s.device)));
-    s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    s.num_cus = (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) / (s.cu_share > 0 ? s.cu_share : 1);
+    if (s.num_cus < 1) s.num_cus = 1;
     GSIM_HIP(hipStreamCreateWithFlags(&s.own_stream, hipStreamNonBlocking));
     s.stream = s.own_stream;
     const gsim::Knobs& kn = db->knobs;

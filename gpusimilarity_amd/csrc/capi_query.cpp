@@ -579,10 +579,46 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
     return GSIM_OK;
 }
 
+// Two half-grid lanes of a shard (Shard::lanes), made on first use: the same rows, half the compute units each, own
+// stream / per-query state / regions / exchange buffer.
+int ensure_lanes(gsim_db* db, Shard& s)
+{
+    if (!s.lanes.empty()) return GSIM_OK;
+    s.lanes.resize(2);
+    for (auto& l : s.lanes) {
+        l.device = s.device;
+        l.cu_share = 2;
+        l.first_row = s.first_row;
+        l.nrows = s.nrows;
+        l.W = s.W;
+        l.d_rows = s.d_rows;
+        l.owns_rows = false;
+        const int rc = setup_shard(db, l);
+        if (rc != GSIM_OK) {
+            for (auto& x : s.lanes) (void) free_shard(x);
+            s.lanes.clear();
+            return rc;
+        }
+    }
+    return GSIM_OK;
+}
+
+// Does a pipelined call alternate this shard's queries between its two lanes?  Only where the single launch ranks the query
+// itself (k up to fused_select_max_k) on a table small enough that the chain behind the scan is a large part of the launch.
+bool lanes_apply(const gsim_db* db, const Shard& s, uint32_t k, uint32_t nq)
+{
+    if (!db->knobs.each_lanes || nq < 4 || s.stream != s.own_stream || s.d_dbg || db->knobs.fused_debug) return false;
+    if (s.nrows * s.W * 4ull > static_cast<uint64_t>(db->knobs.each_lanes_max_mb) << 20) return false;
+    if (s.nrows < 65536) return false; // (tiny tables: the half grid is no smaller than the whole one)
+    return fused_applies(db, s, k) && !fused_publish_applies(db, s, k);
+}
+
 // gsim_db_search_each on a single-shard handle: the queries still run strictly one after the other on the GPU (one
 // stream, one per-query state), but up to kPipe of them are enqueued ahead of the one the host is waiting for, each with
 // its own pinned result block and completion word -- the next kernel starts when the previous one retires instead of
 // after a host round trip (flag seen, hits copied, next launch: ~8 us per query).
+// Round 6, small tables (lanes_apply): consecutive queries alternate between the shard's two half-grid lanes, whose
+// launches run side by side -- one query's scan overlaps the other's selection.
 int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uint32_t k, uint32_t kout, float cutoff, int metric,
                           float alpha, float beta, gsim_hit* hits, uint32_t* counts, uint64_t* approx)
 {
@@ -591,7 +627,12 @@ int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uin
     // pinned block per shard; the host merges query q's blocks while the devices run q + 1 ... q + kPipe - 1
     const size_t nsh = db->shards.size();
     const size_t blk = gsim_result_block_bytes(k);
-    for (auto& s : db->shards) {
+    std::vector<char> use_lanes(nsh, 0);
+    for (size_t i = 0; i < nsh; i++) {
+        Shard& s = db->shards[i];
+        if (s.nrows && lanes_apply(db, s, k, nq) && ensure_lanes(db, s) == GSIM_OK) use_lanes[i] = 1; // (no lanes: the shard itself, as before)
+    }
+    auto pipe_blocks = [&](Shard& s) -> int {
         GSIM_HIP(set_device(s.device));
         if (blk > s.h_pipe_block) {
             if (s.h_pipe) GSIM_HIP(hipHostFree(s.h_pipe));
@@ -600,31 +641,46 @@ int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uin
             GSIM_HIP(hipHostMalloc(reinterpret_cast<void**>(&s.h_pipe), blk * kPipe, kHostPolled));
             s.h_pipe_block = blk;
         }
+        return GSIM_OK;
+    };
+    for (size_t i = 0; i < nsh; i++) {
+        int rc = pipe_blocks(db->shards[i]);
+        if (use_lanes[i])
+            for (auto& l : db->shards[i].lanes)
+                if (rc == GSIM_OK) rc = pipe_blocks(l);
+        if (rc != GSIM_OK) return rc;
     }
+    // query q of the call on shard i: which search state answers it, and in which of its pipeline slots
+    auto state_of = [&](size_t i, uint32_t q) -> Shard& { return use_lanes[i] ? db->shards[i].lanes[q & 1u] : db->shards[i]; };
+    auto slot_of = [&](size_t i, uint32_t q) -> uint32_t { return (use_lanes[i] ? q >> 1 : q) % kPipe; };
     std::vector<gsim_hit> merged;
     std::vector<size_t> ends;
     uint32_t issued = 0;
     for (uint32_t done = 0; done < nq; done++) {
         for (; issued < nq && issued - done < static_cast<uint32_t>(kPipe); issued++) {
-            for (auto& s : db->shards) {
-                if (s.nrows == 0) continue;
+            for (size_t i = 0; i < nsh; i++) {
+                if (db->shards[i].nrows == 0) continue;
+                Shard& s = state_of(i, issued);
+                const uint32_t slot = slot_of(i, issued);
                 const int rc = enqueue_query(db, s, queries + static_cast<size_t>(issued) * db->W, k, cutoff, metric, alpha, beta,
-                                             db->row_base + static_cast<uint32_t>(s.first_row), s.h_pipe + (issued % kPipe) * s.h_pipe_block, true,
-                                             kAuto, issued % kPipe);
+                                             db->row_base + static_cast<uint32_t>(s.first_row), s.h_pipe + slot * s.h_pipe_block, true, kAuto, slot);
                 if (rc != GSIM_OK) return rc;
+                if (use_lanes[i]) db->lane_queries++;
             }
         }
         uint64_t ap = 0;
         merged.clear();
         ends.clear();
-        for (auto& s : db->shards) {
-            if (s.nrows == 0) continue;
+        for (size_t i = 0; i < nsh; i++) {
+            if (db->shards[i].nrows == 0) continue;
+            Shard& s = state_of(i, done);
+            const uint32_t slot = slot_of(i, done);
             GSIM_HIP(set_device(s.device));
-            void* out = s.h_pipe + (done % kPipe) * s.h_pipe_block;
+            void* out = s.h_pipe + slot * s.h_pipe_block;
             const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta,
-                                             db->row_base + static_cast<uint32_t>(s.first_row), out, done % kPipe);
+                                             db->row_base + static_cast<uint32_t>(s.first_row), out, slot);
             if (rc != GSIM_OK) return rc;
-            if (done < db->query_flags.size()) db->query_flags[done] |= s.slot_why[done % kPipe];
+            if (done < db->query_flags.size()) db->query_flags[done] |= s.slot_why[slot];
             const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
             const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
             ap += h->approx;

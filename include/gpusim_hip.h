@@ -109,6 +109,8 @@ typedef struct {
     uint64_t rerun_behind;  /* it ran behind a launch that ended without closing its query (GPU shared: a wait ran out and the
                                kernel was gone before its header): every query in flight on that state is run again            */
     uint64_t rerun_torn;    /* = blocks_torn                                                                                    */
+    uint64_t lane_queries;  /* since the handle was created: shard queries of gsim_db_search_each that ran on one of the shard's two
+                               half-grid lanes (small tables: consecutive queries overlap)                  */
     uint64_t backoff_skips; /* queries routed AROUND the single launch (or its publishing mode / the bin-ranked emission) because
                                earlier ones were handed back: they scan once, on the four-kernel pipeline, and are not hand-backs */
 } gsim_timing;
@@ -298,6 +300,11 @@ typedef struct gsim_comm gsim_comm;
  * gsim_db_finalize(db, device, n) places shard i on device + i). */
 int gsim_comm_create(const int* devices, int ndevices, gsim_comm** out);
 int gsim_comm_destroy(gsim_comm* comm); /* detach it from every handle first (gsim_db_set_comm(db, NULL)) */
+/* The RCCL this process is bound to: NCCL_VERSION_CODE of the header the library was built with, ncclGetVersion() of the
+ * library the loader resolved, and that library's file (a process that imported PyTorch first runs on PyTorch's own
+ * librccl.so, not /opt/rocm/lib's).  gsim_comm_create refuses a different MAJOR version; a different minor one is this
+ * call's to report (the entry points used are unchanged across 2.x).  Any pointer may be NULL. */
+int gsim_rccl_info(int* header_version, int* runtime_version, char* path, size_t path_bytes);
 int gsim_comm_size(const gsim_comm* comm);
 /* Route gsim_db_search / gsim_db_search_each of this handle through the communicator (NULL: back to the host
  * merge).  The communicator's devices must be the shards' devices, in order.  Not for folded tables. */

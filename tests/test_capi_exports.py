@@ -115,3 +115,18 @@ def test_seam_b_adapter_compiles_against_the_reference_header():
     if r.returncode == 77:
         pytest.skip("reference / Qt headers not present")
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_rccl_info_names_the_bound_library():
+    """gsim_rccl_info (no GPU needed): the header version the library was built with, and the version + file of the librccl.so
+    the loader bound -- PyTorch's own when torch was imported first (capi.load does), /opt/rocm/lib's otherwise; the version it
+    reports is that file's own ncclGetVersion."""
+    import ctypes
+    import os
+    from gpusimilarity_amd import capi
+    info = capi.rccl_info()
+    assert info["header_version"] >= 20000 and info["runtime_version"] // 10000 == info["header_version"] // 10000, info
+    assert os.path.exists(info["path"]) and "rccl" in os.path.basename(info["path"]), info
+    v = ctypes.c_int(0)
+    ctypes.CDLL(info["path"]).ncclGetVersion(ctypes.byref(v))
+    assert v.value == info["runtime_version"], (v.value, info)

@@ -82,3 +82,28 @@ def test_server_shards_over_aliased_devices(gpus, merge, monkeypatch, tmp_path):
         H.check_frames(srv, "gpu")
     finally:
         srv.close()
+
+
+def test_bench_in_process_on_four_aliased_devices_names_its_collective():
+    """the first contact with a real multi-GPU node must not be able to fail on plumbing.  `bench.py --gpus 4
+    --in-process` on four aliased devices (test-hooks build): ONE line under 12 KB, `collective.world == 4` with all four ranks
+    listed and the data-path collective named, the RCCL the library is bound to reported, identical hits between the host merge
+    and the gsim_comm route asserted by the script itself and stated in the line, every route timed."""
+    import json
+    from conftest import hooks_env
+    env = hooks_env(GSIM_TEST_ALIAS_DEVICES="4")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--in-process", "--steps", "2", "--warmup", "1",
+                          "--queries-per-step", "16", "--rows-per-gpu", "2000000", "--no-torch-route"], env=env, capture_output=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 12000, (len(lines), len(lines[0]) if lines else 0)
+    d = json.loads(lines[0])
+    c = d["collective"]
+    assert d["n_gpus"] == 4 and c["world"] == 4 and [m["rank"] for m in c["ranks"]] == [0, 1, 2, 3]
+    assert len({m["device"] for m in c["ranks"]}) == 4 and "ncclAllGather" in c["data_path_collective"]
+    assert c["identical_hits_across_routes"] is True and d["routes"]["gsim_comm"]["identical_to_host_merge"] is True
+    assert c["rccl"]["runtime_version"] // 10000 == c["rccl"]["header_version"] // 10000 and os.path.exists(c["rccl"]["path"])
+    for name in ("host_merge", "gsim_comm", "twin"):
+        assert d["routes"][name]["ms_per_query"] > 0, name
+    assert d["routes"]["gsim_comm"]["collectives"] == 2 * 16 and d["routes"]["gsim_comm"]["gather_us_avg"] > 0
+    assert d["config"]["shards"] == 4 and d["value"] > 0 and "roofline" in d
