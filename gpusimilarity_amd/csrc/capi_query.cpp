@@ -583,11 +583,12 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
 // stream / per-query state / regions / exchange buffer.
 int ensure_lanes(gsim_db* db, Shard& s)
 {
+    const int nl = db->knobs.each_lanes >= 4 ? 4 : 2; // (three 85-CU lanes were measured too: their grids hand queries back)
     if (!s.lanes.empty()) return GSIM_OK;
-    s.lanes.resize(2);
+    s.lanes.resize(static_cast<size_t>(nl));
     for (auto& l : s.lanes) {
         l.device = s.device;
-        l.cu_share = 2;
+        l.cu_share = nl;
         l.first_row = s.first_row;
         l.nrows = s.nrows;
         l.W = s.W;
@@ -607,7 +608,7 @@ int ensure_lanes(gsim_db* db, Shard& s)
 // itself (k up to fused_select_max_k) on a table small enough that the chain behind the scan is a large part of the launch.
 bool lanes_apply(const gsim_db* db, const Shard& s, uint32_t k, uint32_t nq)
 {
-    if (!db->knobs.each_lanes || nq < 4 || s.stream != s.own_stream || s.d_dbg || db->knobs.fused_debug) return false;
+    if (db->knobs.each_lanes < 2 || nq < 4 || s.stream != s.own_stream || s.d_dbg || db->knobs.fused_debug) return false;
     if (s.nrows * s.W * 4ull > static_cast<uint64_t>(db->knobs.each_lanes_max_mb) << 20) return false;
     if (s.nrows < 65536) return false; // (tiny tables: the half grid is no smaller than the whole one)
     return fused_applies(db, s, k) && !fused_publish_applies(db, s, k);
@@ -651,8 +652,8 @@ int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uin
         if (rc != GSIM_OK) return rc;
     }
     // query q of the call on shard i: which search state answers it, and in which of its pipeline slots
-    auto state_of = [&](size_t i, uint32_t q) -> Shard& { return use_lanes[i] ? db->shards[i].lanes[q & 1u] : db->shards[i]; };
-    auto slot_of = [&](size_t i, uint32_t q) -> uint32_t { return (use_lanes[i] ? q >> 1 : q) % kPipe; };
+    auto state_of = [&](size_t i, uint32_t q) -> Shard& { return use_lanes[i] ? db->shards[i].lanes[q % db->shards[i].lanes.size()] : db->shards[i]; };
+    auto slot_of = [&](size_t i, uint32_t q) -> uint32_t { return (use_lanes[i] ? q / static_cast<uint32_t>(db->shards[i].lanes.size()) : q) % kPipe; };
     std::vector<gsim_hit> merged;
     std::vector<size_t> ends;
     uint32_t issued = 0;

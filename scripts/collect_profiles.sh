@@ -4,7 +4,7 @@
 #   the per-query timeline at 1 M rows, and the SQ counters of the matrix-core batch pass.
 set -uo pipefail
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_r05
+OUT=gpurun_out/prof_r06
 rm -rf "$OUT"; mkdir -p "$OUT"
 R="rocprofv3 --output-format csv"
 # (the headline alone: the default run also measures configs[1] and configs[4] in the same process, whose launches of the same

@@ -327,7 +327,8 @@ def test_pipelined_hand_backs_equal_one_at_a_time_under_both_elections():
     script = os.path.join(ROOT, "scripts", "trace_handbacks.py")
     res = {}
     for name, env in (("sampled", {"GSIM_FUSED_FLAGS": "0"}), ("ranked", {"GSIM_FUSED_FLAGS": "8192"})):
-        e = dict(os.environ, GSIM_FUSED_BACKOFF="0", GSIM_PUBLISH_MIN_ROWS_PER_K="64", SOAK_KIND="morgan", **env)
+        # (GSIM_EACH_LANES=0: one stream, the whole grid -- on the two half-grid lanes a query meets other thresholds than one at a time)
+        e = dict(os.environ, GSIM_FUSED_BACKOFF="0", GSIM_PUBLISH_MIN_ROWS_PER_K="64", GSIM_EACH_LANES="0", SOAK_KIND="morgan", **env)
         out = subprocess.run([sys.executable, script, "300000", "8192", "6"], env=e, capture_output=True, timeout=600)
         assert out.returncode == 0, out.stderr.decode()[-3000:]
         res[name] = r = json.loads(out.stdout.decode().strip().splitlines()[-1])
@@ -339,8 +340,52 @@ def test_pipelined_hand_backs_equal_one_at_a_time_under_both_elections():
             assert m["rerun_behind"] == 0 and m["rerun_torn"] == 0 and m["rerun_publish"] == 0 and m["backoff_skips"] == 0, m
     assert set(res["ranked"]["one_at_a_time"]["handed_back_by_query"]) <= set(res["sampled"]["one_at_a_time"]["handed_back_by_query"])
     assert len(res["sampled"]["one_at_a_time"]["handed_back_by_query"]) > 0  # (the table does what the test is about)
+    # the same on the two lanes (half grids: their own set of failing queries), back-off off: the books still balance, pass after pass
+    e = dict(os.environ, GSIM_FUSED_BACKOFF="0", GSIM_PUBLISH_MIN_ROWS_PER_K="64", GSIM_EACH_LANES="2", SOAK_KIND="morgan")
+    out = subprocess.run([sys.executable, script, "300000", "8192", "6"], env=e, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    m = json.loads(out.stdout.decode().strip().splitlines()[-1])["pipelined"]
+    assert m["device_handed_back"] == m["rerun_own"] == sum(m["handed_back_by_query"].values()) and m["rerun_behind"] == 0 and m["rerun_torn"] == 0, m
     out = subprocess.run([sys.executable, script, "300000", "8192", "6"], env=dict(os.environ, SOAK_KIND="morgan"), capture_output=True, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     r = json.loads(out.stdout.decode().strip().splitlines()[-1])
     for m in (r["one_at_a_time"], r["pipelined"]):
         assert m["device_handed_back"] == 0 and m["rerun_own"] + m["rerun_publish"] + m["rerun_behind"] + m["rerun_torn"] + m["backoff_skips"] == 0, m
+
+
+def test_pipelined_queries_on_two_half_grid_lanes_match_the_oracle():
+    """Round 6: gsim_db_search_each on a small table alternates consecutive queries between the shard's two
+    half-grid lanes -- own stream, per-query state, regions and exchange buffer each, the same rows -- so one query's scan
+    overlaps the other's selection (1 M rows: 39.6 -> 27.9 us per query).  Every result equals the oracle's, single queries of
+    the same handle (whole grid) in between included; gsim_timing.lane_queries counts them; k above the single launch's own
+    ranking (the publishing route) and GSIM_EACH_LANES=0 do not use lanes."""
+    for n, kind, seed in ((1_000_003, 0, 0x1A9E5), (300_000, O.KIND_MORGAN, 0x1A9E6)):
+        db = O.synth_rows_mt(seed, kind, 0, n, 32)
+        t = make_table(db)
+        t.enable_timing(True)
+        qs = np.ascontiguousarray(np.stack([db[O.query_row(i, n)] for i in range(37)]))
+        lane_q = 0
+        for k, cutoff in ((1000, 0.0), (10, 0.0), (2048, 0.0), (100, 0.12)):
+            bufs = t.make_search_buffers(len(qs), k)
+            t.search_each_into(qs, k, bufs, cutoff)
+            lane_q += len(qs)
+            assert t.timing()["lane_queries"] == lane_q
+            for i in range(len(qs)):
+                want, wap = O.search(qs[i], db, k, np.float32(cutoff), nthreads=16)
+                assert int(bufs[2][i]) == wap, (n, k, i)
+                assert_hits_equal(bufs[0][i, :bufs[1][i]], want, "lanes n=%d k=%d q=%d" % (n, k, i))
+            h, ap = t.search(qs[5], k, cutoff)  # one at a time: the whole grid, the shard's own state
+            want, wap = O.search(qs[5], db, k, np.float32(cutoff), nthreads=16)
+            assert int(ap[0]) == wap
+            assert_hits_equal(h[0], want, "single n=%d k=%d" % (n, k))
+        bufs = t.make_search_buffers(len(qs), 5000)  # the publishing route: no lanes
+        t.search_each_into(qs, 5000, bufs)
+        assert t.timing()["lane_queries"] == lane_q
+        assert t.timing()["handed_back"] == 0
+        t.close()
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from gpusimilarity_amd import capi\n"
+            "t = capi.Table(1024); t.generate(1, 0, 0, 500000, 0); t.enable_timing(True)\n"
+            "q = np.ascontiguousarray(np.stack([capi.synth_row(1, 0, i, 1024) for i in range(16)])); b = t.make_search_buffers(16, 100)\n"
+            "t.search_each_into(q, 100, b); assert t.timing()['lane_queries'] == 0; assert (b[0][:, 0]['row'] == np.arange(16)).all(); print('ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSIM_EACH_LANES="0"), capture_output=True, timeout=300)
+    assert out.returncode == 0 and b"ok" in out.stdout, out.stderr.decode()[-2000:]
