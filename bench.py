@@ -908,6 +908,8 @@ def main():
         try:
             cfgs.append(single_cfg("large k: 100M x 1024-bit, Tanimoto top-20000 (single launch publishes, bin-ranked emission)", 100_000_000,
                                    kind, 32, k_=20000))
+            cfgs.append(single_cfg("large k: 100M x 1024-bit, Tanimoto top-50000 (single launch publishes, bin-ranked emission)", 100_000_000,
+                                   kind, 16, k_=50000))
             cfgs.append(single_cfg("large k: 1M x 1024-bit, Tanimoto top-8192", 1_000_000, kind, 128, k_=8192))
         except Exception as e:
             cfgs.append({"name": "large k", "error": repr(e)})

@@ -81,12 +81,13 @@ bool fused_applies(const gsim_db* db, const Shard& s, uint32_t k)
 // finalists"); at 100 M rows k = 4096 0.856 -> 0.872 of the roofline.
 bool fused_publish_applies(const gsim_db* db, const Shard& s, uint32_t k)
 {
-    if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(db->knobs.fused_select_max_k) || k > gsim::kFusedPublishMaxK || s.nrows == 0 ||
+    if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(db->knobs.fused_select_max_k) || k > static_cast<uint32_t>(db->knobs.fused_publish_max_k) || s.nrows == 0 ||
         !gsim::fused_supported(s.fgeo))
         return false;
     if (s.fgeo.lanes_per_row < 4 || s.fgeo.ragged_words || s.fgeo.ragged_loads) return false;
-    if (gsim::fused_summary_keys(s.fgeo.nwaves, k, 64) == 0) return false; // (no thresholds: every row would be published)
+    if (gsim::fused_summary_keys(s.fgeo.nwaves, k, gsim::fused_publish_max_m(k)) == 0) return false; // (no thresholds: every row would be published)
     if (s.nrows < static_cast<uint64_t>(db->knobs.publish_min_rows_per_k) * k) return false; // (a short table: the thresholds come late and most of it is published)
+    if (k > 65536u && s.nrows < 32ull * k) return false; // (measured: 1 M rows, k = 100 000 -- a tenth of the table -- 286 us classic, 303 published)
     const long long max_rows = db->knobs.fused_max_rows;
     return max_rows < 0 || s.nrows <= static_cast<uint64_t>(max_rows);
 }
@@ -271,7 +272,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         f.hdr = s.d_hdr;
         f.arrive = s.d_summ + 4096 + kTicketWords;
         f.summ = s.d_summ;
-        f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k, 64);
+        f.summ_keys = gsim::fused_summary_keys(s.fgeo.nwaves, k, gsim::fused_publish_max_m(k));
         f.final_keys = 0; // (no end-of-scan reports: nobody elects a final threshold)
         f.tickets = s.d_summ + 4096;
         f.wait_ticks = static_cast<uint32_t>(std::min<uint64_t>(200000ull + static_cast<uint64_t>(s.nrows) * s.W * 4 / 10000ull, 0xFFFFFFFFull));
@@ -293,7 +294,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             // The caller reads the block: a hand-back costs a second run, not a wrong answer -- so the finalists are placed by coarse
             // bin and ranked inside their bins (two launches; the radix select + gather + sort are four and a gap).  Tables whose
             // top bins hold more than kBinRankCap rows (ties) hand that back: the next large-k queries take the radix tail.
-            if (db->knobs.largek_binrank && s.binrank_skip == 0) {
+            if (db->knobs.largek_binrank && s.binrank_skip == 0 && k <= static_cast<uint32_t>(db->knobs.largek_binrank_max_k)) {
                 GSIM_HIP(gsim::launch_fused_binsort(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.d_bincur, s.stream));
                 if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
                 GSIM_HIP(gsim::launch_binrank_emit(a, s.d_final, s.final_cap, s.d_bincur, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
@@ -304,7 +305,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
                 }
                 return record_slot_event(s, pipe_slot);
             }
-            if (s.binrank_skip) {
+            if (s.binrank_skip && k <= static_cast<uint32_t>(db->knobs.largek_binrank_max_k)) {
                 s.binrank_skip--;
                 s.slot_why[pipe_slot] |= kQSkipPublish;
                 db->backoff_skips++;

@@ -98,7 +98,11 @@ struct ScanArgs {
 
 // ---- single-launch path: scan + publish + select in ONE kernel --------------------------------
 constexpr uint32_t kFusedMaxK = 8192;       // largest k the single-launch path serves
-constexpr uint32_t kFusedPublishMaxK = 32768; // ... and the largest it scans and publishes for (k > kSelectCap: the large-k kernels rank what it published)
+constexpr uint32_t kFusedPublishMaxK = 262144; // ... and the largest it scans and publishes for (k > kSelectCap: the large-k kernels rank what it published)
+// M of the publishing launch's in-loop reports: up to 64 as long as 64 rows per wave cover k (65 536 hits on 1024 waves), up to 256 beyond
+// (mth_best keeps four keys per lane -- eight from M = 65 on -- i.e. 256 / 512 per wave: a report is the wave's M-th best of those,
+// valid at any M, tight while M is well below that)
+constexpr uint32_t fused_publish_max_m(uint32_t k) { return k > 65536u ? 256u : 64u; }
 constexpr uint32_t kFusedPublishOnly = 2048u; // FusedArgs::xflags: scan + publish, no selection (launch_fused_handoff follows)
 constexpr int kFusedWaveCap = 2048;         // candidate slots per wavefront, in LDS
 constexpr int kFusedSelectors = 256;        // workgroups of the grid: every one of them ranks its share of the finalists
@@ -160,6 +164,11 @@ struct Knobs {
     int fused_publish = 1;           // GSIM_FUSED_PUBLISH       0: k in (2048, 8192] is ranked inside the single launch, k above 8192 scans with the four-kernel pipeline
     int fused_select_max_k = 2048;   // GSIM_FUSED_SELECT_MAX_K  largest k the single launch ranks itself (2048 ... 8192) where it can also publish for the large-k kernels
     int largek_one_block_max = 32768; // GSIM_LARGEK_ONE_BLOCK_MAX
+    int fused_publish_max_k = 100000; // GSIM_FUSED_PUBLISH_MAX_K (up to kFusedPublishMaxK; round 5: 32768).  Measured at 100 M rows (profiles/r06_large_k.txt):
+                                      // k = 50 000 2.18 -> 1.93 ms (0.83 of the roofline), 100 000 2.31 -> 2.17; at 131 072 and beyond the waves' stores
+                                      // overflow before the first useful election and the queries are handed back: slower than the four-kernel pipeline
+    int largek_binrank_max_k = 65536; // GSIM_LARGEK_BINRANK_MAX_K  above it the published rows go through the radix select + sort (measured: 100 M rows, k = 100 000
+                                      // 2.31 ms bin-ranked with hand-backs for crowded bins, 2.11 ms by the radix tail; at k = 50 000 1.94 against 1.97)
     int fused_backoff = 1;           // GSIM_FUSED_BACKOFF       0: a query handed back never routes later ones around the single launch
     int publish_min_rows_per_k = 0;  // GSIM_PUBLISH_MIN_ROWS_PER_K  tables shorter than this many rows per hit rank large k inside the launch (up
                                      // to round 5: 64 -- short tables publish most of their rows; measured in round 6 the publishing route is

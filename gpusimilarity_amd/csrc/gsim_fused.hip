@@ -286,6 +286,7 @@ struct FusedFilter {
     // smaller key, for which the statement still holds).
     __device__ __forceinline__ u64 mth_best(int lane) const
     {
+        if (M > 64u) return mth_best_deep(lane); // (wave-uniform; only the publishing launch of k above 65 536)
         u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         for (uint32_t i = lane; i < staged; i += 64) {
             const u64 v = skey[i];
@@ -307,6 +308,38 @@ struct FusedFilter {
                 t1 = t2;
                 t2 = t3;
                 t3 = 0;
+            }
+        }
+        return mth;
+    }
+
+    // ... with eight keys per lane (512 per wave) for M up to 256: k above 65 536 through the publishing launch.  Rare and long
+    // (M rounds).  Scalars, not an array, and inlined: a call or an indexed array put the kernel on scratch memory.
+    __device__ __forceinline__ u64 mth_best_deep(int lane) const
+    {
+        u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0;
+        for (uint32_t i = lane; i < staged; i += 64) {
+            const u64 v = skey[i];
+            if (v > t7) {
+                t7 = v;
+                if (t7 > t6) { const u64 x = t6; t6 = t7; t7 = x; }
+                if (t6 > t5) { const u64 x = t5; t5 = t6; t6 = x; }
+                if (t5 > t4) { const u64 x = t4; t4 = t5; t5 = x; }
+                if (t4 > t3) { const u64 x = t3; t3 = t4; t4 = x; }
+                if (t3 > t2) { const u64 x = t2; t2 = t3; t3 = x; }
+                if (t2 > t1) { const u64 x = t1; t1 = t2; t2 = x; }
+                if (t1 > t0) { const u64 x = t0; t0 = t1; t1 = x; }
+            }
+        }
+        u64 mth = 0;
+#pragma unroll 1
+        for (uint32_t r = 0; r < M; r++) {
+            const uint32_t hi = wave_max_u32(static_cast<uint32_t>(t0 >> 32));
+            const uint32_t lo = wave_max_u32(static_cast<uint32_t>(t0 >> 32) == hi ? static_cast<uint32_t>(t0) : 0u);
+            mth = (static_cast<u64>(hi) << 32) | lo;
+            const u64 b = __ballot(t0 == mth);
+            if (lane == __builtin_ctzll(b)) {
+                t0 = t1; t1 = t2; t2 = t3; t3 = t4; t4 = t5; t5 = t6; t6 = t7; t7 = 0;
             }
         }
         return mth;

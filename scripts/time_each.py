@@ -10,11 +10,11 @@ import numpy as np
 from bench import DB_SEED, query_row, synth_row
 from gpusimilarity_amd import capi
 
-NQ = 512
+NQ = int(os.environ.get("TE_NQ", "512"))
 ks = [int(x) for x in os.environ.get("TE_K", "1000").split(",")]
 kinds = os.environ.get("TE_KINDS", "sparse,morgan").split(",")
 sizes = [int(x) for x in sys.argv[1:]] or [100_000, 300_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000]
-label = " ".join("%s=%s" % (e, os.environ[e]) for e in ("GSIM_EACH_LANES", "GSIM_EACH_LANES_MAX_MB", "TE_TIMING") if e in os.environ) or "default"
+label = " ".join("%s=%s" % (e, os.environ[e]) for e in ("GSIM_EACH_LANES", "GSIM_EACH_LANES_MAX_MB", "TE_TIMING", "GSIM_FUSED_PUBLISH_MAX_K", "GSIM_LARGEK_BINRANK") if e in os.environ) or "default"
 for n in sizes:
     for kn in kinds:
         kind = {"sparse": capi.SYNTH_SPARSE, "morgan": capi.SYNTH_MORGAN}[kn]
@@ -26,10 +26,10 @@ for n in sizes:
             ref = t.make_search_buffers(64, k)
             sec = t.search_timed_into(qs[:64], k, ref)
             t_warm = time.perf_counter()
-            while time.perf_counter() - t_warm < 0.3:
+            while time.perf_counter() - t_warm < float(os.environ.get("TE_WARM_S", "0.3")):
                 t.search_each_into(qs, k, bufs)
             t.enable_timing(os.environ.get("TE_TIMING", "0") == "1")  # (HIP events around every kernel lengthen the gaps between launches)
-            reps = 6
+            reps = int(os.environ.get("TE_REPS", "6"))
             t0 = time.perf_counter()
             for _ in range(reps):
                 t.search_each_into(qs, k, bufs)

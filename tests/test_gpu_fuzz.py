@@ -88,7 +88,7 @@ def test_random_odd_width_tables_match_the_oracle(seed):
 
 def large_k_walk(seed, stats=None):
     """One random table of 150 k (every third seed: 20 k) ... 3 M rows of 512 ... 4096 bits (i.i.d., dense, Morgan-shaped; every fifth with heavy
-    duplication), eight queries with k from 2049 to 40000 (cutoffs, Tversky) through gsim_db_search and the same queries through
+    duplication), eight queries with k from 2049 to 200 000 (cutoffs, Tversky) through gsim_db_search and the same queries through
     the pipelined gsim_db_search_each, each against the oracle: the single launch publishes and the rows are placed by score
     bin and ranked inside their bins -- or (ties, k above 32768, hand-backs) the radix tail / the four-kernel pipeline answers."""
     rng = np.random.default_rng(0x1A26E + seed)
@@ -103,7 +103,7 @@ def large_k_walk(seed, stats=None):
     cases = []
     for case in range(8):
         q = db[int(rng.integers(n))] if rng.random() < 0.8 else O.synth_rows(0x1A269999 + seed, 0 if kind != 1 else 1, 50 + case, 1, W)[0]
-        k = int(rng.choice([2049, 2500, 3000, 4096, 4097, 6000, 8192, 8193, 12000, 20000, 32768, 32769, 40000]))
+        k = int(rng.choice([2049, 2500, 3000, 4096, 4097, 6000, 8192, 8193, 12000, 20000, 32768, 32769, 40000, 50000, 65536, 65537, 100000, 131072, 131073, 200000]))
         cutoff = float(rng.choice([0.0, 0.0, 0.0, 0.03, 0.1, 0.4]))
         cases.append((q, k, cutoff, tv if rng.random() < 0.25 else {}))
     nq = 0
