@@ -47,6 +47,7 @@ gsim::Knobs read_knobs()
     k.fused_select_max_k = std::min(std::max(env_value("GSIM_FUSED_SELECT_MAX_K", k.fused_select_max_k), 2048), static_cast<int>(gsim::kFusedMaxK)); // (the large-k sort takes k > 2048)
     k.largek_one_block_max = env_value("GSIM_LARGEK_ONE_BLOCK_MAX", k.largek_one_block_max);
     k.fused_backoff = env_value("GSIM_FUSED_BACKOFF", k.fused_backoff);
+    k.publish_narrow = env_value("GSIM_PUBLISH_NARROW", k.publish_narrow);
     k.largek_binrank_max_k = env_value("GSIM_LARGEK_BINRANK_MAX_K", k.largek_binrank_max_k);
     k.fused_publish_max_k = std::min(std::max(env_value("GSIM_FUSED_PUBLISH_MAX_K", k.fused_publish_max_k), 2048), static_cast<int>(gsim::kFusedPublishMaxK));
     k.publish_min_rows_per_k = std::max(env_value("GSIM_PUBLISH_MIN_ROWS_PER_K", k.publish_min_rows_per_k), 0);

@@ -84,7 +84,8 @@ bool fused_publish_applies(const gsim_db* db, const Shard& s, uint32_t k)
     if (!db->knobs.fused || !db->knobs.fused_publish || k <= static_cast<uint32_t>(db->knobs.fused_select_max_k) || k > static_cast<uint32_t>(db->knobs.fused_publish_max_k) || s.nrows == 0 ||
         !gsim::fused_supported(s.fgeo))
         return false;
-    if (s.fgeo.lanes_per_row < 4 || s.fgeo.ragged_words || s.fgeo.ragged_loads) return false;
+    if (s.fgeo.ragged_words || s.fgeo.ragged_loads) return false;
+    if (s.fgeo.lanes_per_row < 4 && !db->knobs.publish_narrow) return false; // (128 / 256-bit rows: seeded like the ranking launch, enqueue_query_impl)
     if (gsim::fused_summary_keys(s.fgeo.nwaves, k, gsim::fused_publish_max_m(k)) == 0) return false; // (no thresholds: every row would be published)
     if (s.nrows < static_cast<uint64_t>(db->knobs.publish_min_rows_per_k) * k) return false; // (a short table: the thresholds come late and most of it is published)
     if (k > 65536u && s.nrows < 32ull * k) return false; // (measured: 1 M rows, k = 100 000 -- a tenth of the table -- 286 us classic, 303 published)
@@ -287,6 +288,12 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             GSIM_HIP(hipMemsetAsync(s.d_bincur, 0, static_cast<size_t>(gsim::kScanBins) * 8, s.stream));
         }
         if (ev) GSIM_HIP(hipEventRecord(ev[0], s.stream));
+        // narrow rows: the sampled seed, as for the ranking launch above (a wave's store fills before the first election otherwise)
+        if (db->knobs.fused_seed_narrow && s.geo.lanes_per_row != 0 && s.geo.lanes_per_row <= 2 && s.nrows > 1500ull * s.fgeo.nwaves && s.sample_chunks > 0) {
+            bool seeded = false;
+            GSIM_HIP(gsim::launch_sample(a, s.geo, 1u, s.stream, &seeded, db->knobs.sample_shift));
+            if (seeded) f.xflags |= 4u;
+        }
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
         db->large_k_published++;
         if (caller_syncs) {

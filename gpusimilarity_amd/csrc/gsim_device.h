@@ -167,6 +167,7 @@ struct Knobs {
     int fused_publish_max_k = 100000; // GSIM_FUSED_PUBLISH_MAX_K (up to kFusedPublishMaxK; round 5: 32768).  Measured at 100 M rows (profiles/r06_large_k.txt):
                                       // k = 50 000 2.18 -> 1.93 ms (0.83 of the roofline), 100 000 2.31 -> 2.17; at 131 072 and beyond the waves' stores
                                       // overflow before the first useful election and the queries are handed back: slower than the four-kernel pipeline
+    int publish_narrow = 1;           // GSIM_PUBLISH_NARROW      0: 128 / 256-bit rows never take the publishing launch for large k (round 5)
     int largek_binrank_max_k = 65536; // GSIM_LARGEK_BINRANK_MAX_K  above it the published rows go through the radix select + sort (measured: 100 M rows, k = 100 000
                                       // 2.31 ms bin-ranked with hand-backs for crowded bins, 2.11 ms by the radix tail; at k = 50 000 1.94 against 1.97)
     int fused_backoff = 1;           // GSIM_FUSED_BACKOFF       0: a query handed back never routes later ones around the single launch

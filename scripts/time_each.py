@@ -11,16 +11,17 @@ from bench import DB_SEED, query_row, synth_row
 from gpusimilarity_amd import capi
 
 NQ = int(os.environ.get("TE_NQ", "512"))
+BITS = int(os.environ.get("TE_BITS", "1024"))
 ks = [int(x) for x in os.environ.get("TE_K", "1000").split(",")]
 kinds = os.environ.get("TE_KINDS", "sparse,morgan").split(",")
 sizes = [int(x) for x in sys.argv[1:]] or [100_000, 300_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000]
-label = " ".join("%s=%s" % (e, os.environ[e]) for e in ("GSIM_EACH_LANES", "GSIM_EACH_LANES_MAX_MB", "TE_TIMING", "GSIM_FUSED_PUBLISH_MAX_K", "GSIM_LARGEK_BINRANK") if e in os.environ) or "default"
+label = " ".join("%s=%s" % (e, os.environ[e]) for e in ("GSIM_EACH_LANES", "GSIM_EACH_LANES_MAX_MB", "TE_TIMING", "GSIM_FUSED_PUBLISH_MAX_K", "GSIM_LARGEK_BINRANK", "GSIM_PUBLISH_NARROW", "TE_BITS") if e in os.environ) or "default"
 for n in sizes:
     for kn in kinds:
         kind = {"sparse": capi.SYNTH_SPARSE, "morgan": capi.SYNTH_MORGAN}[kn]
-        t = capi.Table(1024)
+        t = capi.Table(BITS)
         t.generate(DB_SEED, kind, 0, n, 0)
-        qs = np.ascontiguousarray(np.stack([synth_row(DB_SEED, kind, query_row(i % 64, n), 32) for i in range(NQ)]))
+        qs = np.ascontiguousarray(np.stack([synth_row(DB_SEED, kind, query_row(i % 64, n), BITS // 32) for i in range(NQ)]))
         for k in ks:
             bufs = t.make_search_buffers(NQ, k)
             ref = t.make_search_buffers(64, k)

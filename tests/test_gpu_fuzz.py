@@ -92,7 +92,7 @@ def large_k_walk(seed, stats=None):
     the pipelined gsim_db_search_each, each against the oracle: the single launch publishes and the rows are placed by score
     bin and ranked inside their bins -- or (ties, k above 32768, hand-backs) the radix tail / the four-kernel pipeline answers."""
     rng = np.random.default_rng(0x1A26E + seed)
-    W = int(rng.choice([16, 32, 32, 32, 64, 128]))
+    W = int(rng.choice([16, 32, 32, 32, 64, 128])) if seed % 4 else int(rng.choice([4, 8]))  # (every fourth: 128 / 256-bit rows)
     n = int(np.exp(rng.uniform(np.log(20_000 if seed % 3 == 1 else 150_000), np.log(3_000_000 if W <= 32 else 700_000))))  # (every third: short tables too)
     kind = int(rng.choice([0, 0, 1, O.KIND_MORGAN])) if W == 32 else int(rng.choice([0, 1]))
     db = O.synth_rows(0x1A260000 + seed, kind, 0, n, W)
