@@ -470,22 +470,30 @@ MFMA_ISSUE_PROBE = ((0, 38.2), (4, 38.1), (8, 57.6), (12, 69.7))
 # ... and the shipped 2048-bit kernel's vector instructions per MFMA, SQ_INSTS_VALU / SQ_INSTS_MFMA
 # (profiles/r05_batch_mfma_pmc_raw.txt; 5 of them are the operand expansion, round 5 could not take them out: DESIGN.md section 3)
 BATCH_VALU_PER_MFMA = {64: 7.6}
+# ... and of its dense-cutoff variant (batch_mfma_kernel<64,1,1,4096,2,true>: one row tile per wave -- with two it spills 104 registers --
+# and the band classification of every pair: profiles/r06_batch_cutoff_pmc_raw.txt, 12.80 G vector instructions per 1.000 G MFMAs)
+BATCH_VALU_PER_MFMA_DENSE = {64: 12.8}
 
 
-def issue_roofline(W, frac):
-    n = BATCH_VALU_PER_MFMA.get(W)
+def issue_roofline(W, frac, dense=False):
+    n = (BATCH_VALU_PER_MFMA_DENSE if dense else BATCH_VALU_PER_MFMA).get(W)
     if n is None or not frac:
         return None
     pts = MFMA_ISSUE_PROBE
-    cyc = pts[-1][1]
+    (n0, c0), (n1, c1) = pts[-2], pts[-1]
+    cyc = c1 + (c1 - c0) * (n - n1) / (n1 - n0)  # beyond the probe's last point: its last slope (3.0 cycles per instruction)
     for (n0, c0), (n1, c1) in zip(pts, pts[1:]):
         if n0 <= n <= n1:
             cyc = c0 + (c1 - c0) * (n - n0) / (n1 - n0)
             break
     ceiling = 32.0 / cyc
-    return {"valu_per_mfma": n, "issue_ceiling_frac_of_peak": ceiling, "issue_frac": frac / ceiling,
-            "source": "profiles/r01_mfma_fp4_probe.txt (cycles per MFMA at n vector instructions, two waves per SIMD) and "
-                      "profiles/r05_batch_mfma_pmc_raw.txt (SQ_INSTS_VALU / SQ_INSTS_MFMA of this kernel)"}
+    out = {"valu_per_mfma": n, "issue_ceiling_frac_of_peak": ceiling, "issue_frac": frac / ceiling,
+           "source": "profiles/r01_mfma_fp4_probe.txt (cycles per MFMA at n vector instructions, two waves per SIMD) and "
+                     + ("profiles/r06_batch_cutoff_pmc_raw.txt" if dense else "profiles/r05_batch_mfma_pmc_raw.txt") + " (SQ_INSTS_VALU / SQ_INSTS_MFMA of this kernel)"}
+    if dense:
+        out["note"] = ("below its issue ceiling: the dense variant runs ONE row tile per wave (a single dependent MFMA chain; with two the "
+                       "kernel spills 104 registers and takes 65.8 ms) -- DESIGN.md section 3")
+    return out
 
 
 def time_batches(ctx, table, total_rows, R, fp_bits, kind, k, Q, steps, warmup, sharded, cutoff=0.0):
@@ -545,7 +553,7 @@ def time_batches(ctx, table, total_rows, R, fp_bits, kind, k, Q, steps, warmup, 
         "roofline": {"kernel": "batch_mfma_kernel<%d> (MX-FP4 contraction of the packed bits, f32 accumulate: exact)" % W,
                      "bound": "mfma", "achieved": tf_kernel, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf_kernel / MFMA_FP4_PEAK_TFLOPS, "traffic": None, "kernel_ms_avg": kms,
-                     "issue": issue_roofline(W, tf_kernel / MFMA_FP4_PEAK_TFLOPS) if not cutoff else None,
+                     "issue": issue_roofline(W, tf_kernel / MFMA_FP4_PEAK_TFLOPS, dense=bool(cutoff)),
                      "whole_step_tflops": flops / per / 1e12,
                      "timed_with_hip_events": tm["batches"],
                      "table_bytes_read_once_per_batch_GBs": R * fp_bits / 8 / per / 1e9},
@@ -694,6 +702,8 @@ def main():
     ap.add_argument("--batch-queries", type=int, default=0,
                     help="BASELINE configs[4] instead of the headline run: Tversky(0.3, 0.7) batches of this many "
                          "queries per step (use with --fp-bits 2048); a step is one batch")
+    ap.add_argument("--cutoff", type=float, default=0.0, help="--batch-queries: similarity cutoff of the batch (0.1 keeps 4.5 %% of the synthetic table per query: "
+                                                               "the dense-cutoff variant of the contraction kernel counts them)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the process rocprofv3 counts (pmc_traffic)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--in-process", action="store_true",
@@ -782,7 +792,7 @@ def main():
     table = make_table(R, args.fp_bits, rank * R)
     if args.batch_queries:
         Q = args.batch_queries
-        res = time_batches(ctx, table, total_rows, R, args.fp_bits, kind, k, Q, args.steps, args.warmup, sharded)
+        res = time_batches(ctx, table, total_rows, R, args.fp_bits, kind, k, Q, args.steps, args.warmup, sharded, cutoff=np.float32(args.cutoff))
         out = {
             "metric": "(query, fingerprint) pairs scored/sec (%d-bit Tversky(0.3,0.7), %d-query batches, top-%d)" % (args.fp_bits, Q, k),
             "value": res["pairs_per_s"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1159,6 +1159,9 @@ hipError_t launch_batch_mfma_scan(const BatchArgs& a, int num_cus, hipStream_t s
     // runs the batch; any other batch it leaves alone.  Weights without a usable band (cutoff_band): the VALU pass,
     // re-enqueued by the host when it finds flag 8 without flag 16.
     if (a.cutoff > 0.0f && batch_mfma_dense_applies(a.metric, a.alpha, a.beta, a.cutoff, (a.opts & 2u) != 0)) {
+        // (2048-bit rows: ONE row tile per wave.  With two -- the plain kernel's shape -- the sixteen per-query counters and the band constants no
+        // longer fit beside the 128 registers of expanded queries: 100-104 registers spilled whichever way the epilogue is ordered, 65.8 ms
+        // against 39.9, round 6.  The single MFMA chain per wave is why this variant sits at 0.74 of its issue ceiling: DESIGN.md section 3)
         if (a.W == 64) launch_variant<64, 1, 1, kMChunks, 2, true>(a, num_cus, s);
         else if (a.W == 32) launch_variant<32, 1, 2, kMChunks, 2, true>(a, num_cus, s);
         else if (a.W == 16) launch_variant<16, 1, 2, kMChunks, 2, true>(a, num_cus, s);
