@@ -56,7 +56,7 @@ EXPORTS = [
     "gsim_merge_device_batch", "gsim_merge_host",
     "gsim_comm_create", "gsim_comm_destroy", "gsim_comm_size", "gsim_rccl_info", "gsim_db_set_comm", "gsim_db_set_comm_root",
     "gsim_db_enable_timing",
-    "gsim_db_get_timing", "gsim_debug_query_flags", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
+    "gsim_db_get_timing", "gsim_debug_query_flags", "gsim_debug_litmus", "gsim_debug_score_table", "gsim_debug_prefilter_constants", "gsim_debug_sort_desc", "gsim_last_error", "gsim_version",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
         "gsim_db_set_comm_root": (C.c_int, [vp, C.c_int]),
         "gsim_db_enable_timing": (C.c_int, [vp, C.c_int]),
         "gsim_db_get_timing": (C.c_int, [vp, C.POINTER(GsimTiming)]),
+        "gsim_debug_litmus": (C.c_int, [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_ulonglong)]),
         "gsim_debug_query_flags": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_uint32, C.POINTER(C.c_uint32)]),
         "gsim_debug_score_table": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                              C.c_uint32, C.POINTER(C.c_float)]),
@@ -350,6 +351,13 @@ class Table:
         w = C.c_uint32(0)
         check(self._L.gsim_debug_query_flags(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n, C.byref(w)))
         return out[:w.value]
+
+
+def litmus(test: int, workgroups: int = 256, iterations: int = 100000, device: int = 0) -> dict:
+    """gsim_debug_litmus -> {loads, torn, headers_seen, stale_first_read, never_landed, rereads, timed_out, stores}"""
+    st = (C.c_ulonglong * 8)()
+    check(load().gsim_debug_litmus(device, test, workgroups, iterations, st))
+    return dict(zip(("loads", "torn", "headers_seen", "stale_first_read", "never_landed", "rereads", "timed_out", "stores"), [int(x) for x in st]))
 
 
 def rccl_info() -> dict:

@@ -2,6 +2,8 @@
 // instrumented runs (GSIM_FUSED_DEBUG), device/host tables for the parity tests.
 #include "capi_internal.h"
 
+#include <chrono>
+
 namespace gsim_host
 {
 
@@ -207,6 +209,78 @@ int gsim_debug_query_flags(gsim_db* db, uint8_t* flags, uint32_t n, uint32_t* wr
     const uint32_t m = static_cast<uint32_t>(std::min<size_t>(n, db->query_flags.size()));
     if (m) std::memcpy(flags, db->query_flags.data(), m);
     if (written) *written = m;
+    return GSIM_OK;
+}
+
+// The litmus kernels of gsim_litmus.hip.  test 1: 16-byte sc1 stores against 16-byte sc1 loads of another workgroup; 2: 16-byte system-scope
+// stores into pinned host memory against a host that polls one word and reads the rest (finish_query_sync's way); 3: entry then header,
+// how often the header is visible first and whether a re-read always finds the entry (4: the entry stored by another wave, a barrier between).  `workgroups` (even; 256 = one per CU), `iterations`
+// stores per slot.  stats[8]: loads, torn values, headers seen, entries behind their header at the first read, entries that never caught up,
+// re-reads, readers / writers that ran out of time, stores.
+int gsim_debug_litmus(int device, int test, uint32_t workgroups, uint32_t iterations, unsigned long long* stats)
+{
+    if (!stats || test < 1 || test > 4 || workgroups < 2 || (workgroups & 1u) || workgroups > 4096 || iterations == 0) return fail(GSIM_ERR_INVALID, "litmus: bad argument");
+    int ndev = 0;
+    gsim_device_count(&ndev);
+    if (device < 0 || device >= ndev) return fail(GSIM_ERR_NO_DEVICE, "device index out of range");
+    GSIM_HIP(set_device(device));
+    const unsigned long long budget = 3000000000ull; // 30 s of the 100 MHz clock: a test that needs it has failed
+    unsigned long long* d_stats = nullptr;
+    GSIM_HIP(hipMalloc(reinterpret_cast<void**>(&d_stats), 8 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d_stats, 0, 8 * sizeof(unsigned long long));
+    void *d_a = nullptr, *d_b = nullptr, *h_slots = nullptr;
+    uint32_t* h_ack = nullptr;
+    unsigned long long host_obs = 0, host_torn = 0;
+    if (e == hipSuccess && test != 2) {
+        const size_t bytes = static_cast<size_t>(workgroups) * 32 * 16;
+        e = hipMalloc(&d_a, bytes);
+        if (e == hipSuccess) e = hipMalloc(&d_b, bytes);
+        if (e == hipSuccess) e = hipMemset(d_a, 0, bytes);
+        if (e == hipSuccess) e = hipMemset(d_b, 0, bytes);
+        if (e == hipSuccess) e = gsim::launch_litmus_pair(d_a, d_b, d_stats, workgroups, iterations, test == 3 ? 1 : (test == 4 ? 2 : 0), budget, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    } else if (e == hipSuccess) {
+        e = hipHostMalloc(&h_slots, static_cast<size_t>(workgroups) * 16, kHostPolled);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h_ack), static_cast<size_t>(workgroups) * 4, kHostPolled);
+        if (e == hipSuccess) {
+            std::memset(h_slots, 0, static_cast<size_t>(workgroups) * 16);
+            std::memset(h_ack, 0, static_cast<size_t>(workgroups) * 4);
+            e = gsim::launch_litmus_host(h_slots, h_ack, d_stats, workgroups, iterations, budget, nullptr);
+        }
+        if (e == hipSuccess) {
+            volatile uint32_t* w = static_cast<volatile uint32_t*>(h_slots);
+            std::vector<uint32_t> last(workgroups, 0);
+            uint32_t finished = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (finished < workgroups) {
+                for (uint32_t b = 0; b < workgroups; b++) {
+                    if (last[b] == iterations) continue;
+                    const uint32_t it = w[4 * b + 1]; // the polled word (a header's flags | epoch)
+                    if (it == last[b]) continue;
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    const uint32_t y = w[4 * b + 0], z = w[4 * b + 2], x3 = w[4 * b + 3];
+                    host_obs++;
+                    if (y != it * 0x9E3779B1u + b || z != (it ^ 0xA5A5A5A5u) + b * 0x85EBCA6Bu || x3 != ~it) host_torn++;
+                    last[b] = it;
+                    __atomic_store_n(&h_ack[b], it, __ATOMIC_RELEASE);
+                    if (it == iterations) finished++;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) break;
+            }
+            e = hipDeviceSynchronize();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpy(stats, d_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (test == 2) {
+        stats[0] = host_obs;
+        stats[1] = host_torn;
+    }
+    if (d_a) (void) hipFree(d_a);
+    if (d_b) (void) hipFree(d_b);
+    if (h_slots) (void) hipHostFree(h_slots);
+    if (h_ack) (void) hipHostFree(h_ack);
+    (void) hipFree(d_stats);
+    if (e != hipSuccess) return fail_hip(e, "litmus");
     return GSIM_OK;
 }
 

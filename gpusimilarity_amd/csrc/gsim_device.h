@@ -323,6 +323,11 @@ void prefilter_table_host(int tversky, float alpha, float beta, uint32_t max_qa,
 hipError_t launch_generate(void* rows, uint64_t seed, int kind, uint64_t first_row, uint64_t nrows,
                            uint32_t W, hipStream_t s);
 
+// gsim_litmus.hip: the hardware behaviours the single launch rests on, as litmus kernels (gsim_debug_litmus)
+hipError_t launch_litmus_pair(void* entries, void* headers, unsigned long long* stats, uint32_t nblocks, uint32_t iters, int with_header,
+                              unsigned long long budget_ticks, hipStream_t s);
+hipError_t launch_litmus_host(void* slots, const uint32_t* ack, unsigned long long* stats, uint32_t nblocks, uint32_t iters, unsigned long long budget_ticks,
+                              hipStream_t s);
 hipError_t launch_score_table(int metric, float alpha, float beta, uint32_t a, uint32_t max_b,
                               uint32_t max_c, float* d_out, hipStream_t s);
 

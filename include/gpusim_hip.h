@@ -322,6 +322,15 @@ int gsim_db_get_timing(gsim_db* db, gsim_timing* out); /* synchronises the strea
  * bin-ranked emission handed it back, 32 large k: routed around those by a back-off.  For the tests that compare the pipelined
  * entry point with one query at a time. */
 int gsim_debug_query_flags(gsim_db* db, uint8_t* flags, uint32_t n, uint32_t* written);
+/* Litmus tests of the hardware behaviours the single launch rests on, with its own instructions (gsim_litmus.hip; nothing of the product
+ * calls them).  test 1: aligned 16-byte write-through (sc1) stores are seen whole by 16-byte sc1 loads of another workgroup; test 2: a
+ * 16-byte system-scope store into pinned host memory is whole for a host that polls one of its words and then reads the others (how
+ * gsim_db_search reads a result header); test 3: entry then header from one lane -- how often a reader sees the header first, and that
+ * a re-read always finds the entry; test 4: the same with the product's shape (entries stored by another wave, a workgroup barrier, then
+ * the header).  `workgroups` even (pairs of writer + reader; test 2: one writer each), `iterations` stores per slot
+ * (64 slots per pair; test 2: one per workgroup).  stats[8] = {loads (test 2: host observations), torn values, headers seen, entries
+ * behind their header at the first read, entries that never caught up, re-reads, workgroups that ran out of time, stores}. */
+int gsim_debug_litmus(int device, int test, uint32_t workgroups, uint32_t iterations, unsigned long long* stats);
 /* score of every (common, popc_db) pair for a query of popcount a, computed ON
  * THE DEVICE with the scan kernel's arithmetic: out[c * (max_b+1) + b].  Used
  * by the parity tests to pin the f32 divide bit for bit. */
