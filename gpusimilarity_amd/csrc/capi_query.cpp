@@ -619,7 +619,8 @@ bool lanes_apply(const gsim_db* db, const Shard& s, uint32_t k, uint32_t nq)
     if (db->knobs.each_lanes < 2 || nq < 4 || s.stream != s.own_stream || s.d_dbg || db->knobs.fused_debug) return false;
     if (s.nrows * s.W * 4ull > static_cast<uint64_t>(db->knobs.each_lanes_max_mb) << 20) return false;
     if (s.nrows < 65536) return false; // (tiny tables: the half grid is no smaller than the whole one)
-    return fused_applies(db, s, k) && !fused_publish_applies(db, s, k);
+    if (fused_publish_applies(db, s, k)) return db->knobs.each_lanes_publish != 0; // (large k: the launch publishes, two small kernels rank -- per lane)
+    return fused_applies(db, s, k);
 }
 
 // gsim_db_search_each on a single-shard handle: the queries still run strictly one after the other on the GPU (one
@@ -639,7 +640,9 @@ int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uin
     std::vector<char> use_lanes(nsh, 0);
     for (size_t i = 0; i < nsh; i++) {
         Shard& s = db->shards[i];
-        if (s.nrows && lanes_apply(db, s, k, nq) && ensure_lanes(db, s) == GSIM_OK) use_lanes[i] = 1; // (no lanes: the shard itself, as before)
+        if (s.nrows && lanes_apply(db, s, k, nq) && ensure_lanes(db, s) == GSIM_OK &&
+            (fused_applies(db, s.lanes[0], k) || fused_publish_applies(db, s.lanes[0], k))) // (the half grid's own geometry must carry the route too)
+            use_lanes[i] = 1; // (no lanes: the shard itself, as before)
     }
     auto pipe_blocks = [&](Shard& s) -> int {
         GSIM_HIP(set_device(s.device));

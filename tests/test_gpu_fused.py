@@ -300,6 +300,18 @@ for n, W, kind in ((700_001, 32, 0), (40_000, 32, 0), (300_000, 32, 2), (900_000
     tm = t.timing()
     if W >= 32 and kind == 0:
         assert tm["handed_back"] == 0, tm
+    if n == 700_001:
+        # the enqueue-only route (gsim_db_search_device: the RCCL route's shard step) has no host-side checksum behind it (ADVICE r05):
+        # its blocks under the same forced path
+        import torch
+        for k in (1000, 8192):
+            out = torch.zeros(capi.result_block_bytes(k), dtype=torch.uint8, device="cuda:0")
+            for i in range(6):
+                t.search_device(qs[i], k, out.data_ptr(), 0.0)
+                torch.cuda.synchronize()
+                hits, approx, _ = capi.parse_result_block(out.cpu().numpy().tobytes(), k)
+                want, wap = O.search(qs[i], db, k, 0.0, nthreads=8)
+                assert approx == wap and (hits["row"] == want["row"]).all() and (hits["score"].view(np.uint32) == want["score"].view(np.uint32)).all(), (k, i)
     t.close()
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
