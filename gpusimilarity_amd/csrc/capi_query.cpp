@@ -301,7 +301,11 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             // The caller reads the block: a hand-back costs a second run, not a wrong answer -- so the finalists are placed by coarse
             // bin and ranked inside their bins (two launches; the radix select + gather + sort are four and a gap).  Tables whose
             // top bins hold more than kBinRankCap rows (ties) hand that back: the next large-k queries take the radix tail.
-            if (db->knobs.largek_binrank && s.binrank_skip == 0 && k <= static_cast<uint32_t>(db->knobs.largek_binrank_max_k)) {
+            // (128 / 256-bit rows score coarsely: from k ~ 10 000 on a top bin holds more than the emission takes -- 7 % of the k = 32 768
+            // queries of an 8 M x 128-bit soak were handed back for it; their large k goes straight to the radix tail)
+            const uint32_t binrank_max = (s.fgeo.lanes_per_row != 0 && s.fgeo.lanes_per_row <= 2) ? std::min<uint32_t>(8192u, static_cast<uint32_t>(db->knobs.largek_binrank_max_k))
+                                                                                                 : static_cast<uint32_t>(db->knobs.largek_binrank_max_k);
+            if (db->knobs.largek_binrank && s.binrank_skip == 0 && k <= binrank_max) {
                 GSIM_HIP(gsim::launch_fused_binsort(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.d_bincur, s.stream));
                 if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
                 GSIM_HIP(gsim::launch_binrank_emit(a, s.d_final, s.final_cap, s.d_bincur, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
@@ -312,7 +316,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
                 }
                 return record_slot_event(s, pipe_slot);
             }
-            if (s.binrank_skip && k <= static_cast<uint32_t>(db->knobs.largek_binrank_max_k)) {
+            if (s.binrank_skip && k <= binrank_max) {
                 s.binrank_skip--;
                 s.slot_why[pipe_slot] |= kQSkipPublish;
                 db->backoff_skips++;

@@ -370,7 +370,7 @@ def test_pipelined_queries_on_two_half_grid_lanes_match_the_oracle():
     half-grid lanes -- own stream, per-query state, regions and exchange buffer each, the same rows -- so one query's scan
     overlaps the other's selection (1 M rows: 39.6 -> 27.9 us per query).  Every result equals the oracle's, single queries of
     the same handle (whole grid) in between included; gsim_timing.lane_queries counts them; k above the single launch's own
-    ranking (the publishing route) and GSIM_EACH_LANES=0 do not use lanes."""
+    ranking (the publishing route) runs on the lanes too; GSIM_EACH_LANES=0 switches them off."""
     for n, kind, seed in ((1_000_003, 0, 0x1A9E5), (300_000, O.KIND_MORGAN, 0x1A9E6)):
         db = O.synth_rows_mt(seed, kind, 0, n, 32)
         t = make_table(db)
@@ -390,9 +390,13 @@ def test_pipelined_queries_on_two_half_grid_lanes_match_the_oracle():
             want, wap = O.search(qs[5], db, k, np.float32(cutoff), nthreads=16)
             assert int(ap[0]) == wap
             assert_hits_equal(h[0], want, "single n=%d k=%d" % (n, k))
-        bufs = t.make_search_buffers(len(qs), 5000)  # the publishing route: no lanes
+        bufs = t.make_search_buffers(len(qs), 5000)  # the publishing route (launch + binsort + binrank), per lane as well
         t.search_each_into(qs, 5000, bufs)
-        assert t.timing()["lane_queries"] == lane_q
+        assert t.timing()["lane_queries"] == lane_q + len(qs)
+        for i in (0, 7, 36):
+            want, wap = O.search(qs[i], db, 5000, np.float32(0.0), nthreads=16)
+            assert int(bufs[2][i]) == wap
+            assert_hits_equal(bufs[0][i, :bufs[1][i]], want, "lanes, publishing route n=%d q=%d" % (n, i))
         assert t.timing()["handed_back"] == 0
         t.close()
     code = ("import sys; sys.path.insert(0, %r); import numpy as np; from gpusimilarity_amd import capi\n"
