@@ -405,3 +405,24 @@ def test_pipelined_queries_on_two_half_grid_lanes_match_the_oracle():
             "t.search_each_into(q, 100, b); assert t.timing()['lane_queries'] == 0; assert (b[0][:, 0]['row'] == np.arange(16)).all(); print('ok')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSIM_EACH_LANES="0"), capture_output=True, timeout=300)
     assert out.returncode == 0 and b"ok" in out.stdout, out.stderr.decode()[-2000:]
+
+
+@pytest.mark.parametrize("W,n,k", [(8, 3_000_000, 12000), (4, 4_000_000, 9000), (32, 2_000_000, 70000), (32, 400_000, 20000)])
+def test_enqueue_only_large_k_through_the_publishing_launch(W, n, k):
+    """Round 6 widened the publishing launch (k up to 100 000, 128 / 256-bit rows behind the sample kernel's seed, short tables):
+    the enqueue-only route (gsim_db_search_device: fused publish -> hand-off -> radix select -> sort, the gated classic kernels
+    behind it) on those shapes, blocks compared with the oracle."""
+    import torch
+    db = O.synth_rows_mt(0x6A11 + W, 0, 0, n, W)
+    t = make_table(db)
+    out = torch.zeros(capi.result_block_bytes(k), dtype=torch.uint8, device="cuda:0")
+    for i, cutoff in ((3, 0.0), (11, 0.0), (12, 0.05)):
+        q = db[O.query_row(i, n)]
+        t.search_device(q, k, out.data_ptr(), cutoff)
+        torch.cuda.synchronize()
+        hits, approx, _ = capi.parse_result_block(out.cpu().numpy().tobytes(), k)
+        want, wap = O.search(q, db, k, np.float32(cutoff), nthreads=16)
+        assert approx == wap
+        assert_hits_equal(hits, want, "device block W=%d n=%d k=%d cutoff=%g" % (W, n, k, cutoff))
+    assert t.timing()["large_k_single_scan"] >= 3
+    t.close()
