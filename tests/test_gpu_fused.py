@@ -407,7 +407,7 @@ def test_pipelined_queries_on_two_half_grid_lanes_match_the_oracle():
     assert out.returncode == 0 and b"ok" in out.stdout, out.stderr.decode()[-2000:]
 
 
-@pytest.mark.parametrize("W,n,k", [(8, 3_000_000, 12000), (4, 4_000_000, 9000), (32, 2_000_000, 70000), (32, 400_000, 20000)])
+@pytest.mark.parametrize("W,n,k", [(8, 3_000_000, 12000), (4, 4_000_000, 9000), (32, 2_400_000, 70000), (32, 400_000, 20000)])  # (k above 65 536: at least 32 rows per hit)
 def test_enqueue_only_large_k_through_the_publishing_launch(W, n, k):
     """Round 6 widened the publishing launch (k up to 100 000, 128 / 256-bit rows behind the sample kernel's seed, short tables):
     the enqueue-only route (gsim_db_search_device: fused publish -> hand-off -> radix select -> sort, the gated classic kernels
