@@ -118,15 +118,19 @@ struct Shard {
     uint32_t* h_done = nullptr; // single-launch path: pinned words, one per pipeline slot (since round 3 only their address is used: "the caller polls the header")
     uint32_t epoch = 0;
     uint32_t pub_tag = 0;           // the last single launch's FusedArgs::pub_tag
-    bool slot_fused[kPipe] = {};    // the synchronous enqueue of the slot went through the single-launch path ...
-    uint32_t slot_epoch[kPipe] = {}; // ... with this epoch
-    hipEvent_t slot_ev[kPipe] = {}; // recorded behind the last kernel of a synchronous enqueue that is not the single launch's own: its
-    bool slot_ev_set[kPipe] = {};   // caller waits for THIS query, not for the queries enqueued behind it on the stream
-    bool slot_publish[kPipe] = {};  // the synchronous enqueue of the slot was a large-k query scanned by the single launch (header flag 2: run it again)
-    bool slot_binrank[kPipe] = {};  // ... and ranked by coarse bin (a hand-back sends the next ones to the radix tail)
-    bool slot_rerun[kPipe] = {};    // ... but behind a launch that left the per-query state dirty: not to be trusted, run again
-    bool slot_inflight[kPipe] = {}; // a synchronous enqueue of the slot has not been finished yet (whatever route it took)
-    uint8_t slot_why[kPipe] = {};   // kQ* bits: how the slot's query was routed and why it was run again (gsim_debug_query_flags)
+    // One synchronous query in flight on this shard (gsim_db_search: slot 0; gsim_db_search_each: up to kPipe, slot = query mod kPipe):
+    // how it was enqueued, what its caller waits for, and why it had to be run again.
+    struct PipeSlot {
+        bool inflight = false;  // enqueued by a synchronous caller and not finished yet (whatever route it took)
+        bool fused = false;     // it went through the single launch, which announces itself in the block's header ...
+        uint32_t epoch = 0;     // ... with this epoch
+        bool publish = false;   // a large-k query scanned by the publishing launch (header flag 2: run it again)
+        bool binrank = false;   // ... and ranked by coarse bin (a hand-back sends the next ones to the radix tail)
+        hipEvent_t ev = nullptr; // recorded behind the last kernel of an enqueue that is not the single launch's own: the caller waits
+        bool ev_set = false;    // for THIS query, not for the queries enqueued behind it on the stream
+        bool rerun = false;     // it ran behind a launch that left the per-query state dirty: not to be trusted, run again
+        uint8_t why = 0;        // kQ* bits: how it was routed and why it was run again (gsim_debug_query_flags)
+    } slot[kPipe];
     char* h_pipe = nullptr;          // kPipe pinned result blocks (gsim_db_search_each)
     size_t h_pipe_block = 0;
     // Tables whose scores tie heavily (narrow or very sparse fingerprints) make the single-launch path hand every
@@ -246,7 +250,7 @@ inline uint32_t popcount_words(const uint32_t* q, uint32_t W)
 }
 
 enum QueryMode { kAuto = 0, kClassic = 1 };
-// Per-query record of the synchronous routes (Shard::slot_why -> gsim_db::query_flags -> gsim_debug_query_flags)
+// Per-query record of the synchronous routes (Shard::PipeSlot::why -> gsim_db::query_flags -> gsim_debug_query_flags)
 constexpr uint8_t kQHandedBack = 1;   // the single launch ran the query and handed it back itself (gsim_timing.handed_back counts these)
 constexpr uint8_t kQRerunBehind = 2;  // run again because a launch ahead of it on the stream ended without closing its query
 constexpr uint8_t kQTorn = 4;         // run again because its block's checksum never matched

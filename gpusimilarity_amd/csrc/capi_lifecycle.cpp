@@ -122,8 +122,8 @@ int free_shard(Shard& s)
     if (s.d_large) (void) hipFree(s.d_large);
     if (s.d_lk) (void) hipFree(s.d_lk);
     if (s.d_bincur) (void) hipFree(s.d_bincur);
-    for (auto& e : s.slot_ev)
-        if (e) (void) hipEventDestroy(e);
+    for (auto& sl : s.slot)
+        if (sl.ev) (void) hipEventDestroy(sl.ev);
     if (s.d_pub) (void) hipFree(s.d_pub);
     if (s.d_hdr) (void) hipFree(s.d_hdr);
     if (s.d_summ) (void) hipFree(s.d_summ);

@@ -109,9 +109,10 @@ uint32_t next_pub_tag(Shard& s)
 
 int record_slot_event(Shard& s, uint32_t pipe_slot)
 {
-    if (!s.slot_ev[pipe_slot]) GSIM_HIP(hipEventCreateWithFlags(&s.slot_ev[pipe_slot], hipEventDisableTiming));
-    GSIM_HIP(hipEventRecord(s.slot_ev[pipe_slot], s.stream));
-    s.slot_ev_set[pipe_slot] = true;
+    Shard::PipeSlot& sl = s.slot[pipe_slot];
+    if (!sl.ev) GSIM_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    GSIM_HIP(hipEventRecord(sl.ev, s.stream));
+    sl.ev_set = true;
     return GSIM_OK;
 }
 
@@ -130,6 +131,7 @@ int record_slot_event(Shard& s, uint32_t pipe_slot)
 int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
                        float beta, uint32_t row_base, void* out, bool caller_syncs, QueryMode mode, uint32_t pipe_slot)
 {
+    Shard::PipeSlot& sl = s.slot[pipe_slot]; // (only touched for synchronous callers)
     GSIM_HIP(set_device(s.device));
     if (s.state_dirty) { // a previous enqueue failed half way: the per-query state may not be zero
         GSIM_HIP(hipMemsetAsync(s.d_state, 0, offsetof(gsim::QueryState, redo_why), s.stream)); // (the per-query part)
@@ -204,13 +206,13 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         ev = &s.ev[3 * s.ev_used];
     }
     if (caller_syncs) {
-        s.slot_fused[pipe_slot] = false;
-        s.slot_publish[pipe_slot] = false;
-        s.slot_binrank[pipe_slot] = false;
-        s.slot_ev_set[pipe_slot] = false;
-        s.slot_rerun[pipe_slot] = false; // (a slot is enqueued again only after it was finished: a flag still set here is stale -- ADVICE r05)
-        s.slot_inflight[pipe_slot] = true;
-        if (mode == kAuto) s.slot_why[pipe_slot] = why; // (a re-run, kClassic, keeps what the first run recorded)
+        sl.fused = false;
+        sl.publish = false;
+        sl.binrank = false;
+        sl.ev_set = false;
+        sl.rerun = false; // (a slot is enqueued again only after it was finished: a flag still set here is stale -- ADVICE r05)
+        sl.inflight = true;
+        if (mode == kAuto) sl.why = why; // (a re-run, kClassic, keeps what the first run recorded)
     }
     if (fused) {
         gsim::FusedArgs f{};
@@ -254,8 +256,8 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
         if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
         if (caller_syncs) {
-            s.slot_fused[pipe_slot] = true;
-            s.slot_epoch[pipe_slot] = f.epoch;
+            sl.fused = true;
+            sl.epoch = f.epoch;
             if (ev) {
                 GSIM_HIP(hipEventRecord(ev[2], s.stream));
                 s.ev_used++;
@@ -297,7 +299,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
         GSIM_HIP(gsim::launch_fused(a, s.fgeo, f, s.stream));
         db->large_k_published++;
         if (caller_syncs) {
-            s.slot_publish[pipe_slot] = true;
+            sl.publish = true;
             // The caller reads the block: a hand-back costs a second run, not a wrong answer -- so the finalists are placed by coarse
             // bin and ranked inside their bins (two launches; the radix select + gather + sort are four and a gap).  Tables whose
             // top bins hold more than kBinRankCap rows (ties) hand that back: the next large-k queries take the radix tail.
@@ -309,7 +311,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
                 GSIM_HIP(gsim::launch_fused_binsort(a, f, s.fgeo.nwaves / 4, s.d_final, s.final_cap, s.d_bincur, s.stream));
                 if (ev) GSIM_HIP(hipEventRecord(ev[1], s.stream));
                 GSIM_HIP(gsim::launch_binrank_emit(a, s.d_final, s.final_cap, s.d_bincur, s.d_lk, row_base, s.nrows, 1u, out, s.stream));
-                s.slot_binrank[pipe_slot] = true;
+                sl.binrank = true;
                 if (ev) {
                     GSIM_HIP(hipEventRecord(ev[2], s.stream));
                     s.ev_used++;
@@ -318,7 +320,7 @@ int enqueue_query_impl(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k,
             }
             if (s.binrank_skip && k <= binrank_max) {
                 s.binrank_skip--;
-                s.slot_why[pipe_slot] |= kQSkipPublish;
+                sl.why |= kQSkipPublish;
                 db->backoff_skips++;
             }
         }
@@ -414,37 +416,38 @@ int wait_stream(hipStream_t st)
 int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, float cutoff, int metric, float alpha,
                       float beta, uint32_t row_base, void* out, uint32_t pipe_slot)
 {
-    s.slot_inflight[pipe_slot] = false;
+    Shard::PipeSlot& sl = s.slot[pipe_slot];
+    sl.inflight = false;
     const bool backoff = db->knobs.fused_backoff != 0;
     auto run_again = [&]() -> int { // the four-kernel pipeline, waited for
         int rc = enqueue_query(db, s, query, k, cutoff, metric, alpha, beta, row_base, out, true, kClassic, pipe_slot);
         if (rc == GSIM_OK) rc = wait_stream(s.stream);
-        s.slot_inflight[pipe_slot] = false;
-        s.slot_ev_set[pipe_slot] = false;
+        sl.inflight = false;
+        sl.ev_set = false;
         return rc;
     };
-    if (s.slot_rerun[pipe_slot]) {
+    if (sl.rerun) {
         // Enqueued behind a single launch that ended without closing its query (below): this one ran on per-query state
         // nobody had re-zeroed -- WHATEVER route it took (a classic or publishing query behind the failed launch
         // shared that state too) -- and a block's checksum only covers the block's own hits: run it again.  The stream had
         // drained when the flag was set, so its own kernels are over.
-        s.slot_rerun[pipe_slot] = false;
-        s.slot_fused[pipe_slot] = s.slot_publish[pipe_slot] = s.slot_binrank[pipe_slot] = false;
-        s.slot_why[pipe_slot] |= kQRerunBehind;
+        sl.rerun = false;
+        sl.fused = sl.publish = sl.binrank = false;
+        sl.why |= kQRerunBehind;
         db->rerun_behind++;
         return run_again();
     }
-    if (!s.slot_fused[pipe_slot]) {
-        int rc = s.slot_ev_set[pipe_slot] ? wait_event(s.slot_ev[pipe_slot]) : wait_stream(s.stream);
-        s.slot_ev_set[pipe_slot] = false;
-        const bool back = rc == GSIM_OK && s.slot_publish[pipe_slot] && (static_cast<const gsim_result_header*>(out)->flags & 2u);
-        if (rc == GSIM_OK && s.slot_publish[pipe_slot] && !back) {
+    if (!sl.fused) {
+        int rc = sl.ev_set ? wait_event(sl.ev) : wait_stream(s.stream);
+        sl.ev_set = false;
+        const bool back = rc == GSIM_OK && sl.publish && (static_cast<const gsim_result_header*>(out)->flags & 2u);
+        if (rc == GSIM_OK && sl.publish && !back) {
             s.publish_streak = 0;
-            if (s.slot_binrank[pipe_slot]) s.binrank_streak = 0;
+            if (sl.binrank) s.binrank_streak = 0;
         }
         if (back) {
             // large k, scanned by the single launch, handed back (heavy ties): the emission cleared the per-query state
-            if (s.slot_binrank[pipe_slot]) {
+            if (sl.binrank) {
                 // ties in the top bins, most likely: the next ones by the radix tail -- 16, 32, ... 1024 of them while it keeps
                 // happening (a fixed 16 made a tie-heavy table pay a second scan every 17th large-k query for good)
                 if (backoff) s.binrank_skip = 16u << s.binrank_streak;
@@ -453,17 +456,17 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
                 s.publish_streak = s.publish_streak < 6 ? s.publish_streak + 1 : 6;
                 if (backoff) s.publish_skip = 1u << s.publish_streak;
             }
-            s.slot_why[pipe_slot] |= kQPublishBack;
+            sl.why |= kQPublishBack;
             db->rerun_publish++;
-            s.slot_publish[pipe_slot] = false;
+            sl.publish = false;
             return run_again();
         }
-        s.slot_publish[pipe_slot] = false;
+        sl.publish = false;
         return rc;
     }
-    s.slot_fused[pipe_slot] = false;
+    sl.fused = false;
     volatile uint32_t* flag = &static_cast<gsim_result_header*>(out)->flags; // (flags | epoch << 8: one 16-byte store with the rest of the header)
-    const uint32_t want = s.slot_epoch[pipe_slot];
+    const uint32_t want = sl.epoch;
     bool done = false;
     for (uint64_t spins = 0;; spins++) {
         if ((*flag >> 8) == want) {
@@ -531,10 +534,10 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
     if (done && !torn) {
         s.redo_streak = s.redo_streak < 6 ? s.redo_streak + 1 : 6;
         if (backoff && s.redo_streak >= 2) s.fused_skip = 1u << s.redo_streak;
-        s.slot_why[pipe_slot] |= kQHandedBack;
+        sl.why |= kQHandedBack;
         db->rerun_own++;
     } else if (torn) {
-        s.slot_why[pipe_slot] |= kQTorn;
+        sl.why |= kQTorn;
         db->rerun_torn++;
     }
     if (!done) {
@@ -542,10 +545,10 @@ int finish_query_sync(gsim_db* db, Shard& s, const uint32_t* query, uint32_t k, 
         // the stream has drained, so they have all run already, on that state -- are run again, whichever
         // route they took (every slot in flight, not only the single launch's)
         s.state_dirty = true;
-        s.slot_why[pipe_slot] |= kQRerunBehind;
+        sl.why |= kQRerunBehind;
         db->rerun_behind++;
         for (uint32_t j = 0; j < static_cast<uint32_t>(kPipe); j++)
-            if (j != pipe_slot && s.slot_inflight[j]) s.slot_rerun[j] = true;
+            if (j != pipe_slot && s.slot[j].inflight) s.slot[j].rerun = true;
     }
     // handed back: the per-query state is zero again (the last selector reset it), `redo` is set
     return run_again();
@@ -574,7 +577,7 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
         int rc = finish_query_sync(db, s, query, k, cutoff, metric, alpha, beta,
                                    db->row_base + static_cast<uint32_t>(s.first_row), s.h_result);
         if (rc != GSIM_OK) return rc;
-        if (db->query_flags_at < db->query_flags.size()) db->query_flags[db->query_flags_at] |= s.slot_why[0];
+        if (db->query_flags_at < db->query_flags.size()) db->query_flags[db->query_flags_at] |= s.slot[0].why;
         const gsim_result_header* h = reinterpret_cast<const gsim_result_header*>(s.h_result);
         const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
         ap += h->approx;
@@ -696,7 +699,7 @@ int search_each_pipelined(gsim_db* db, const uint32_t* queries, uint32_t nq, uin
             const int rc = finish_query_sync(db, s, queries + static_cast<size_t>(done) * db->W, k, cutoff, metric, alpha, beta,
                                              db->row_base + static_cast<uint32_t>(s.first_row), out, slot);
             if (rc != GSIM_OK) return rc;
-            if (done < db->query_flags.size()) db->query_flags[done] |= s.slot_why[slot];
+            if (done < db->query_flags.size()) db->query_flags[done] |= s.slot[slot].why;
             const gsim_result_header* h = static_cast<const gsim_result_header*>(out);
             const gsim_hit* hh = reinterpret_cast<const gsim_hit*>(h + 1);
             ap += h->approx;
