@@ -53,6 +53,7 @@ gsim::Knobs read_knobs()
     k.publish_min_rows_per_k = std::max(env_value("GSIM_PUBLISH_MIN_ROWS_PER_K", k.publish_min_rows_per_k), 0);
     k.each_pipeline = env_value("GSIM_EACH_PIPELINE", k.each_pipeline);
     k.each_lanes = env_value("GSIM_EACH_LANES", k.each_lanes);
+    k.each_lanes_share = env_value("GSIM_EACH_LANES_SHARE", k.each_lanes_share);
     k.each_lanes_publish = env_value("GSIM_EACH_LANES_PUBLISH", k.each_lanes_publish);
     k.each_lanes_max_mb = env_value("GSIM_EACH_LANES_MAX_MB", k.each_lanes_max_mb);
     k.batch = env_value("GSIM_BATCH", k.batch);

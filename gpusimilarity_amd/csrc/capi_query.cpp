@@ -598,12 +598,12 @@ int search_one(gsim_db* db, const uint32_t* query, uint32_t k, float cutoff, int
 // stream / per-query state / regions / exchange buffer.
 int ensure_lanes(gsim_db* db, Shard& s)
 {
-    const int nl = db->knobs.each_lanes >= 4 ? 4 : 2; // (three 85-CU lanes were measured too: their grids hand queries back)
+    const int nl = std::min(std::max(db->knobs.each_lanes, 2), 4);
     if (!s.lanes.empty()) return GSIM_OK;
     s.lanes.resize(static_cast<size_t>(nl));
     for (auto& l : s.lanes) {
         l.device = s.device;
-        l.cu_share = nl;
+        l.cu_share = std::max(db->knobs.each_lanes_share, 1); // (the lanes' grids: the CUs divided by this -- not necessarily by the number of lanes)
         l.first_row = s.first_row;
         l.nrows = s.nrows;
         l.W = s.W;

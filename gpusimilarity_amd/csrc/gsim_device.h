@@ -177,6 +177,7 @@ struct Knobs {
     int largek_binrank = 1;          // GSIM_LARGEK_BINRANK      0: the published rows of a large-k query always go through the radix select + sort
     int each_pipeline = 1;           // GSIM_EACH_PIPELINE       0: gsim_db_search_each waits for every query before the next
     int each_lanes = 2;              // GSIM_EACH_LANES          2 (or 4): pipelined queries of small tables alternate between that many part-grid lanes; 0: never
+    int each_lanes_share = 2;        // GSIM_EACH_LANES_SHARE    a lane's grid is sized for the CUs divided by this
     int each_lanes_publish = 1;      // GSIM_EACH_LANES_PUBLISH  0: large k (the publishing route) stays on one stream
     int each_lanes_max_mb = 4096;    // GSIM_EACH_LANES_MAX_MB   ... only shards of at most this many MB do (larger ones are HBM-bound: nothing to overlap)
     int batch = 1;                   // GSIM_BATCH               0: no shared table passes

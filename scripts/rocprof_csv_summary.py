@@ -55,12 +55,14 @@ def pmc(d):
 
 def timeline(d, sub, n=3):
     files = find(d, "*kernel_trace.csv")
-    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(files[0]))))
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", r.get("Stream_Id", "")))
+                   for r in csv.DictReader(open(files[0]))))
     idx = [i for i, r in enumerate(rows) if sub in r[2]]
     i0, i1 = idx[-n], idx[-1]
     t0, prev = rows[i0][0], None
-    for s, e, name in rows[i0:i1 + 1]:
-        print("%-50s start %9.1f us  dur %8.1f us  gap_before %6.1f us" % (name[:50], (s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
+    for s, e, name, q in rows[i0:i1 + 1]:
+        # (gap_before < 0: the launch started while the previous one -- on another queue -- was still running)
+        print("%-50s queue %-4s start %9.1f us  end %9.1f us  dur %8.1f us  gap_before %6.1f us" % (name[:50], q, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0.0))
         prev = e
 
 

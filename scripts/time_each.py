@@ -15,7 +15,7 @@ BITS = int(os.environ.get("TE_BITS", "1024"))
 ks = [int(x) for x in os.environ.get("TE_K", "1000").split(",")]
 kinds = os.environ.get("TE_KINDS", "sparse,morgan").split(",")
 sizes = [int(x) for x in sys.argv[1:]] or [100_000, 300_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000]
-label = " ".join("%s=%s" % (e, os.environ[e]) for e in ("GSIM_EACH_LANES", "GSIM_EACH_LANES_MAX_MB", "TE_TIMING", "GSIM_FUSED_PUBLISH_MAX_K", "GSIM_LARGEK_BINRANK", "GSIM_PUBLISH_NARROW", "TE_BITS", "GSIM_EACH_LANES_PUBLISH") if e in os.environ) or "default"
+label = " ".join("%s=%s" % (e, os.environ[e]) for e in ("GSIM_EACH_LANES", "GSIM_EACH_LANES_SHARE", "GSIM_EACH_LANES_MAX_MB", "TE_TIMING", "GSIM_FUSED_PUBLISH_MAX_K", "GSIM_LARGEK_BINRANK", "GSIM_PUBLISH_NARROW", "TE_BITS", "GSIM_EACH_LANES_PUBLISH") if e in os.environ) or "default"
 for n in sizes:
     for kn in kinds:
         kind = {"sparse": capi.SYNTH_SPARSE, "morgan": capi.SYNTH_MORGAN}[kn]
